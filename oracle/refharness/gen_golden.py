@@ -1,0 +1,225 @@
+#!/opt/conda/bin/python3.9
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (/root/reference/src/stripenn).
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 oracle/refharness/gen_golden.py
+
+Environment pinned by this interpreter: python 3.9.7, numpy 1.26.4, scipy 1.7.1,
+scikit-image 0.18.3, pandas 2.3.3, joblib 1.1.0, glibc 2.35.  cv2 is absent: the three OpenCV
+calls are served by oracle/refharness/standins/cv2.py (documented semantics, "parity unpinned").
+cooler is absent: stripenn_amd.synth.SynthSelector implements cooler's fetch extent rule.
+
+The fixtures hold only DATA: seeds/parameters of the synthetic inputs, and the reference's
+outputs (bit-packed masks, integer arrays, float arrays or their sha256).  No reference source.
+"""
+import sys, os, hashlib, io, warnings
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(HERE, 'standins'))
+sys.path.insert(0, '/root/reference/src')
+sys.path.insert(0, REPO)
+warnings.filterwarnings('ignore')
+import contextlib
+import numpy as np
+import pandas as pd
+import random
+
+from stripenn_amd import synth
+import stripenn.getStripe as gs_mod
+from stripenn import ImageProcessing as ip_mod
+import cv2 as cv_standin
+import scipy.ndimage as ndi
+from scipy.ndimage import filters as ndi_filters
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+def sha(a):
+    a = np.ascontiguousarray(a)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def pack(mask):
+    return np.packbits(np.asarray(mask).astype(bool), axis=1)
+
+
+@contextlib.contextmanager
+def quiet():
+    so = sys.stdout
+    se = sys.stderr
+    sys.stdout = io.StringIO()
+    sys.stderr = io.StringIO()
+    try:
+        yield
+    finally:
+        sys.stdout = so
+        sys.stderr = se
+
+
+class Tap:
+    """Records the inputs/outputs of the third-party / helper calls inside StripeSearch."""
+
+    def __init__(self):
+        self.reset()
+        self._canny = gs_mod.feature.canny
+        self._vl = ip_mod.verticalLine
+        self._blk = ip_mod.block
+        self._cvt = cv_standin.cvtColor
+
+    def reset(self):
+        self.gray = []; self.edges = []; self.vert = []; self.blocks = []; self.sigma = None
+
+    def install(self):
+        tap = self
+
+        def canny(img, sigma=1.0, **kw):
+            tap.sigma = sigma
+            out = tap._canny(img, sigma=sigma, **kw)
+            tap.edges.append(np.array(out, dtype=bool))
+            tap.blocks.append([])
+            return out
+
+        def vl(M, L=60, H=120):
+            out = tap._vl(M, L=L, H=H)
+            tap.vert.append(np.array(out))
+            return out
+
+        def blk(mat, c):
+            t, e = tap._blk(mat, c)
+            tap.blocks[-1].append((int(t), int(e)))
+            return t, e
+
+        def cvt(src, code):
+            out = tap._cvt(src, code)
+            tap.gray.append(np.array(out))
+            return out
+        gs_mod.feature.canny = canny
+        ip_mod.verticalLine = vl
+        ip_mod.block = blk
+        cv_standin.cvtColor = cvt
+
+    def uninstall(self):
+        gs_mod.feature.canny = self._canny
+        ip_mod.verticalLine = self._vl
+        ip_mod.block = self._blk
+        cv_standin.cvtColor = self._cvt
+
+
+def canny_internals(gray, sigma):
+    """Intermediate arrays of skimage.feature.canny recomputed with the same scipy calls."""
+    from skimage.filters import gaussian
+    from skimage import img_as_float
+    mask = np.ones(gray.shape, dtype=bool)
+    fs = lambda x: img_as_float(gaussian(x, sigma, mode='constant'))
+    bleed = fs(mask.astype(float))
+    sm = fs(gray) / (bleed + np.finfo(float).eps)
+    js = ndi.sobel(sm, axis=1)
+    is_ = ndi.sobel(sm, axis=0)
+    mag = np.hypot(is_, js)
+    return sm, is_, js, mag
+
+
+def make_obj(sel, names, sizes, resol, core=1, canny=2.0, minH=10, maxW=8, bfilter=3, seed=123456789):
+    return gs_mod.getStripe(sel, resol, minH, maxW, canny, list(names), list(names), np.array(sizes),
+                            np.array(sizes), core, bfilter, seed)
+
+
+class Info:
+    pass
+
+
+def stage_goldens():
+    resol = 5000
+    nbins = 1200
+    names, sizes, sel = synth.make_genome([nbins * resol - 1234], resol, seed0=16, names=['chr7'])
+    obj = make_obj(sel, names, sizes, resol)
+    info = Info(); info.chromsizes = pd.Series(sizes, index=names)
+    with quiet():
+        MP = obj.getQuantile_original(info, names, [0.95, 0.99])
+    tap = Tap()
+    cases = []
+    # (frame idx, M, label)
+    plan = [(0, MP['chr7'][1], 'first_frame_S300'), (1, MP['chr7'][1], 'regular'), (3, MP['chr7'][0], 'mp95'),
+            (5, MP['chr7'][1], 'last_frame'), (2, MP['chr7'][1] / 8.0, 'saturated'), (2, 1e9, 'no_edges')]
+    store = {'resol': resol, 'nbins': nbins, 'seed0': 16, 'chromsize': int(sizes[0]),
+             'MP': MP['chr7'], 'bvals': np.arange(0.5, 1.01, 0.1)}
+    for ci, (idx, M, label) in enumerate(plan):
+        # replicate search_frame's window/compaction by calling the reference's extract on one frame:
+        # we call StripeSearch directly with the same D the reference builds (getStripe.py:794-822)
+        rowsize = int(np.ceil(sizes[0] / resol))
+        start = idx * 200 - 100
+        end = (idx + 1) * 200 + 99
+        if end >= rowsize:
+            end = rowsize - 1
+        if idx == 0:
+            start = 0
+        fs = end - start + 1
+        start_array = [(start + j) * resol + 1 for j in range(fs)]
+        end_array = [s + resol - 1 for s in start_array]
+        if end_array[-1] >= sizes[0]:
+            end_array[-1] = int(sizes[0])
+        locus = 'chr7:%d-%d' % (start_array[0], end_array[-1])
+        D = sel.fetch(locus, locus)
+        D = gs_mod.nantozero(D)
+        nz = np.where(np.sum(D, axis=0) != 0)[0]
+        S = len(nz)
+        D = D[np.ix_(nz, nz)]
+        sa = [start_array[s] for s in nz]
+        ea = [end_array[s] for s in nz]
+        tap.reset(); tap.install()
+        raw = {}
+        orig_rr = gs_mod.getStripe.RemoveRedundant
+
+        def rr(self, df, by):
+            raw['df'] = df.copy()
+            return orig_rr(self, df, by)
+        gs_mod.getStripe.RemoveRedundant = rr
+        try:
+            with quiet():
+                res = obj.StripeSearch(D, idx, start, end, M, 0.99, 'chr7', S, sa, ea)
+        finally:
+            gs_mod.getStripe.RemoveRedundant = orig_rr
+            tap.uninstall()
+        df = raw['df']
+        p = 'c%d_' % ci
+        store[p + 'label'] = label; store[p + 'idx'] = idx; store[p + 'M'] = M; store[p + 'S'] = S
+        store[p + 'start'] = start; store[p + 'end'] = end; store[p + 'nz'] = nz.astype(np.int32)
+        store[p + 'D_sha'] = sha(D)
+        nb = len(tap.gray)
+        store[p + 'gray_sha'] = np.array([sha(g) for g in tap.gray])
+        store[p + 'gray_row'] = np.stack([g[S // 2] for g in tap.gray])  # one full row per b
+        store[p + 'edges'] = np.stack([pack(e) for e in tap.edges])
+        store[p + 'vert'] = np.stack([pack(v) for v in tap.vert])
+        store[p + 'block'] = np.array(tap.blocks, dtype=np.int32)  # (nb, S, 2)
+        ints = [canny_internals(g, tap.sigma) for g in tap.gray]
+        store[p + 'smoothed_sha'] = np.array([sha(t[0]) for t in ints])
+        store[p + 'isobel_sha'] = np.array([sha(t[1]) for t in ints])
+        store[p + 'jsobel_sha'] = np.array([sha(t[2]) for t in ints])
+        store[p + 'mag_sha'] = np.array([sha(t[3]) for t in ints])
+        store[p + 'mag_row'] = np.stack([t[3][S // 2] for t in ints])
+        # raw records before the per-frame RemoveRedundant: x,y,w,h,total (order preserved)
+        store[p + 'rec_xywh'] = df[['x', 'y', 'h', 'w']].to_numpy(dtype=np.int64) if len(df) else np.zeros((0, 4), np.int64)
+        store[p + 'rec_total'] = df['total'].to_numpy(dtype=np.float64) if len(df) else np.zeros(0)
+        store[p + 'rec_pos'] = df[['pos1', 'pos2', 'pos3', 'pos4']].to_numpy(dtype=np.int64) if len(df) else np.zeros((0, 4), np.int64)
+        store[p + 'medpixel'] = float(df['medpixel'].iloc[0]) if len(df) else float(np.quantile(D[D > 0], 0.5))
+        store[p + 'kept_xywh'] = res[['x', 'y', 'h', 'w']].to_numpy(dtype=np.int64) if len(res) else np.zeros((0, 4), np.int64)
+        print('stage case', ci, label, 'S', S, 'records', len(df), 'kept', len(res), 'edges', [int(e.sum()) for e in tap.edges])
+        cases.append(label)
+    store['ncases'] = len(plan)
+    # gaussian weights exactly as scipy builds them (for sigma 2.0 and 2.5)
+    for sg in (2.0, 2.5):
+        r = int(4.0 * sg + 0.5)
+        store['gw_%s' % str(sg).replace('.', 'p')] = ndi_filters._gaussian_kernel1d(sg, 0, r)[::-1]
+    np.savez_compressed(os.path.join(OUT, 'stages_chr7.npz'), **store)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['stages']
+    if 'stages' in which:
+        stage_goldens()
+    if 'e2e' in which:
+        from gen_golden_e2e import e2e_goldens
+        e2e_goldens()
