@@ -1,0 +1,748 @@
+// stp_phases.h -- per-phase bodies of the gfx950 kernels of libstripenn_hip.so.
+//
+// Every kernel in stripenn_hip.hip is a sequence of phases separated by workgroup barriers;
+// a phase is a strided loop `for (i = tid; i < N; i += nt)` over LDS / global arrays.  The phase
+// bodies live here as plain inline functions so that tests/emu (a g++ build used only by the
+// CPU test-suite) can replay one workgroup sequentially (tid = 0, nt = 1) and compare it with
+// the oracle before anything is launched on a GPU.  The product never runs this code on the
+// CPU: the only shipped entry points are the __global__ kernels.
+//
+// Arithmetic contract: one IEEE rounding per source-level operation (-ffp-contract=off), the
+// same operation order as the reference / pinned third-party routine cited at each function.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include <float.h>
+
+#if defined(__HIPCC__)
+#define STP_HD __host__ __device__ __forceinline__
+#else
+#define STP_HD static inline
+#endif
+
+typedef unsigned long long stp_u64;
+
+#define STP_PITCH 400 /* pixel pitch of per-image buffers */
+#define STP_NW 7      /* u64 words per bit-row (448 >= 400) */
+#define STP_RCAP 128  /* record slots per image */
+
+// ---------------------------------------------------------------------------------------------
+// tile geometry
+#define GT_Y 32
+#define GT_X 64
+#define GT_AMAX 3 /* bfilter <= 7 */
+#define CT_Y 32
+#define CT_X 64
+#define CT_RMAX 12
+
+struct stp_tile {
+    int S;        // compacted frame size
+    int ty0, tx0; // tile origin (image coordinates)
+};
+
+STP_HD int stp_refl101(int i, int n)
+{   // cv BORDER_REFLECT_101, valid for overshoot < n
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    if (i < 0) i = 0;
+    return i;
+}
+
+STP_HD int stp_refl(int i, int n)
+{   // scipy.ndimage mode='reflect' (d c b a | a b c d | d c b a), overshoot 1
+    if (i < 0) return -i - 1;
+    if (i >= n) return 2 * n - 1 - i;
+    return i;
+}
+
+// getStripe.py:889-895  blue = 255*(M-D)/M; <0 -> 0; /255; clip[0,1]
+STP_HD double stp_gplane_px(double D, double M)
+{
+    double t = 255.0 * (M - D);
+    t = t / M;
+    if (t < 0.0) t = 0.0;
+    double v = t / 255.0;
+    if (v < 0.0) v = 0.0;
+    if (v > 1.0) v = 1.0;
+    return v;
+}
+
+// ImageProcessing.py:15-23 with In=(0,b) Out=(0,1)
+STP_HD double stp_bright_px(double v, double b, double k)
+{
+    if (v <= 0.0) return 0.0;
+    if (v > b) return 1.0;
+    if (v > 0.0 && v <= b) return k * (v - 0.0) + 0.0;
+    return 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel A (k_gray): D -> g plane (LDS) -> per brightness: adj (LDS) -> mean blur -> grey f32
+// sg / sadj: (GT_Y + 2a) x (GT_X + 2a) doubles, origin (ty0 - a, tx0 - a)
+STP_HD void gray_p0(int tid, int nt, const double* __restrict__ band, int W, int hw, int64_t st,
+                    const int16_t* __restrict__ nz, stp_tile T, int a, double M, double* sg)
+{
+    const int hh = GT_Y + 2 * a, ww = GT_X + 2 * a;
+    for (int i = tid; i < hh * ww; i += nt) {
+        int yy = i / ww, xx = i - yy * ww;
+        int y = T.ty0 + yy - a, x = T.tx0 + xx - a;
+        double g = 0.0;
+        if (y < T.S + a && x < T.S + a) {
+            int ry = stp_refl101(y, T.S), rx = stp_refl101(x, T.S);
+            int oy = nz[ry], ox = nz[rx];
+            double v = band[(st + oy) * (int64_t)W + (ox - oy + hw)];
+            if (v != v) v = 0.0;                       // nantozero, getStripe.py:809
+            g = stp_gplane_px(v, M);
+        }
+        sg[i] = g;
+    }
+}
+
+STP_HD void gray_p1(int tid, int nt, int a, double b, const double* sg, double* sadj)
+{
+    const int hh = GT_Y + 2 * a, ww = GT_X + 2 * a;
+    const double k = (1.0 - 0.0) / (b - 0.0);          // ImageProcessing.py:30
+    for (int i = tid; i < hh * ww; i += nt) sadj[i] = stp_bright_px(sg[i], b, k);
+}
+
+STP_HD void gray_p2(int tid, int nt, stp_tile T, int a, const double* sadj, float* __restrict__ gray_img)
+{
+    const int ww = GT_X + 2 * a, bf = 2 * a + 1;
+    const double kv = 1.0 / (double)(bf * bf);         // np.ones((bf,bf))/(bf*bf), getStripe.py:908
+    double rb = 0.0;                                    // red plane: constant 1 through the same filter
+    for (int t = 0; t < bf * bf; t++) rb = rb + kv * 1.0;
+    if (rb < 0.0) rb = 0.0;
+    if (rb > 1.0) rb = 1.0;
+    const float r32 = (float)rb;
+    for (int i = tid; i < GT_Y * GT_X; i += nt) {
+        int yy = i / GT_X, xx = i - yy * GT_X;
+        int y = T.ty0 + yy, x = T.tx0 + xx;
+        if (y >= T.S || x >= T.S) continue;
+        double acc = 0.0;
+        for (int ky = 0; ky < bf; ky++)
+            for (int kx = 0; kx < bf; kx++) acc = acc + kv * sadj[(yy + ky) * ww + (xx + kx)];
+        if (acc < 0.0) acc = 0.0;
+        if (acc > 1.0) acc = 1.0;
+        float g32 = (float)acc;                        // np.float32(blur), getStripe.py:913
+        float v = r32 * 0.299f;                        // RGB2GRAY, left to right
+        v = v + g32 * 0.587f;
+        v = v + g32 * 0.114f;
+        gray_img[y * STP_PITCH + x] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel B (k_canny): grey -> Gaussian (f32 rounding after each axis) -> /bleed -> Sobel ->
+// hypot -> NMS -> class bit-planes.   skimage 0.18.3 _canny.py:53-280, scipy ni_filters.c.
+// LDS arrays (R = gaussian radius):
+//   sG  (CT_Y+2R+4) x GW  f32, GW = CT_X+2R+4, origin (ty0-R-2, tx0-R-2), 0 outside the image
+//   sV  (CT_Y+4)    x GW  f32, origin (ty0-2, tx0-R-2)          vertical pass
+//   sS  (CT_Y+4) x (CT_X+4) f64, origin (ty0-2, tx0-2)           smoothed
+//   sM  (CT_Y+2) x (CT_X+2) f64, origin (ty0-1, tx0-1)           magnitude
+STP_HD int ct_gw(int R) { return CT_X + 2 * R + 4; }
+
+STP_HD void canny_p0(int tid, int nt, const float* __restrict__ gray_img, stp_tile T, int R, float* sG)
+{
+    const int GH = CT_Y + 2 * R + 4, GW = ct_gw(R);
+    for (int i = tid; i < GH * GW; i += nt) {
+        int yy = i / GW, xx = i - yy * GW;
+        int y = T.ty0 - R - 2 + yy, x = T.tx0 - R - 2 + xx;
+        sG[i] = (y >= 0 && y < T.S && x >= 0 && x < T.S) ? gray_img[y * STP_PITCH + x] : 0.0f;
+    }
+}
+
+// NI_Correlate1D symmetric branch: o = x[0]*w[c]; for k = R..1: o += (x[-k] + x[k]) * w[c-k]
+STP_HD void canny_p1(int tid, int nt, stp_tile T, int R, const double* w, const float* sG, float* sV)
+{
+    const int VH = CT_Y + 4, GW = ct_gw(R);
+    for (int i = tid; i < VH * GW; i += nt) {
+        int yy = i / GW, xx = i - yy * GW;
+        int y = T.ty0 - 2 + yy, x = T.tx0 - R - 2 + xx;
+        float out = 0.0f;
+        if (y >= 0 && y < T.S && x >= 0 && x < T.S) {
+            const float* c = sG + (yy + R) * GW + xx;
+            double o = (double)c[0] * w[R];
+            for (int k = R; k >= 1; k--) o += ((double)c[-k * GW] + (double)c[k * GW]) * w[R - k];
+            out = (float)o;
+        }
+        sV[i] = out;
+    }
+}
+
+// bleed_over = gaussian(ones): column factor, then row pass on the constant row (f64)
+STP_HD double stp_bleed_v(int y, int S, int R, const double* w)
+{
+    double o = 1.0 * w[R];
+    for (int k = R; k >= 1; k--) {
+        double a = (y - k >= 0) ? 1.0 : 0.0, b = (y + k < S) ? 1.0 : 0.0;
+        o += (a + b) * w[R - k];
+    }
+    return o;
+}
+STP_HD double stp_bleed_h(double V, int x, int S, int R, const double* w)
+{
+    double o = V * w[R];
+    for (int k = R; k >= 1; k--) {
+        double a = (x - k >= 0) ? V : 0.0, b = (x + k < S) ? V : 0.0;
+        o += (a + b) * w[R - k];
+    }
+    return o;
+}
+
+// sB[0..VH) = column factor V(y); sB[VH..2VH) = full bleed for an interior x (x-R>=0, x+R<S)
+STP_HD void canny_p1b(int tid, int nt, stp_tile T, int R, const double* w, double* sB)
+{
+    const int VH = CT_Y + 4;
+    for (int i = tid; i < VH; i += nt) {
+        int y = T.ty0 - 2 + i;
+        double V = 0.0, BI = 0.0;
+        if (y >= 0 && y < T.S) {
+            V = stp_bleed_v(y, T.S, R, w);
+            if (T.S >= 2 * R + 1) BI = stp_bleed_h(V, R, T.S, R, w);
+        }
+        sB[i] = V;
+        sB[VH + i] = BI;
+    }
+}
+
+STP_HD void canny_p2(int tid, int nt, stp_tile T, int R, const double* w, const float* sV, const double* sB,
+                     double* sS)
+{
+    const int VH = CT_Y + 4, GW = ct_gw(R), SW = CT_X + 4;
+    for (int i = tid; i < VH * SW; i += nt) {
+        int yy = i / SW, xx = i - yy * SW;
+        int y = T.ty0 - 2 + yy, x = T.tx0 - 2 + xx;
+        double s = 0.0;
+        if (y >= 0 && y < T.S && x >= 0 && x < T.S) {
+            const float* c = sV + yy * GW + (xx + R);
+            double o = (double)c[0] * w[R];
+            for (int k = R; k >= 1; k--) o += ((double)c[-k] + (double)c[k]) * w[R - k];
+            float f = (float)o;
+            double bl = (x >= R && x + R < T.S) ? sB[VH + yy] : stp_bleed_h(sB[yy], x, T.S, R, w);
+            s = (double)f / (bl + DBL_EPSILON);       // _canny.py:49
+        }
+        sS[i] = s;
+    }
+}
+
+// glibc 2.35 sysdeps/ieee754/dbl-64/e_hypot.c (non-FMA kernel), what numpy's np.hypot calls.
+STP_HD double stp_hypot(double x, double y)
+{
+    x = fabs(x); y = fabs(y);
+    double ax = x < y ? y : x, ay = x < y ? x : y;
+    if (ax > 0x1p+511) {
+        if (ay <= ax * 0x1p-54) return ax + ay;
+        ax *= 0x1p-600; ay *= 0x1p-600;
+        double h = sqrt(ax * ax + ay * ay);
+        double t1, t2;
+        if (h <= 2.0 * ay) { double d = h - ay; t1 = ax * (2.0 * d - ax); t2 = (d - 2.0 * (ax - ay)) * d; }
+        else { double d = h - ax; t1 = 2.0 * d * (ax - 2.0 * ay); t2 = (4.0 * d - ay) * ay + d * d; }
+        h -= (t1 + t2) / (2.0 * h);
+        return h * 0x1p+600;
+    }
+    if (ay < 0x1p-459) {
+        if (ax >= ay / 0x1p-54) return ax + ay;
+        ax *= 0x1p+600; ay *= 0x1p+600;
+        double h = sqrt(ax * ax + ay * ay);
+        double t1, t2;
+        if (h <= 2.0 * ay) { double d = h - ay; t1 = ax * (2.0 * d - ax); t2 = (d - 2.0 * (ax - ay)) * d; }
+        else { double d = h - ax; t1 = 2.0 * d * (ax - 2.0 * ay); t2 = (4.0 * d - ay) * ay + d * d; }
+        h -= (t1 + t2) / (2.0 * h);
+        return h * 0x1p-600;
+    }
+    if (ax >= ay / 0x1p-54) return ax + ay;
+    double h = sqrt(ax * ax + ay * ay);
+    double t1, t2;
+    if (h <= 2.0 * ay) {
+        double d = h - ay;
+        t1 = ax * (2.0 * d - ax);
+        t2 = (d - 2.0 * (ax - ay)) * d;
+    } else {
+        double d = h - ax;
+        t1 = 2.0 * d * (ax - 2.0 * ay);
+        t2 = (4.0 * d - ay) * ay + d * d;
+    }
+    h -= (t1 + t2) / (2.0 * h);
+    return h;
+}
+
+// smoothed value at image (y, x) with scipy 'reflect' (only +-1 overshoot is ever requested)
+STP_HD double ct_s(const double* sS, stp_tile T, int y, int x)
+{
+    int ry = stp_refl(y, T.S), rx = stp_refl(x, T.S);
+    return sS[(ry - (T.ty0 - 2)) * (CT_X + 4) + (rx - (T.tx0 - 2))];
+}
+
+// ndi.sobel: antisymmetric pass o = x[0]*0 + (x[-1]-x[1])*(-1) (== x[1]-x[-1]); symmetric pass
+// o = x[0]*2 + (x[-1]+x[1])*1.   jsobel = sobel(axis=1), isobel = sobel(axis=0) (_canny.py:183-184)
+STP_HD void ct_sobel(const double* sS, stp_tile T, int y, int x, double* is, double* js)
+{
+    double s00 = ct_s(sS, T, y - 1, x - 1), s01 = ct_s(sS, T, y - 1, x), s02 = ct_s(sS, T, y - 1, x + 1);
+    double s10 = ct_s(sS, T, y, x - 1), s12 = ct_s(sS, T, y, x + 1);
+    double s20 = ct_s(sS, T, y + 1, x - 1), s21 = ct_s(sS, T, y + 1, x), s22 = ct_s(sS, T, y + 1, x + 1);
+    double dm = (s00 - s02) * -1.0, d0 = (s10 - s12) * -1.0, dp = (s20 - s22) * -1.0;
+    double j = d0 * 2.0;
+    j += (dm + dp) * 1.0;
+    double em = (s00 - s20) * -1.0, e0 = (s01 - s21) * -1.0, ep = (s02 - s22) * -1.0;
+    double i = e0 * 2.0;
+    i += (em + ep) * 1.0;
+    *is = i; *js = j;
+}
+
+STP_HD void canny_p3(int tid, int nt, stp_tile T, const double* sS, double* sM)
+{
+    const int MH = CT_Y + 2, MW = CT_X + 2;
+    for (int i = tid; i < MH * MW; i += nt) {
+        int yy = i / MW, xx = i - yy * MW;
+        int y = T.ty0 - 1 + yy, x = T.tx0 - 1 + xx;
+        double m = 0.0;
+        if (y >= 0 && y < T.S && x >= 0 && x < T.S) {
+            double is, js;
+            ct_sobel(sS, T, y, x, &is, &js);
+            m = stp_hypot(is, js);
+        }
+        sM[i] = m;
+    }
+}
+
+// _canny.py:193-280: interior & magnitude>0, four overlapping sectors (later ones override),
+// bilinear interpolation with `<=`, thresholds 0.1 / 0.2 with `>=`.  Returns 0 / 1 (low) / 2 (high).
+STP_HD int ct_nms(const double* sS, const double* sM, stp_tile T, int y, int x)
+{
+    if (y < 1 || x < 1 || y >= T.S - 1 || x >= T.S - 1) return 0;
+    const int MW = CT_X + 2;
+    const double* mp = sM + (y - (T.ty0 - 1)) * MW + (x - (T.tx0 - 1));
+    double m = mp[0];
+    if (!(m > 0.0)) return 0;
+    double gi, gj;
+    ct_sobel(sS, T, y, x, &gi, &gj);
+    double ai = fabs(gi), aj = fabs(gj);
+    bool same = (gi >= 0 && gj >= 0) || (gi <= 0 && gj <= 0);
+    bool opp = (gi <= 0 && gj >= 0) || (gi >= 0 && gj <= 0);
+    // the LAST matching sector decides (assignment order in _canny.py)
+    double c1p, c2p, c1m, c2m, wq;
+    if (opp && ai >= aj) {                 // 135-180
+        wq = aj / ai;
+        c1p = mp[-MW]; c2p = mp[-MW + 1]; c1m = mp[MW]; c2m = mp[MW - 1];
+    } else if (opp && ai <= aj) {          // 90-135
+        wq = ai / aj;
+        c1p = mp[1]; c2p = mp[-MW + 1]; c1m = mp[-1]; c2m = mp[MW - 1];
+    } else if (same && ai <= aj) {         // 45-90
+        wq = ai / aj;
+        c1p = mp[1]; c2p = mp[MW + 1]; c1m = mp[-1]; c2m = mp[-MW - 1];
+    } else if (same && ai >= aj) {         // 0-45
+        wq = aj / ai;
+        c1p = mp[MW]; c2p = mp[MW + 1]; c1m = mp[-MW]; c2m = mp[-MW - 1];
+    } else {
+        return 0;
+    }
+    double omw = 1.0 - wq;
+    bool cp = (c2p * wq + c1p * omw) <= m;
+    bool cm = (c2m * wq + c1m * omw) <= m;
+    if (!(cp && cm)) return 0;
+    return (m >= 0.2) ? 2 : ((m >= 0.1) ? 1 : 0);
+}
+
+// class of every tile pixel into an LDS byte tile (CT_Y x CT_X)
+STP_HD void canny_p4(int tid, int nt, stp_tile T, const double* sS, const double* sM, uint8_t* sC)
+{
+    for (int i = tid; i < CT_Y * CT_X; i += nt) {
+        int yy = i / CT_X, xx = i - yy * CT_X;
+        int y = T.ty0 + yy, x = T.tx0 + xx;
+        sC[i] = (y < T.S && x < T.S) ? (uint8_t)ct_nms(sS, sM, T, y, x) : 0;
+    }
+}
+
+// pack the byte tile into the two global bit-planes (one u64 word per tile row; CT_X == 64)
+STP_HD void canny_p5(int tid, int nt, stp_tile T, const uint8_t* sC, stp_u64* __restrict__ low_img,
+                     stp_u64* __restrict__ high_img)
+{
+    for (int yy = tid; yy < CT_Y; yy += nt) {
+        int y = T.ty0 + yy;
+        if (y >= T.S) continue;
+        stp_u64 lo = 0, hi = 0;
+        for (int xx = 0; xx < CT_X; xx++) {
+            uint8_t c = sC[yy * CT_X + xx];
+            lo |= (stp_u64)(c >= 1) << xx;
+            hi |= (stp_u64)(c == 2) << xx;
+        }
+        low_img[y * STP_NW + (T.tx0 >> 6)] = lo;
+        high_img[y * STP_NW + (T.tx0 >> 6)] = hi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel C (k_lines): one workgroup per image, everything bit-packed in LDS.
+// Bit matrices: S rows x STP_NW u64 words, bit x of row r = word[x>>6] >> (x&63); bits >= S are 0.
+STP_HD stp_u64 bm_shl1(const stp_u64* row, int w)   // result bit x = row bit x-1
+{
+    return (row[w] << 1) | (w > 0 ? row[w - 1] >> 63 : 0ull);
+}
+STP_HD stp_u64 bm_shr1(const stp_u64* row, int w)   // result bit x = row bit x+1
+{
+    return (row[w] >> 1) | (w + 1 < STP_NW ? row[w + 1] << 63 : 0ull);
+}
+STP_HD stp_u64 bm_shr2(const stp_u64* row, int w)   // result bit x = row bit x+2
+{
+    return (row[w] >> 2) | (w + 1 < STP_NW ? row[w + 1] << 62 : 0ull);
+}
+STP_HD int bm_get(const stp_u64* m, int r, int x) { return (int)((m[r * STP_NW + (x >> 6)] >> (x & 63)) & 1ull); }
+STP_HD stp_u64 stp_brev64(stp_u64 v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(v);
+#else
+    v = ((v >> 1) & 0x5555555555555555ull) | ((v & 0x5555555555555555ull) << 1);
+    v = ((v >> 2) & 0x3333333333333333ull) | ((v & 0x3333333333333333ull) << 2);
+    v = ((v >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((v & 0x0F0F0F0F0F0F0F0Full) << 4);
+    v = ((v >> 8) & 0x00FF00FF00FF00FFull) | ((v & 0x00FF00FF00FF00FFull) << 8);
+    v = ((v >> 16) & 0x0000FFFF0000FFFFull) | ((v & 0x0000FFFF0000FFFFull) << 16);
+    return (v >> 32) | (v << 32);
+#endif
+}
+STP_HD int stp_ctz64(stp_u64 v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((long long)v) - 1;
+#else
+    return __builtin_ctzll(v);
+#endif
+}
+// flood `seed` (subset of mask) along the runs of ones of `mask` inside one word
+STP_HD stp_u64 stp_runfill(stp_u64 mask, stp_u64 seed)
+{
+    stp_u64 up = (mask & ~(mask + seed)) | seed;
+    stp_u64 rm = stp_brev64(mask), rs = stp_brev64(up);
+    stp_u64 dn = (rm & ~(rm + rs)) | rs;
+    return stp_brev64(dn);
+}
+
+STP_HD void lines_load(int tid, int nt, int S, const stp_u64* __restrict__ low_img,
+                       const stp_u64* __restrict__ high_img, stp_u64* sLow, stp_u64* sE)
+{
+    const int nwu = (S + 63) >> 6;
+    for (int i = tid; i < S * STP_NW; i += nt) {
+        int w = i % STP_NW;
+        stp_u64 lo = 0, hi = 0;
+        if (w < nwu) { lo = low_img[i]; hi = high_img[i]; }
+        sLow[i] = lo; sE[i] = hi;
+    }
+}
+
+// one in-place dilation sweep of the hysteresis closure (_canny.py:286-296: 8-connected
+// components of low that contain a high pixel).  Returns 1 when this thread changed a word.
+STP_HD int lines_hyst_sweep(int tid, int nt, int S, const stp_u64* sLow, stp_u64* sE)
+{
+    int changed = 0;
+    for (int i = tid; i < S * STP_NW; i += nt) {
+        stp_u64 lowv = sLow[i];
+        if (!lowv) continue;
+        int r = i / STP_NW, w = i - r * STP_NW;
+        stp_u64 cur = sE[i], n = 0;
+        for (int dr = -1; dr <= 1; dr++) {
+            int rr = r + dr;
+            if (rr < 0 || rr >= S) continue;
+            const stp_u64* row = sE + rr * STP_NW;
+            n |= row[w] | bm_shl1(row, w) | bm_shr1(row, w);
+        }
+        stp_u64 seed = n & lowv;
+        if (!seed) continue;
+        stp_u64 nv = stp_runfill(lowv, seed) | cur;
+        if (nv != cur) { sE[i] = nv; changed = 1; }
+    }
+    return changed;
+}
+
+STP_HD void stp_fa(stp_u64 x, stp_u64 y, stp_u64 c, stp_u64* s, stp_u64* co)
+{
+    stp_u64 t = x ^ y;
+    *s = t ^ c;
+    *co = (x & y) | (c & t);
+}
+// bit-sliced n = p + 2*q + r  (0..4) -> bits n0,n1,n2
+STP_HD void stp_w121(stp_u64 p, stp_u64 q, stp_u64 r, stp_u64* n0, stp_u64* n1, stp_u64* n2)
+{
+    stp_u64 cy = p & r;
+    *n0 = p ^ r;
+    *n1 = cy ^ q;
+    *n2 = cy & q;
+}
+// bit-sliced d = a - b + 8 for 3-bit a, b (0..4): a + (~b & 7) + 1 -> 4 bits
+STP_HD void stp_diff8(stp_u64 a0, stp_u64 a1, stp_u64 a2, stp_u64 b0, stp_u64 b1, stp_u64 b2, stp_u64* d0,
+                      stp_u64* d1, stp_u64* d2, stp_u64* d3)
+{
+    stp_u64 c;
+    stp_fa(a0, ~b0, ~0ull, d0, &c);
+    stp_fa(a1, ~b1, c, d1, &c);
+    stp_fa(a2, ~b2, c, d2, &c);
+    *d3 = c;
+}
+
+// ImageProcessing.verticalLine(edges, 60, 120) (ImageProcessing.py:61-83), exact integer form:
+// hit(i,j) <=> Fx > 0 and 3*Fy^2 < Fx^2 with Fx = (1,2,1)^T.(E[:,j-1]-E[:,j+1]),
+// Fy = (1,2,1).(E[i+1,:]-E[i-1,:]); the hit is stored at column j-1 (:78).  Column 0's hit would
+// wrap to S-1 but needs Fx>0 with an empty left column, which is impossible, so V[:,S-1] = 0.
+STP_HD void lines_vline(int tid, int nt, int S, const stp_u64* sE, stp_u64* sV)
+{
+    for (int i = tid; i < S * STP_NW; i += nt) {
+        int r = i / STP_NW, w = i - r * STP_NW;
+        stp_u64 X[3][3];
+        for (int dr = 0; dr < 3; dr++) {
+            int rr = r + dr - 1;
+            if (rr < 0 || rr >= S) { X[dr][0] = X[dr][1] = X[dr][2] = 0; continue; }
+            const stp_u64* row = sE + rr * STP_NW;
+            X[dr][0] = row[w]; X[dr][1] = bm_shr1(row, w); X[dr][2] = bm_shr2(row, w);
+        }
+        stp_u64 L0, L1, L2, R0, R1, R2, T0, T1, T2, B0, B1, B2;
+        stp_w121(X[0][0], X[1][0], X[2][0], &L0, &L1, &L2);   // left column  a + 2d + g
+        stp_w121(X[0][2], X[1][2], X[2][2], &R0, &R1, &R2);   // right column c + 2f + i
+        stp_w121(X[0][0], X[0][1], X[0][2], &T0, &T1, &T2);   // top row     a + 2b + c
+        stp_w121(X[2][0], X[2][1], X[2][2], &B0, &B1, &B2);   // bottom row  g + 2h + i
+        stp_u64 x0, x1, x2, x3, y0, y1, y2, y3;
+        stp_diff8(L0, L1, L2, R0, R1, R2, &x0, &x1, &x2, &x3);  // Fx + 8 in [4, 12]
+        stp_diff8(B0, B1, B2, T0, T1, T2, &y0, &y1, &y2, &y3);  // Fy + 8
+        stp_u64 fx_ge1 = x3 & (x0 | x1 | x2);
+        stp_u64 fx_ge2 = x3 & (x1 | x2);
+        stp_u64 fx_eq4 = x3 & x2;
+        stp_u64 fy_eq0 = y3 & ~y2 & ~y1 & ~y0;
+        stp_u64 fy_le1 = (y3 & ~y2 & ~y1) | (~y3 & y2 & y1 & y0);
+        stp_u64 hit = (fx_ge1 & fy_eq0) | (fx_ge2 & fy_le1) | fx_eq4;
+        // valid output columns j' = 64w + bit with j' + 1 <= S - 1
+        int lim = S - 1 - 64 * w;                       // number of valid bits in this word
+        stp_u64 vm = lim <= 0 ? 0ull : (lim >= 64 ? ~0ull : ((1ull << lim) - 1ull));
+        sV[i] = hit & vm;
+    }
+}
+
+// V3[r][c] = V[r][c-1] | V[r][c] | V[r][c+1]  (ImageProcessing.py:122-123)
+STP_HD void lines_v3(int tid, int nt, int S, const stp_u64* sV, stp_u64* sV3)
+{
+    for (int i = tid; i < S * STP_NW; i += nt) {
+        int r = i / STP_NW, w = i - r * STP_NW;
+        const stp_u64* row = sV + r * STP_NW;
+        sV3[i] = row[w] | bm_shl1(row, w) | bm_shr1(row, w);
+    }
+}
+
+// ImageProcessing.block (ImageProcessing.py:124-195) + the caller's keep test (getStripe.py:929-940)
+STP_HD void lines_block(int tid, int nt, int S, int minH, const stp_u64* sV, const stp_u64* sV3, int16_t* colT,
+                        int16_t* colEnd, int16_t* colUd)
+{
+    for (int c = tid; c < S; c += nt) {
+        int count = 0, MAX = 0, END = 0, J = 0, buffer = 0;
+        const int wi = c >> 6;
+        const stp_u64 bit = 1ull << (c & 63);
+        for (int i = 0; i < S; i++) {
+            if (sV3[i * STP_NW + wi] & bit) { count++; J = i; }
+            else if (buffer < 5) buffer++;
+            else {
+                if (count > MAX) { MAX = count; END = J; }
+                count = 0; buffer = 0;
+            }
+        }
+        if (count > MAX) { MAX = count; END = J; }
+        int t = MAX;
+        if (END < c) END = END - t + 1;
+        int above = c < END ? c : END, bottom = c > END ? c : END;
+        int any = 0;
+        if (above < 0) above = 0;
+        if (bottom > S - 1) bottom = S - 1;
+        for (int y = above; y <= bottom; y++) any |= (sV[y * STP_NW + wi] & bit) != 0;
+        colT[c] = (int16_t)t; colEnd[c] = (int16_t)END;
+        colUd[c] = (int16_t)((t > minH && any) ? (END > c ? 2 : 1) : 0);
+    }
+}
+
+STP_HD void lines_zero(int tid, int nt, int n, stp_u64* m)
+{
+    for (int i = tid; i < n; i += nt) m[i] = 0;
+}
+
+// getStripe.py:948-955: column c painted on rows [st, en) (thread-per-column; needs LDS atomics
+// on the device because columns of one word belong to different threads)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define STP_ATOMIC_OR(p, v) atomicOr((p), (v))
+#else
+#define STP_ATOMIC_OR(p, v) (*(p) |= (v))
+#endif
+STP_HD void lines_paint(int tid, int nt, int S, int ud, const int16_t* colEnd, const int16_t* colUd, stp_u64* sT)
+{
+    for (int c = tid; c < S; c += nt) {
+        if (colUd[c] != ud) continue;
+        int st = c, en = colEnd[c];
+        if (ud == 1) { int t = st; st = en; en = t; }
+        if (st < 0) st = 0;
+        if (en > S) en = S;
+        const stp_u64 bit = 1ull << (c & 63);
+        for (int y = st; y < en; y++) STP_ATOMIC_OR(&sT[y * STP_NW + (c >> 6)], bit);
+    }
+}
+
+// helpers on one bit-row
+STP_HD int row_next_set(const stp_u64* row, int from, int S)
+{
+    if (from >= S) return S;
+    int w = from >> 6;
+    stp_u64 v = row[w] & (~0ull << (from & 63));
+    while (true) {
+        if (v) { int x = (w << 6) + stp_ctz64(v); return x < S ? x : S; }
+        if (++w >= STP_NW) return S;
+        v = row[w];
+    }
+}
+STP_HD int row_next_clear(const stp_u64* row, int from, int S)
+{
+    if (from >= S) return S;
+    int w = from >> 6;
+    stp_u64 v = ~row[w] & (~0ull << (from & 63));
+    while (true) {
+        if (v) { int x = (w << 6) + stp_ctz64(v); return x < S ? x : S; }
+        if (++w >= STP_NW) return S;
+        v = ~row[w];
+    }
+}
+STP_HD stp_u64 word_range_mask(int w, int lo, int hi)   // bits of word w inside [lo, hi]
+{
+    int a = lo - 64 * w, b = hi - 64 * w;
+    if (b < 0 || a > 63) return 0ull;
+    if (a < 0) a = 0;
+    if (b > 63) b = 63;
+    stp_u64 m = (b == 63) ? ~0ull : ((1ull << (b + 1)) - 1ull);
+    return m & (~0ull << a);
+}
+
+// getStripe.py:957-978 line refinement, thread per row
+STP_HD void lines_refine(int tid, int nt, int S, const stp_u64* sE, const stp_u64* sV, stp_u64* sT)
+{
+    for (int r = tid; r < S; r += nt) {
+        stp_u64* trow = sT + r * STP_NW;
+        const stp_u64* erow = sE + r * STP_NW;
+        const stp_u64* vrow = sV + r * STP_NW;
+        // runs are determined from the row as painted (st/en lists are built before the L loop)
+        stp_u64 orig[STP_NW];
+        for (int w = 0; w < STP_NW; w++) orig[w] = trow[w];
+        int x = 0;
+        while (true) {
+            int st = row_next_set(orig, x, S);
+            if (st >= S) break;
+            int en = row_next_clear(orig, st, S) - 1;
+            int any = 0;
+            for (int w = st >> 6; w <= en >> 6; w++) any |= (erow[w] & word_range_mask(w, st, en)) != 0;
+            if (any) {          // testmat[r, st:en] = vert[r, st:en]   (column en untouched)
+                for (int w = st >> 6; w <= (en >> 6); w++) {
+                    stp_u64 m = word_range_mask(w, st, en - 1);
+                    trow[w] = (trow[w] & ~m) | (vrow[w] & m);
+                }
+            } else {            // clear [st, en), set MED = round-half-even((st+en)/2)
+                for (int w = st >> 6; w <= (en >> 6); w++) trow[w] &= ~word_range_mask(w, st, en - 1);
+                int s2 = st + en, k = s2 >> 1;
+                int med = (s2 & 1) ? ((k & 1) ? k + 1 : k) : k;
+                trow[med >> 6] |= 1ull << (med & 63);
+            }
+            x = en + 1;
+        }
+    }
+}
+
+// per-column pixel count and first / last row (getStripe.py:981-984, 1060-1065)
+STP_HD void lines_colstat(int tid, int nt, int S, const stp_u64* sT, int16_t* cnt, int16_t* minr, int16_t* maxr)
+{
+    for (int c = tid; c < S; c += nt) {
+        const int wi = c >> 6;
+        const stp_u64 bit = 1ull << (c & 63);
+        int n = 0, mn = S, mx = -1;
+        for (int y = 0; y < S; y++)
+            if (sT[y * STP_NW + wi] & bit) { n++; if (mn == S) mn = y; mx = y; }
+        cnt[c] = (int16_t)n; minr[c] = (int16_t)mn; maxr[c] = (int16_t)mx;
+    }
+}
+
+struct stp_lrec { int16_t ud, x, y, w, h; };
+
+// getStripe.py:994-1078 for one ud: column grouping (incl. the stale-[Current] behaviour of the
+// loop at :1019-1028), X = sorted(set(meanX)), neighbour pairing.  Executed by ONE thread.
+// scratch: cidx[S], clen[S] (int16), xs[S+2] (int16).  Returns the new record count.
+STP_HD int lines_group_pairs(int S, int ud, int maxW, const int16_t* cnt, const int16_t* minr, const int16_t* maxr,
+                             int16_t* cidx, int16_t* clen, int16_t* xs, stp_lrec* recs, int nrec, int cap)
+{
+    int nrow = 0;
+    for (int c = 0; c < S; c++)
+        if (cnt[c] >= 3) { cidx[nrow] = (int16_t)c; clen[nrow] = cnt[c]; nrow++; }
+    // meanX values are integers in [0, S): mark them in a bitmap (set semantics + sorted order)
+    stp_u64 seen[STP_NW];
+    for (int w = 0; w < STP_NW; w++) seen[w] = 0;
+    int g0 = 0, gn = 0;          // Continuous = cidx[g0 .. g0+gn) or the single stale entry
+    bool isContinue = false;
+#define STP_FLUSH() do { \
+        long ssum = 0; for (int q = 0; q < gn; q++) ssum += clen[g0 + q]; \
+        double temp = 0.0; \
+        for (int q = 0; q < gn; q++) temp = temp + (double)cidx[g0 + q] * ((double)clen[g0 + q] / (double)ssum); \
+        int mv = (int)nearbyint(temp); \
+        if (mv >= 0 && mv < S) seen[mv >> 6] |= 1ull << (mv & 63); } while (0)
+    for (int c = 0; c + 1 < nrow; c++) {
+        int Current = cidx[c], Next = cidx[c + 1];
+        if (Next - Current == 1 && isContinue) {
+            gn++;                                      // group stays contiguous in cidx
+        } else if (Next - Current == 1 && !isContinue) {
+            g0 = c; gn = 2; isContinue = true;
+        } else if (Next - Current != 1 && !isContinue) {
+            g0 = c; gn = 1; isContinue = false;
+            STP_FLUSH();
+        } else {
+            STP_FLUSH();
+            g0 = c; gn = 1; isContinue = false;        // stale [Current]: last column of the flushed group
+        }
+    }
+    if (gn == 0) seen[0] |= 1ull;                       // np.round(sum([])) = 0
+    else STP_FLUSH();
+#undef STP_FLUSH
+    int nx = 0;
+    for (int w = 0; w < STP_NW; w++) {
+        stp_u64 v = seen[w];
+        while (v) { int b = stp_ctz64(v); v &= v - 1; xs[nx++] = (int16_t)((w << 6) + b); }
+    }
+    for (int c = 0; c + 1 < nx; c++) {
+        int n = xs[c], m = xs[c + 1];
+        int gap = m - n;
+        if (gap > 1 && gap <= maxW) {
+            int p1 = gap > 4 ? m - 2 : m;
+            int MIN = S, MAX = -1;
+            for (int q = 0; q < 2; q++) {
+                int ctr = q ? m : n;
+                int lo = ctr - 1 < 0 ? 0 : ctr - 1, hi = ctr + 2 > S ? S : ctr + 2;
+                for (int xx = lo; xx < hi; xx++) {
+                    if (minr[xx] < MIN) MIN = minr[xx];
+                    if (maxr[xx] > MAX) MAX = maxr[xx];
+                }
+            }
+            if (ud == 1) MAX = p1; else MIN = n;
+            if (nrec < cap) {
+                recs[nrec].ud = (int16_t)ud; recs[nrec].x = (int16_t)n; recs[nrec].y = (int16_t)MIN;
+                recs[nrec].w = (int16_t)(p1 - n + 1); recs[nrec].h = (int16_t)(MAX - MIN + 1);
+            }
+            nrec++;
+        }
+    }
+    return nrec;
+}
+
+// row sums of submat[y:y+h, x:x+w] (numpy adds the w (<8) elements of a row sequentially and
+// then the rows in order, getStripe.py:1094)
+STP_HD void lines_rowsum(int tid, int nt, int S, const double* __restrict__ band, int W, int hw, int64_t st,
+                         const int16_t* nz, stp_lrec rc, double* rs)
+{
+    for (int i = tid; i < rc.h; i += nt) {
+        int y = rc.y + i;
+        double s = 0.0;
+        if (y >= 0 && y < S) {
+            int oy = nz[y];
+            for (int x = rc.x; x < rc.x + rc.w && x < S; x++) {
+                int ox = nz[x];
+                double v = band[(st + oy) * (int64_t)W + (ox - oy + hw)];
+                if (v != v) v = 0.0;
+                s += v;
+            }
+        }
+        rs[i] = s;
+    }
+}

@@ -1,0 +1,701 @@
+// libstripenn_hip.so -- gfx950 kernels + C ABI (include/stripenn_hip.h).
+// Build: stripenn_amd/csrc/Makefile (hipcc --offload-arch=gfx950 -O3 -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <new>
+#include "../../include/stripenn_hip.h"
+#include "stp_phases.h"
+
+// ============================================================================================
+// device kernels
+// ============================================================================================
+
+// K0: zero-column removal of every frame (getStripe.py:809-821).  One workgroup per frame,
+// one lane per column; rows are walked sequentially so the column sum has numpy's axis-0
+// order; consecutive lanes read consecutive band addresses (coalesced).
+__global__ __launch_bounds__(512) void k_frame_compact(const double* __restrict__ band, int W, int hw,
+                                                        const int32_t* __restrict__ fstart,
+                                                        const int32_t* __restrict__ fn0, int32_t* __restrict__ S_out,
+                                                        int16_t* __restrict__ nz_out)
+{
+    __shared__ int s_wave[8];
+    const int f = blockIdx.x, c = threadIdx.x;
+    const int64_t st = fstart[f];
+    const int n0 = fn0[f];
+    double sum = 0.0;
+    if (c < n0) {
+        for (int r = 0; r < n0; r++) {
+            double v = band[(st + r) * (int64_t)W + (c - r + hw)];
+            if (v != v) v = 0.0;
+            sum += v;
+        }
+    }
+    const bool flag = (c < n0) && (sum != 0.0);
+    const unsigned long long bal = __ballot(flag);
+    const int lane = c & 63, wv = c >> 6;
+    if (lane == 0) s_wave[wv] = __popcll(bal);
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int i = 0; i < 8; i++) {
+        if (i < wv) base += s_wave[i];
+        total += s_wave[i];
+    }
+    const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+    if (flag) nz_out[f * STP_FRAME_MAX + pos] = (int16_t)c;
+    if (c == 0) S_out[f] = (total > 10) ? total : 0;   // getStripe.py:818
+}
+
+// K-A: image build + brightness + mean blur + grey for all brightness levels of one tile.
+__global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, int W, int hw,
+                                               const int32_t* __restrict__ fstart, const int32_t* __restrict__ fS,
+                                               const int16_t* __restrict__ fnz, int f0,
+                                               const double* __restrict__ Mlev, int nlev,
+                                               const double* __restrict__ bvals, int nb, int a,
+                                               float* __restrict__ gray)
+{
+    __shared__ double sg[(GT_Y + 2 * GT_AMAX) * (GT_X + 2 * GT_AMAX)];
+    __shared__ double sadj[(GT_Y + 2 * GT_AMAX) * (GT_X + 2 * GT_AMAX)];
+    const int fl = blockIdx.z, lev = blockIdx.y, f = f0 + fl;
+    const int S = fS[f];
+    if (S == 0) return;
+    const int tpr = (STP_FRAME_MAX + GT_X - 1) / GT_X;
+    stp_tile T;
+    T.S = S; T.ty0 = (blockIdx.x / tpr) * GT_Y; T.tx0 = (blockIdx.x % tpr) * GT_X;
+    if (T.ty0 >= S || T.tx0 >= S) return;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    gray_p0(tid, nt, band, W, hw, (int64_t)fstart[f], fnz + (size_t)f * STP_FRAME_MAX, T, a, Mlev[lev], sg);
+    __syncthreads();
+    for (int bi = 0; bi < nb; bi++) {
+        gray_p1(tid, nt, a, bvals[bi], sg, sadj);
+        __syncthreads();
+        const size_t img = ((size_t)fl * nlev + lev) * nb + bi;
+        gray_p2(tid, nt, T, a, sadj, gray + img * (size_t)(STP_PITCH * STP_PITCH));
+        __syncthreads();
+    }
+}
+
+// K-B: Canny up to the classified local maxima, one tile of one image per workgroup.
+__global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
+                                                int imgs_per_frame, int R, const double* __restrict__ gw,
+                                                stp_u64* __restrict__ low, stp_u64* __restrict__ high)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int img = blockIdx.y;
+    const int f = f0 + img / imgs_per_frame;
+    const int S = fS[f];
+    if (S == 0) return;
+    const int tpr = (STP_FRAME_MAX + CT_X - 1) / CT_X;
+    stp_tile T;
+    T.S = S; T.ty0 = (blockIdx.x / tpr) * CT_Y; T.tx0 = (blockIdx.x % tpr) * CT_X;
+    if (T.ty0 >= S || T.tx0 >= S) return;
+    const int GW = ct_gw(R), GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
+    // layout: [sW | sB | sS | sG | sV]; sM and sC alias sG/sV once those are dead
+    double* sW = (double*)smem;                                   // 2*CT_RMAX+1 -> 32 slots
+    double* sB = sW + 32;                                         // 2*VH
+    double* sS = sB + 2 * VH;                                     // VH*(CT_X+4)
+    float* sG = (float*)(sS + VH * (CT_X + 4));                   // GH*GW
+    float* sV = sG + GH * GW;                                     // VH*GW
+    double* sM = (double*)sG;                                     // (CT_Y+2)*(CT_X+2) f64 <= (GH+VH)*GW f32
+    uint8_t* sC = (uint8_t*)(sM + (CT_Y + 2) * (CT_X + 2));
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid < 2 * R + 1) sW[tid] = gw[tid];
+    const float* gimg = gray + (size_t)img * (STP_PITCH * STP_PITCH);
+    canny_p0(tid, nt, gimg, T, R, sG);
+    __syncthreads();
+    canny_p1(tid, nt, T, R, sW, sG, sV);
+    canny_p1b(tid, nt, T, R, sW, sB);
+    __syncthreads();
+    canny_p2(tid, nt, T, R, sW, sV, sB, sS);
+    __syncthreads();
+    canny_p3(tid, nt, T, sS, sM);
+    __syncthreads();
+    canny_p4(tid, nt, T, sS, sM, sC);
+    __syncthreads();
+    canny_p5(tid, nt, T, sC, low + (size_t)img * (STP_FRAME_MAX * STP_NW), high + (size_t)img * (STP_FRAME_MAX * STP_NW));
+}
+
+static size_t canny_smem_bytes(int R)
+{
+    const int GW = CT_X + 2 * R + 4, GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
+    size_t fixed = (32 + 2 * VH + VH * (CT_X + 4)) * sizeof(double);
+    size_t gv = (size_t)(GH + VH) * GW * sizeof(float);
+    size_t mc = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(double) + CT_Y * CT_X;
+    return fixed + (gv > mc ? gv : mc);
+}
+
+struct stp_drec {
+    int16_t ud, x, y, w, h, pad0, pad1, pad2;
+    double total;
+};
+
+// K-C: hysteresis + verticalLine + block + line joining + totals, one workgroup per image,
+// every mask bit-packed in LDS (3 x 22.4 KB).
+__global__ __launch_bounds__(512) void k_lines(const stp_u64* __restrict__ low, const stp_u64* __restrict__ high,
+                                                const double* __restrict__ band, int W, int hw,
+                                                const int32_t* __restrict__ fstart, const int32_t* __restrict__ fS,
+                                                const int16_t* __restrict__ fnz, int f0, int imgs_per_frame,
+                                                int minH, int maxW, stp_drec* __restrict__ recs,
+                                                int32_t* __restrict__ rec_count, int want_dbg,
+                                                stp_u64* __restrict__ dbg /* E,V,T1,T2 */, int16_t* __restrict__ dbg_cols)
+{
+    __shared__ stp_u64 buf0[STP_FRAME_MAX * STP_NW];   // low -> V3 -> testmat
+    __shared__ stp_u64 buf1[STP_FRAME_MAX * STP_NW];   // E (edges)
+    __shared__ stp_u64 buf2[STP_FRAME_MAX * STP_NW];   // V (vert)
+    __shared__ int16_t s_nz[STP_FRAME_MAX];
+    __shared__ int16_t colT[STP_FRAME_MAX], colEnd[STP_FRAME_MAX], colUd[STP_FRAME_MAX];
+    __shared__ int16_t cnt[STP_FRAME_MAX], minr[STP_FRAME_MAX], maxr[STP_FRAME_MAX];
+    __shared__ int16_t cidx[STP_FRAME_MAX], clen[STP_FRAME_MAX], xs[STP_FRAME_MAX + 8];
+    __shared__ stp_lrec lrec[STP_RCAP];
+    __shared__ double rs[STP_FRAME_MAX];
+    __shared__ int s_nrec;
+    const int img = blockIdx.x;
+    const int f = f0 + img / imgs_per_frame;
+    const int S = fS[f];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (S == 0) {
+        if (tid == 0) rec_count[img] = 0;
+        return;
+    }
+    const stp_u64* limg = low + (size_t)img * (STP_FRAME_MAX * STP_NW);
+    const stp_u64* himg = high + (size_t)img * (STP_FRAME_MAX * STP_NW);
+    for (int i = tid; i < S; i += nt) s_nz[i] = fnz[(size_t)f * STP_FRAME_MAX + i];
+    lines_load(tid, nt, S, limg, himg, buf0, buf1);
+    __syncthreads();
+    for (int it = 0; it < 4 * STP_FRAME_MAX * STP_FRAME_MAX; it++) {
+        int ch = lines_hyst_sweep(tid, nt, S, buf0, buf1);
+        if (!__syncthreads_or(ch)) break;
+    }
+    lines_vline(tid, nt, S, buf1, buf2);
+    __syncthreads();
+    lines_v3(tid, nt, S, buf2, buf0);
+    __syncthreads();
+    lines_block(tid, nt, S, minH, buf2, buf0, colT, colEnd, colUd);
+    if (tid == 0) s_nrec = 0;
+    __syncthreads();
+    if (want_dbg) {
+        stp_u64* d = dbg + (size_t)img * 4 * (STP_FRAME_MAX * STP_NW);
+        for (int i = tid; i < S * STP_NW; i += nt) { d[i] = buf1[i]; d[STP_FRAME_MAX * STP_NW + i] = buf2[i]; }
+        int16_t* dc = dbg_cols + (size_t)img * 3 * STP_FRAME_MAX;
+        for (int i = tid; i < S; i += nt) { dc[i] = colT[i]; dc[STP_FRAME_MAX + i] = colEnd[i]; dc[2 * STP_FRAME_MAX + i] = colUd[i]; }
+    }
+    for (int ud = 1; ud <= 2; ud++) {
+        lines_zero(tid, nt, S * STP_NW, buf0);
+        __syncthreads();
+        lines_paint(tid, nt, S, ud, colEnd, colUd, buf0);
+        __syncthreads();
+        lines_refine(tid, nt, S, buf1, buf2, buf0);
+        __syncthreads();
+        lines_colstat(tid, nt, S, buf0, cnt, minr, maxr);
+        if (want_dbg) {
+            stp_u64* d = dbg + (size_t)img * 4 * (STP_FRAME_MAX * STP_NW) + (size_t)(1 + ud) * (STP_FRAME_MAX * STP_NW);
+            for (int i = tid; i < S * STP_NW; i += nt) d[i] = buf0[i];
+        }
+        __syncthreads();
+        if (tid == 0)
+            s_nrec = lines_group_pairs(S, ud, maxW, cnt, minr, maxr, cidx, clen, xs, lrec, s_nrec, STP_RCAP);
+        __syncthreads();
+    }
+    const int nrec = s_nrec;
+    const int nst = nrec < STP_RCAP ? nrec : STP_RCAP;
+    stp_drec* out = recs + (size_t)img * STP_RCAP;
+    const int64_t st = fstart[f];
+    for (int k = 0; k < nst; k++) {
+        stp_lrec rc = lrec[k];
+        lines_rowsum(tid, nt, S, band, W, hw, st, s_nz, rc, rs);
+        __syncthreads();
+        if (tid == 0) {
+            double tot = 0.0;
+            for (int i = 0; i < rc.h; i++) tot += rs[i];
+            stp_drec d;
+            d.ud = rc.ud; d.x = rc.x; d.y = rc.y; d.w = rc.w; d.h = rc.h; d.pad0 = d.pad1 = d.pad2 = 0;
+            d.total = tot;
+            out[k] = d;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) rec_count[img] = nrec;
+}
+
+// ============================================================================================
+// host side
+// ============================================================================================
+struct stp_kstat {
+    std::string name;
+    int64_t launches = 0;
+    double ms = 0.0;
+    double bytes = 0.0;
+};
+
+struct stp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    bool profiling = false;
+    std::vector<stp_kstat> stats;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct stp_band {
+    const double* d = nullptr;
+    int64_t nrows = 0;
+    int hw = 0, W = 0;
+    bool owned = false;
+};
+
+struct stp_frames {
+    const stp_band* band = nullptr;
+    int n = 0;
+    int32_t *d_start = nullptr, *d_n0 = nullptr, *d_S = nullptr;
+    int16_t* d_nz = nullptr;
+    std::vector<int32_t> h_start, h_n0, h_S;
+    std::vector<int16_t> h_nz;
+    std::vector<double> h_med;
+};
+
+static int set_err(stp_ctx* c, int code, const std::string& m)
+{
+    if (c) c->err = m;
+    return code;
+}
+#define HIPCHK(call)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return set_err(ctx, e_ == hipErrorOutOfMemory ? STP_E_NOMEM : STP_E_HIP,             \
+                           std::string(#call) + ": " + hipGetErrorString(e_));                   \
+    } while (0)
+
+static stp_kstat& stat_for(stp_ctx* ctx, const char* name)
+{
+    for (auto& s : ctx->stats)
+        if (s.name == name) return s;
+    ctx->stats.push_back(stp_kstat());
+    ctx->stats.back().name = name;
+    return ctx->stats.back();
+}
+
+struct prof_scope {
+    stp_ctx* ctx;
+    const char* name;
+    double bytes;
+    prof_scope(stp_ctx* c, const char* n, double b) : ctx(c), name(n), bytes(b)
+    {
+        if (ctx->profiling) (void)hipEventRecord(ctx->ev0, ctx->stream);
+    }
+    ~prof_scope()
+    {
+        if (!ctx->profiling) return;
+        (void)hipEventRecord(ctx->ev1, ctx->stream);
+        (void)hipEventSynchronize(ctx->ev1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+        stp_kstat& s = stat_for(ctx, name);
+        s.launches++; s.ms += ms; s.bytes += bytes;
+    }
+};
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int stp_version(void) { return STP_ABI_VERSION; }
+
+int stp_ctx_create(int device_ordinal, stp_ctx** out)
+{
+    if (!out) return STP_E_ARG;
+    *out = nullptr;
+    stp_ctx* ctx = new (std::nothrow) stp_ctx();
+    if (!ctx) return STP_E_NOMEM;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0 || device_ordinal < 0 || device_ordinal >= ndev) {
+        delete ctx;
+        return STP_E_HIP;   // no CPU fallback by design
+    }
+    ctx->device = device_ordinal;
+    if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return STP_E_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) { delete ctx; return STP_E_HIP; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "libstripenn_hip: device %d is %s, this library is built for gfx950 only\n", device_ordinal,
+                prop.gcnArchName);
+        delete ctx;
+        return STP_E_UNSUPPORTED;
+    }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return STP_E_HIP; }
+    ctx->own_stream = true;
+    (void)hipEventCreate(&ctx->ev0);
+    (void)hipEventCreate(&ctx->ev1);
+    *out = ctx;
+    return STP_OK;
+}
+
+void stp_ctx_destroy(stp_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* stp_last_error(const stp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int stp_ctx_set_stream(stp_ctx* ctx, void* s)
+{
+    if (!ctx) return STP_E_ARG;
+    if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (s) { ctx->stream = (hipStream_t)s; ctx->own_stream = false; }
+    else {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return STP_OK;
+}
+
+int stp_ctx_synchronize(stp_ctx* ctx)
+{
+    if (!ctx) return STP_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return STP_OK;
+}
+
+static int check_hw(stp_ctx* ctx, int64_t nrows, int32_t hw)
+{
+    if (nrows <= 0 || hw < 448 || (hw % 64) != 0 || hw > 4096)
+        return set_err(ctx, STP_E_ARG, "band: nrows must be > 0 and halfwidth a multiple of 64 in [448, 4096]");
+    return STP_OK;
+}
+
+int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_t hw, stp_band** out)
+{
+    if (!ctx || !band_host || !out) return STP_E_ARG;
+    int rc = check_hw(ctx, nrows, hw);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    stp_band* b = new (std::nothrow) stp_band();
+    if (!b) return STP_E_NOMEM;
+    b->nrows = nrows; b->hw = hw; b->W = 2 * hw; b->owned = true;
+    double* d = nullptr;
+    size_t bytes = (size_t)nrows * b->W * sizeof(double);
+    hipError_t e = hipMalloc((void**)&d, bytes);
+    if (e != hipSuccess) { delete b; return set_err(ctx, STP_E_NOMEM, "hipMalloc(band) failed"); }
+    e = hipMemcpyAsync(d, band_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d); delete b; return set_err(ctx, STP_E_HIP, "band upload failed"); }
+    b->d = d;
+    *out = b;
+    return STP_OK;
+}
+
+int stp_band_wrap_device(stp_ctx* ctx, const void* dptr, int64_t nrows, int32_t hw, stp_band** out)
+{
+    if (!ctx || !dptr || !out) return STP_E_ARG;
+    int rc = check_hw(ctx, nrows, hw);
+    if (rc) return rc;
+    stp_band* b = new (std::nothrow) stp_band();
+    if (!b) return STP_E_NOMEM;
+    b->d = (const double*)dptr; b->nrows = nrows; b->hw = hw; b->W = 2 * hw; b->owned = false;
+    *out = b;
+    return STP_OK;
+}
+
+void stp_band_free(stp_ctx* ctx, stp_band* b)
+{
+    if (!b) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (b->owned && b->d) (void)hipFree((void*)b->d);
+    delete b;
+}
+
+void stp_frames_free(stp_ctx* ctx, stp_frames* fr)
+{
+    if (!fr) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (fr->d_start) (void)hipFree(fr->d_start);
+    if (fr->d_n0) (void)hipFree(fr->d_n0);
+    if (fr->d_S) (void)hipFree(fr->d_S);
+    if (fr->d_nz) (void)hipFree(fr->d_nz);
+    delete fr;
+}
+
+int stp_frames_create(stp_ctx* ctx, const stp_band* band, const int32_t* start, const int32_t* end, int32_t n,
+                      stp_frames** out)
+{
+    if (!ctx || !band || !start || !end || !out || n <= 0) return STP_E_ARG;
+    for (int i = 0; i < n; i++) {
+        int n0 = end[i] - start[i] + 1;
+        if (start[i] < 0 || end[i] >= band->nrows || n0 < 1 || n0 > STP_FRAME_MAX)
+            return set_err(ctx, STP_E_ARG, "frame " + std::to_string(i) + " out of range or larger than 400");
+        if (n0 > band->hw) return set_err(ctx, STP_E_ARG, "frame wider than band halfwidth");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    stp_frames* fr = new (std::nothrow) stp_frames();
+    if (!fr) return STP_E_NOMEM;
+    fr->band = band; fr->n = n;
+    fr->h_start.assign(start, start + n);
+    fr->h_n0.resize(n);
+    for (int i = 0; i < n; i++) fr->h_n0[i] = end[i] - start[i] + 1;
+    fr->h_S.resize(n); fr->h_nz.assign((size_t)n * STP_FRAME_MAX, 0); fr->h_med.assign(n, 0.0);
+#define FRCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { stp_frames_free(ctx, fr); \
+        return set_err(ctx, e_ == hipErrorOutOfMemory ? STP_E_NOMEM : STP_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
+    FRCHK(hipMalloc((void**)&fr->d_start, n * sizeof(int32_t)));
+    FRCHK(hipMalloc((void**)&fr->d_n0, n * sizeof(int32_t)));
+    FRCHK(hipMalloc((void**)&fr->d_S, n * sizeof(int32_t)));
+    FRCHK(hipMalloc((void**)&fr->d_nz, (size_t)n * STP_FRAME_MAX * sizeof(int16_t)));
+    FRCHK(hipMemcpyAsync(fr->d_start, fr->h_start.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    FRCHK(hipMemcpyAsync(fr->d_n0, fr->h_n0.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    FRCHK(hipMemsetAsync(fr->d_nz, 0, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), ctx->stream));
+    {
+        double bytes = 0;
+        for (int i = 0; i < n; i++) bytes += 8.0 * fr->h_n0[i] * fr->h_n0[i];
+        prof_scope ps(ctx, "frame_compact", bytes);
+        hipLaunchKernelGGL(k_frame_compact, dim3(n), dim3(512), 0, ctx->stream, band->d, band->W, band->hw, fr->d_start,
+                           fr->d_n0, fr->d_S, fr->d_nz);
+    }
+    FRCHK(hipGetLastError());
+    FRCHK(hipMemcpyAsync(fr->h_S.data(), fr->d_S, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FRCHK(hipMemcpyAsync(fr->h_nz.data(), fr->d_nz, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), hipMemcpyDeviceToHost,
+                         ctx->stream));
+    FRCHK(hipStreamSynchronize(ctx->stream));
+#undef FRCHK
+    *out = fr;
+    return STP_OK;
+}
+
+int stp_frames_info(stp_ctx* ctx, const stp_frames* fr, int32_t* S_out, int16_t* nz_out, double* med_out)
+{
+    if (!ctx || !fr) return STP_E_ARG;
+    if (S_out) memcpy(S_out, fr->h_S.data(), fr->n * sizeof(int32_t));
+    if (nz_out) memcpy(nz_out, fr->h_nz.data(), (size_t)fr->n * STP_FRAME_MAX * sizeof(int16_t));
+    if (med_out) memcpy(med_out, fr->h_med.data(), fr->n * sizeof(double));
+    return STP_OK;
+}
+
+static int check_params(stp_ctx* ctx, const stp_search_params* p)
+{
+    if (!p || !p->bright || !p->gauss_w) return set_err(ctx, STP_E_ARG, "null search params");
+    if (p->bfilter < 1 || p->bfilter > 2 * GT_AMAX + 1 || (p->bfilter % 2) == 0)
+        return set_err(ctx, STP_E_UNSUPPORTED, "bfilter must be odd and <= 7");
+    if (p->n_bright < 1 || p->n_bright > 8) return set_err(ctx, STP_E_ARG, "n_bright must be in 1..8");
+    if (p->gauss_radius < 1 || p->gauss_radius > CT_RMAX)
+        return set_err(ctx, STP_E_UNSUPPORTED, "gaussian radius must be in 1..12 (sigma <= 3.1)");
+    if (p->minH < 0 || p->maxW < 2 || p->maxW > STP_FRAME_MAX) return set_err(ctx, STP_E_ARG, "bad minH/maxW");
+    return STP_OK;
+}
+
+struct dev_buf {
+    void* p = nullptr;
+    ~dev_buf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+
+// shared by stp_stripe_search and stp_dbg_stages: run the three image kernels on frames
+// [f0, f0+nf) for n_levels levels; buffers sized by the caller.
+static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, int f0, int nf,
+                     const double* d_M, int nlev, const double* d_b, const double* d_w, float* d_gray, stp_u64* d_low,
+                     stp_u64* d_high, stp_drec* d_recs, int32_t* d_cnt, int want_dbg, stp_u64* d_dbg, int16_t* d_dbgc)
+{
+    const stp_band* band = fr->band;
+    const int nb = prm->n_bright, a = prm->bfilter / 2, R = prm->gauss_radius;
+    const int ipf = nlev * nb;
+    const size_t nimg = (size_t)nf * ipf;
+    double px = 0;
+    for (int i = 0; i < nf; i++) px += (double)fr->h_S[f0 + i] * fr->h_S[f0 + i];
+    const double ipx = px * ipf;   // image pixels in this launch
+    HIPCHK(hipMemsetAsync(d_low, 0, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), ctx->stream));
+    HIPCHK(hipMemsetAsync(d_high, 0, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), ctx->stream));
+    {
+        prof_scope ps(ctx, "gray", ipx * 12.0);          // stage A of SURVEY 8(d): 8 B read + 4 B written per image px
+        const int tiles = ((STP_FRAME_MAX + GT_X - 1) / GT_X) * ((STP_FRAME_MAX + GT_Y - 1) / GT_Y);
+        hipLaunchKernelGGL(k_gray, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
+                           fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray);
+    }
+    HIPCHK(hipGetLastError());
+    {
+        prof_scope ps(ctx, "canny", ipx * 5.0);          // stage B: 4 B read + 1 B written
+        const int tiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
+        hipLaunchKernelGGL(k_canny, dim3(tiles, (unsigned)nimg), dim3(256), canny_smem_bytes(R), ctx->stream, d_gray,
+                           fr->d_S, f0, ipf, R, d_w, d_low, d_high);
+    }
+    HIPCHK(hipGetLastError());
+    {
+        prof_scope ps(ctx, "lines", ipx * 9.0);          // stages C-F: 2 + 2 + 1 + 4 B per image px
+        hipLaunchKernelGGL(k_lines, dim3((unsigned)nimg), dim3(512), 0, ctx->stream, d_low, d_high, band->d, band->W,
+                           band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, ipf, prm->minH, prm->maxW, d_recs, d_cnt,
+                           want_dbg, d_dbg, d_dbgc);
+    }
+    HIPCHK(hipGetLastError());
+    return STP_OK;
+}
+
+int stp_stripe_search(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, const double* M_levels,
+                      int32_t n_levels, stp_stripe_rec* out, int64_t cap, int64_t* out_count)
+{
+    if (!ctx || !fr || !M_levels || !out_count || n_levels < 1 || (cap > 0 && !out)) return STP_E_ARG;
+    int rc = check_params(ctx, prm);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int nb = prm->n_bright, ipf = n_levels * nb;
+    int chunk = 3072 / ipf;
+    if (chunk < 1) chunk = 1;
+    if (chunk > fr->n) chunk = fr->n;
+    const size_t cimg = (size_t)chunk * ipf;
+    dev_buf bM, bB, bW, bGray, bLow, bHigh, bRecs, bCnt;
+    HIPCHK(bM.alloc(n_levels * sizeof(double)));
+    HIPCHK(bB.alloc(nb * sizeof(double)));
+    HIPCHK(bW.alloc((2 * prm->gauss_radius + 1) * sizeof(double)));
+    HIPCHK(bGray.alloc(cimg * STP_PITCH * STP_PITCH * sizeof(float)));
+    HIPCHK(bLow.alloc(cimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
+    HIPCHK(bHigh.alloc(cimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
+    HIPCHK(bRecs.alloc(cimg * STP_RCAP * sizeof(stp_drec)));
+    HIPCHK(bCnt.alloc(cimg * sizeof(int32_t)));
+    HIPCHK(hipMemcpyAsync(bM.p, M_levels, n_levels * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(bB.p, prm->bright, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(bW.p, prm->gauss_w, (2 * prm->gauss_radius + 1) * sizeof(double), hipMemcpyHostToDevice,
+                          ctx->stream));
+    std::vector<int32_t> h_cnt(cimg);
+    std::vector<stp_drec> h_recs(cimg * STP_RCAP);
+    int64_t total = 0;
+    bool overflow = false;
+    for (int f0 = 0; f0 < fr->n; f0 += chunk) {
+        const int nf = (fr->n - f0 < chunk) ? fr->n - f0 : chunk;
+        const size_t nimg = (size_t)nf * ipf;
+        rc = run_chain(ctx, fr, prm, f0, nf, (const double*)bM.p, n_levels, (const double*)bB.p, (const double*)bW.p,
+                       (float*)bGray.p, (stp_u64*)bLow.p, (stp_u64*)bHigh.p, (stp_drec*)bRecs.p, (int32_t*)bCnt.p, 0,
+                       nullptr, nullptr);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(h_cnt.data(), bCnt.p, nimg * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(h_recs.data(), bRecs.p, nimg * STP_RCAP * sizeof(stp_drec), hipMemcpyDeviceToHost,
+                              ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (size_t im = 0; im < nimg; im++) {
+            int n = h_cnt[im];
+            if (n > STP_RCAP) { overflow = true; n = STP_RCAP; }
+            const int fl = (int)(im / ipf), lev = (int)((im % ipf) / nb), bi = (int)(im % nb);
+            for (int k = 0; k < n; k++) {
+                if (total < cap) {
+                    const stp_drec& d = h_recs[im * STP_RCAP + k];
+                    stp_stripe_rec& r = out[total];
+                    r.frame = f0 + fl; r.level = lev; r.b_index = bi; r.ud = d.ud;
+                    r.x = d.x; r.y = d.y; r.w = d.w; r.h = d.h; r.total = d.total;
+                }
+                total++;
+            }
+        }
+    }
+    *out_count = total;
+    if (overflow) return set_err(ctx, STP_E_CAPACITY, "an image produced more than 128 candidate stripes");
+    if (total > cap) return set_err(ctx, STP_E_CAPACITY, "output capacity too small; out_count holds the needed size");
+    return STP_OK;
+}
+
+static void unpack_bits(const stp_u64* src, int S, uint8_t* dst)
+{
+    for (int y = 0; y < S; y++)
+        for (int x = 0; x < S; x++) dst[(size_t)y * S + x] = (uint8_t)((src[y * STP_NW + (x >> 6)] >> (x & 63)) & 1ull);
+}
+
+int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, int32_t f, double M, int32_t bi,
+                   float* gray, uint8_t* cls, uint8_t* edges, uint8_t* vert, int32_t* col_t, int32_t* col_end,
+                   int32_t* col_ud, uint8_t* tm1, uint8_t* tm2)
+{
+    if (!ctx || !fr || f < 0 || f >= fr->n) return STP_E_ARG;
+    int rc = check_params(ctx, prm);
+    if (rc) return rc;
+    if (bi < 0 || bi >= prm->n_bright) return STP_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int S = fr->h_S[f];
+    if (S == 0) return set_err(ctx, STP_E_ARG, "frame has <= 10 non-empty columns");
+    const int nb = prm->n_bright;
+    dev_buf bM, bB, bW, bGray, bLow, bHigh, bRecs, bCnt, bDbg, bDbgc;
+    const size_t nimg = nb;
+    HIPCHK(bM.alloc(sizeof(double)));
+    HIPCHK(bB.alloc(nb * sizeof(double)));
+    HIPCHK(bW.alloc((2 * prm->gauss_radius + 1) * sizeof(double)));
+    HIPCHK(bGray.alloc(nimg * STP_PITCH * STP_PITCH * sizeof(float)));
+    HIPCHK(bLow.alloc(nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
+    HIPCHK(bHigh.alloc(nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
+    HIPCHK(bRecs.alloc(nimg * STP_RCAP * sizeof(stp_drec)));
+    HIPCHK(bCnt.alloc(nimg * sizeof(int32_t)));
+    HIPCHK(bDbg.alloc(nimg * 4 * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
+    HIPCHK(bDbgc.alloc(nimg * 3 * STP_FRAME_MAX * sizeof(int16_t)));
+    HIPCHK(hipMemsetAsync(bDbg.p, 0, nimg * 4 * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), ctx->stream));
+    HIPCHK(hipMemcpyAsync(bM.p, &M, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(bB.p, prm->bright, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(bW.p, prm->gauss_w, (2 * prm->gauss_radius + 1) * sizeof(double), hipMemcpyHostToDevice,
+                          ctx->stream));
+    rc = run_chain(ctx, fr, prm, f, 1, (const double*)bM.p, 1, (const double*)bB.p, (const double*)bW.p, (float*)bGray.p,
+                   (stp_u64*)bLow.p, (stp_u64*)bHigh.p, (stp_drec*)bRecs.p, (int32_t*)bCnt.p, 1, (stp_u64*)bDbg.p,
+                   (int16_t*)bDbgc.p);
+    if (rc) return rc;
+    const size_t BW = STP_FRAME_MAX * STP_NW;
+    std::vector<float> hg((size_t)STP_PITCH * STP_PITCH);
+    std::vector<stp_u64> hl(BW), hh(BW), hd(4 * BW);
+    std::vector<int16_t> hc(3 * STP_FRAME_MAX);
+    HIPCHK(hipMemcpyAsync(hg.data(), (float*)bGray.p + (size_t)bi * STP_PITCH * STP_PITCH, hg.size() * sizeof(float),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hl.data(), (stp_u64*)bLow.p + bi * BW, BW * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hh.data(), (stp_u64*)bHigh.p + bi * BW, BW * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hd.data(), (stp_u64*)bDbg.p + (size_t)bi * 4 * BW, 4 * BW * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hc.data(), (int16_t*)bDbgc.p + (size_t)bi * 3 * STP_FRAME_MAX, hc.size() * 2,
+                          hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (gray)
+        for (int y = 0; y < S; y++) memcpy(gray + (size_t)y * S, hg.data() + (size_t)y * STP_PITCH, S * sizeof(float));
+    if (cls) {
+        std::vector<uint8_t> lo((size_t)S * S), hi((size_t)S * S);
+        unpack_bits(hl.data(), S, lo.data());
+        unpack_bits(hh.data(), S, hi.data());
+        for (size_t i = 0; i < (size_t)S * S; i++) cls[i] = (uint8_t)(lo[i] + hi[i]);
+    }
+    if (edges) unpack_bits(hd.data(), S, edges);
+    if (vert) unpack_bits(hd.data() + BW, S, vert);
+    if (tm1) unpack_bits(hd.data() + 2 * BW, S, tm1);
+    if (tm2) unpack_bits(hd.data() + 3 * BW, S, tm2);
+    for (int c = 0; c < S; c++) {
+        if (col_t) col_t[c] = hc[c];
+        if (col_end) col_end[c] = hc[STP_FRAME_MAX + c];
+        if (col_ud) col_ud[c] = hc[2 * STP_FRAME_MAX + c];
+    }
+    return STP_OK;
+}
+
+int stp_set_profiling(stp_ctx* ctx, int on)
+{
+    if (!ctx) return STP_E_ARG;
+    ctx->profiling = on != 0;
+    return STP_OK;
+}
+
+int stp_get_stats(stp_ctx* ctx, stp_kernel_stat* out, int32_t capacity, int32_t* count)
+{
+    if (!ctx || !count) return STP_E_ARG;
+    *count = (int32_t)ctx->stats.size();
+    if ((int32_t)ctx->stats.size() > capacity) return STP_E_CAPACITY;
+    for (size_t i = 0; i < ctx->stats.size(); i++) {
+        memset(&out[i], 0, sizeof(out[i]));
+        strncpy(out[i].name, ctx->stats[i].name.c_str(), sizeof(out[i].name) - 1);
+        out[i].launches = ctx->stats[i].launches;
+        out[i].ms_total = ctx->stats[i].ms;
+        out[i].alg_bytes = ctx->stats[i].bytes;
+    }
+    return STP_OK;
+}
+
+int stp_reset_stats(stp_ctx* ctx)
+{
+    if (!ctx) return STP_E_ARG;
+    ctx->stats.clear();
+    return STP_OK;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

@@ -1,0 +1,261 @@
+"""ctypes binding of libstripenn_hip.so (include/stripenn_hip.h).
+
+This is the only place the package touches the C ABI.  There is no CPU fallback: if the
+library is missing or no gfx950 device is usable, every entry point raises StripennHipError.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libstripenn_hip.so')
+
+STP_FRAME_MAX = 400
+STP_OK, STP_E_ARG, STP_E_CAPACITY, STP_E_HIP, STP_E_NOMEM, STP_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+_ERRNAMES = {-1: 'STP_E_ARG', -2: 'STP_E_CAPACITY', -3: 'STP_E_HIP', -4: 'STP_E_NOMEM', -5: 'STP_E_UNSUPPORTED'}
+
+EXPORTS = [
+    'stp_version', 'stp_ctx_create', 'stp_ctx_destroy', 'stp_last_error', 'stp_ctx_set_stream',
+    'stp_ctx_synchronize', 'stp_band_upload', 'stp_band_wrap_device', 'stp_band_free',
+    'stp_frames_create', 'stp_frames_info', 'stp_frames_free', 'stp_stripe_search', 'stp_dbg_stages',
+    'stp_set_profiling', 'stp_get_stats', 'stp_reset_stats',
+]
+
+
+class StripennHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('%s (%d): %s' % (_ERRNAMES.get(code, 'STP_E_?'), code, msg))
+        self.code = code
+
+
+class SearchParams(C.Structure):
+    _fields_ = [('minH', C.c_int32), ('maxW', C.c_int32), ('bfilter', C.c_int32), ('n_bright', C.c_int32),
+                ('bright', C.POINTER(C.c_double)), ('gauss_radius', C.c_int32), ('gauss_w', C.POINTER(C.c_double))]
+
+
+class StripeRec(C.Structure):
+    _fields_ = [('frame', C.c_int32), ('level', C.c_int32), ('b_index', C.c_int32), ('ud', C.c_int32),
+                ('x', C.c_int32), ('y', C.c_int32), ('w', C.c_int32), ('h', C.c_int32), ('total', C.c_double)]
+
+
+REC_DTYPE = np.dtype([('frame', np.int32), ('level', np.int32), ('b_index', np.int32), ('ud', np.int32),
+                      ('x', np.int32), ('y', np.int32), ('w', np.int32), ('h', np.int32), ('total', np.float64)])
+
+
+class KernelStat(C.Structure):
+    _fields_ = [('name', C.c_char * 32), ('launches', C.c_int64), ('ms_total', C.c_double), ('alg_bytes', C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built: run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StripennHipError(STP_E_HIP, 'libstripenn_hip.so not built (%s); there is no CPU fallback' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.stp_version.restype = C.c_int
+    L.stp_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.stp_ctx_destroy.argtypes = [vp]
+    L.stp_ctx_destroy.restype = None
+    L.stp_last_error.argtypes = [vp]
+    L.stp_last_error.restype = C.c_char_p
+    L.stp_ctx_set_stream.argtypes = [vp, vp]
+    L.stp_ctx_synchronize.argtypes = [vp]
+    L.stp_band_upload.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.stp_band_wrap_device.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.stp_band_free.argtypes = [vp, vp]
+    L.stp_band_free.restype = None
+    L.stp_frames_create.argtypes = [vp, vp, vp, vp, C.c_int32, C.POINTER(vp)]
+    L.stp_frames_info.argtypes = [vp, vp, vp, vp, vp]
+    L.stp_frames_free.argtypes = [vp, vp]
+    L.stp_frames_free.restype = None
+    L.stp_stripe_search.argtypes = [vp, vp, C.POINTER(SearchParams), vp, C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64)]
+    L.stp_dbg_stages.argtypes = [vp, vp, C.POINTER(SearchParams), C.c_int32, C.c_double, C.c_int32] + [vp] * 9
+    L.stp_set_profiling.argtypes = [vp, C.c_int]
+    L.stp_get_stats.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
+    L.stp_reset_stats.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def gauss_weights(sigma, truncate=4.0):
+    """Weights scipy.ndimage.gaussian_filter1d builds for skimage's canny(sigma): the host computes
+    them with numpy exactly as scipy does (same calls, same order) and hands them to the kernels, so
+    the numpy build in use decides their last bit just as it does for the reference."""
+    sd = float(sigma)
+    lw = int(truncate * sd + 0.5)
+    x = np.arange(-lw, lw + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    phi = phi / phi.sum()
+    return np.ascontiguousarray(phi[::-1]), lw
+
+
+def brightness_levels():
+    return np.ascontiguousarray(np.arange(0.5, 1.01, 0.1))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One HIP device + stream.  Not thread-safe; one per process / GPU."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.stp_ctx_create(int(device), C.byref(h))
+        if rc != STP_OK:
+            raise StripennHipError(rc, 'stp_ctx_create(device=%d) failed: no usable gfx950 device' % device)
+        self.h = h
+        self.device = device
+
+    def _chk(self, rc):
+        if rc != STP_OK:
+            raise StripennHipError(rc, self.L.stp_last_error(self.h).decode(errors='replace'))
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.stp_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.stp_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._chk(self.L.stp_ctx_synchronize(self.h))
+
+    # -- band
+    def band_upload(self, band):
+        band = np.ascontiguousarray(band, dtype=np.float64)
+        nrows, W = band.shape
+        return Band(self, band_host=band, nrows=nrows, hw=W // 2)
+
+    def band_wrap(self, dptr, nrows, hw, keepalive=None):
+        return Band(self, dptr=dptr, nrows=nrows, hw=hw, keepalive=keepalive)
+
+    # -- profiling
+    def set_profiling(self, on):
+        self._chk(self.L.stp_set_profiling(self.h, 1 if on else 0))
+
+    def reset_stats(self):
+        self._chk(self.L.stp_reset_stats(self.h))
+
+    def stats(self):
+        buf = (KernelStat * 32)()
+        n = C.c_int32()
+        self._chk(self.L.stp_get_stats(self.h, buf, 32, C.byref(n)))
+        return {buf[i].name.decode(): dict(launches=buf[i].launches, ms=buf[i].ms_total, alg_bytes=buf[i].alg_bytes)
+                for i in range(n.value)}
+
+
+class Band:
+    def __init__(self, ctx, band_host=None, dptr=None, nrows=0, hw=0, keepalive=None):
+        self.ctx = ctx
+        self.nrows, self.hw = int(nrows), int(hw)
+        self.keepalive = keepalive
+        h = C.c_void_p()
+        if band_host is not None:
+            ctx._chk(ctx.L.stp_band_upload(ctx.h, _ptr(band_host), self.nrows, self.hw, C.byref(h)))
+        else:
+            ctx._chk(ctx.L.stp_band_wrap_device(ctx.h, C.c_void_p(dptr), self.nrows, self.hw, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, 'h', None) and self.ctx.h:
+            self.ctx.L.stp_band_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def frames(self, start, end):
+        return Frames(self, start, end)
+
+
+class Frames:
+    def __init__(self, band, start, end):
+        self.band, self.ctx = band, band.ctx
+        self.start = np.ascontiguousarray(start, dtype=np.int32)
+        self.end = np.ascontiguousarray(end, dtype=np.int32)
+        self.n = len(self.start)
+        h = C.c_void_p()
+        self.ctx._chk(self.ctx.L.stp_frames_create(self.ctx.h, band.h, _ptr(self.start), _ptr(self.end), self.n, C.byref(h)))
+        self.h = h
+        self.S = np.zeros(self.n, np.int32)
+        self.nz = np.zeros((self.n, STP_FRAME_MAX), np.int16)
+        self.medpixel = np.zeros(self.n, np.float64)
+        self.ctx._chk(self.ctx.L.stp_frames_info(self.ctx.h, self.h, _ptr(self.S), _ptr(self.nz), _ptr(self.medpixel)))
+
+    def close(self):
+        if getattr(self, 'h', None) and self.ctx.h:
+            self.ctx.L.stp_frames_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _params(minH, maxW, bfilter, bright, gw, gr):
+        bright = np.ascontiguousarray(bright, dtype=np.float64)
+        gw = np.ascontiguousarray(gw, dtype=np.float64)
+        p = SearchParams(int(minH), int(maxW), int(bfilter), len(bright), bright.ctypes.data_as(C.POINTER(C.c_double)),
+                         int(gr), gw.ctypes.data_as(C.POINTER(C.c_double)))
+        return p, (bright, gw)
+
+    def stripe_search(self, M_levels, sigma=2.0, minH=10, maxW=8, bfilter=3, bright=None, gauss_w=None, capacity=None):
+        """Candidate stripes of every frame x level x brightness, as a structured array (REC_DTYPE)."""
+        M_levels = np.ascontiguousarray(M_levels, dtype=np.float64)
+        if bright is None:
+            bright = brightness_levels()
+        if gauss_w is None:
+            gauss_w, gr = gauss_weights(sigma)
+        else:
+            gr = (len(gauss_w) - 1) // 2
+        p, keep = self._params(minH, maxW, bfilter, bright, gauss_w, gr)
+        cap = capacity or max(1024, 64 * self.n * len(M_levels))
+        while True:
+            out = np.zeros(cap, dtype=REC_DTYPE)
+            cnt = C.c_int64()
+            rc = self.ctx.L.stp_stripe_search(self.ctx.h, self.h, C.byref(p), _ptr(M_levels), len(M_levels), _ptr(out),
+                                              cap, C.byref(cnt))
+            if rc == STP_E_CAPACITY and cnt.value > cap:
+                cap = int(cnt.value)
+                continue
+            self.ctx._chk(rc)
+            return out[:cnt.value]
+
+    def dbg_stages(self, f, M, bi, sigma=2.0, minH=10, maxW=8, bfilter=3, bright=None, gauss_w=None):
+        """Per-stage arrays of one image (parity tests)."""
+        if bright is None:
+            bright = brightness_levels()
+        if gauss_w is None:
+            gauss_w, gr = gauss_weights(sigma)
+        else:
+            gr = (len(gauss_w) - 1) // 2
+        p, keep = self._params(minH, maxW, bfilter, bright, gauss_w, gr)
+        S = int(self.S[f])
+        out = dict(gray=np.zeros((S, S), np.float32), cls=np.zeros((S, S), np.uint8), edges=np.zeros((S, S), np.uint8),
+                   vert=np.zeros((S, S), np.uint8), col_t=np.zeros(S, np.int32), col_end=np.zeros(S, np.int32),
+                   col_ud=np.zeros(S, np.int32), testmat1=np.zeros((S, S), np.uint8), testmat2=np.zeros((S, S), np.uint8))
+        self.ctx._chk(self.ctx.L.stp_dbg_stages(self.ctx.h, self.h, C.byref(p), int(f), float(M), int(bi),
+                                                 *[_ptr(out[k]) for k in ('gray', 'cls', 'edges', 'vert', 'col_t',
+                                                                          'col_end', 'col_ud', 'testmat1', 'testmat2')]))
+        return out

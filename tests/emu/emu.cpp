@@ -1,0 +1,106 @@
+// tests/emu/emu.cpp -- CPU replay of ONE workgroup of each libstripenn_hip kernel (tid = 0, nt = 1).
+// TEST-ONLY: lets the CPU test-suite check the kernels' phase code (stripenn_amd/csrc/stp_phases.h)
+// against the oracle without a GPU.  Never linked into the product library.
+#include <vector>
+#include <string.h>
+#include "../../include/stripenn_hip.h"
+#include "../../stripenn_amd/csrc/stp_phases.h"
+
+extern "C" {
+
+// zero-column removal (mirror of k_frame_compact)
+int emu_compact(const double* band, int W, int hw, int64_t st, int n0, int16_t* nz)
+{
+    int S = 0;
+    for (int c = 0; c < n0; c++) {
+        double sum = 0.0;
+        for (int r = 0; r < n0; r++) {
+            double v = band[(st + r) * (int64_t)W + (c - r + hw)];
+            if (v != v) v = 0.0;
+            sum += v;
+        }
+        if (sum != 0.0) nz[S++] = (int16_t)c;
+    }
+    return S > 10 ? S : 0;
+}
+
+void emu_gray(const double* band, int W, int hw, int64_t st, const int16_t* nz, int S, double M, const double* bvals,
+              int nb, int a, float* gray /* nb images, pitch 400 */)
+{
+    std::vector<double> sg((GT_Y + 2 * GT_AMAX) * (GT_X + 2 * GT_AMAX)), sadj(sg.size());
+    for (int ty0 = 0; ty0 < S; ty0 += GT_Y)
+        for (int tx0 = 0; tx0 < S; tx0 += GT_X) {
+            stp_tile T; T.S = S; T.ty0 = ty0; T.tx0 = tx0;
+            gray_p0(0, 1, band, W, hw, st, nz, T, a, M, sg.data());
+            for (int bi = 0; bi < nb; bi++) {
+                gray_p1(0, 1, a, bvals[bi], sg.data(), sadj.data());
+                gray_p2(0, 1, T, a, sadj.data(), gray + (size_t)bi * STP_PITCH * STP_PITCH);
+            }
+        }
+}
+
+void emu_canny(const float* gray /* pitch 400 */, int S, int R, const double* w, stp_u64* low, stp_u64* high)
+{
+    const int GW = ct_gw(R), GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
+    std::vector<float> sG(GH * GW), sV(VH * GW);
+    std::vector<double> sB(2 * VH), sS(VH * (CT_X + 4)), sM((CT_Y + 2) * (CT_X + 2));
+    std::vector<uint8_t> sC(CT_Y * CT_X);
+    memset(low, 0, sizeof(stp_u64) * STP_FRAME_MAX * STP_NW);
+    memset(high, 0, sizeof(stp_u64) * STP_FRAME_MAX * STP_NW);
+    for (int ty0 = 0; ty0 < S; ty0 += CT_Y)
+        for (int tx0 = 0; tx0 < S; tx0 += CT_X) {
+            stp_tile T; T.S = S; T.ty0 = ty0; T.tx0 = tx0;
+            canny_p0(0, 1, gray, T, R, sG.data());
+            canny_p1(0, 1, T, R, w, sG.data(), sV.data());
+            canny_p1b(0, 1, T, R, w, sB.data());
+            canny_p2(0, 1, T, R, w, sV.data(), sB.data(), sS.data());
+            canny_p3(0, 1, T, sS.data(), sM.data());
+            canny_p4(0, 1, T, sS.data(), sM.data(), sC.data());
+            canny_p5(0, 1, T, sC.data(), low, high);
+        }
+}
+
+struct emu_rec { int32_t ud, x, y, w, h; double total; };
+
+// mirror of k_lines; dbg: E, V, T1, T2 bit matrices (each 400*7 words); cols: t, end, ud (3 x 400)
+int emu_lines(const stp_u64* low, const stp_u64* high, const double* band, int W, int hw, int64_t st,
+              const int16_t* nz, int S, int minH, int maxW, stp_u64* dbg, int16_t* cols, emu_rec* recs, int cap,
+              int* sweeps_out)
+{
+    const int BW = STP_FRAME_MAX * STP_NW;
+    std::vector<stp_u64> buf0(BW), buf1(BW), buf2(BW);
+    std::vector<int16_t> colT(400), colEnd(400), colUd(400), cnt(400), minr(400), maxr(400), cidx(400), clen(400), xs(408);
+    std::vector<stp_lrec> lrec(STP_RCAP);
+    std::vector<double> rs(400);
+    lines_load(0, 1, S, low, high, buf0.data(), buf1.data());
+    int sweeps = 0;
+    while (lines_hyst_sweep(0, 1, S, buf0.data(), buf1.data())) sweeps++;
+    if (sweeps_out) *sweeps_out = sweeps;
+    lines_vline(0, 1, S, buf1.data(), buf2.data());
+    lines_v3(0, 1, S, buf2.data(), buf0.data());
+    lines_block(0, 1, S, minH, buf2.data(), buf0.data(), colT.data(), colEnd.data(), colUd.data());
+    memcpy(dbg, buf1.data(), BW * 8);
+    memcpy(dbg + BW, buf2.data(), BW * 8);
+    for (int i = 0; i < S; i++) { cols[i] = colT[i]; cols[400 + i] = colEnd[i]; cols[800 + i] = colUd[i]; }
+    int nrec = 0;
+    for (int ud = 1; ud <= 2; ud++) {
+        lines_zero(0, 1, S * STP_NW, buf0.data());
+        lines_paint(0, 1, S, ud, colEnd.data(), colUd.data(), buf0.data());
+        lines_refine(0, 1, S, buf1.data(), buf2.data(), buf0.data());
+        lines_colstat(0, 1, S, buf0.data(), cnt.data(), minr.data(), maxr.data());
+        memcpy(dbg + (size_t)(1 + ud) * BW, buf0.data(), BW * 8);
+        nrec = lines_group_pairs(S, ud, maxW, cnt.data(), minr.data(), maxr.data(), cidx.data(), clen.data(), xs.data(),
+                                 lrec.data(), nrec, STP_RCAP);
+    }
+    int nst = nrec < STP_RCAP ? nrec : STP_RCAP;
+    for (int k = 0; k < nst && k < cap; k++) {
+        stp_lrec rc = lrec[k];
+        lines_rowsum(0, 1, S, band, W, hw, st, nz, rc, rs.data());
+        double tot = 0.0;
+        for (int i = 0; i < rc.h; i++) tot += rs[i];
+        recs[k].ud = rc.ud; recs[k].x = rc.x; recs[k].y = rc.y; recs[k].w = rc.w; recs[k].h = rc.h; recs[k].total = tot;
+    }
+    return nrec;
+}
+
+}  // extern "C"
