@@ -230,8 +230,15 @@ struct stp_kstat {
     double bytes = 0.0;
 };
 
+struct stp_pending {
+    hipEvent_t e0, e1;
+    const char* name;
+    double bytes;
+};
+
 struct stp_ctx {
     int device = 0;
+    std::vector<stp_pending> pending;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
@@ -279,25 +286,43 @@ static stp_kstat& stat_for(stp_ctx* ctx, const char* name)
     return ctx->stats.back();
 }
 
+// Kernel timing without stalling the stream: each profiled launch records an event pair; the
+// pairs are resolved (hipEventElapsedTime) when statistics are read.
 struct prof_scope {
     stp_ctx* ctx;
     const char* name;
     double bytes;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     prof_scope(stp_ctx* c, const char* n, double b) : ctx(c), name(n), bytes(b)
     {
-        if (ctx->profiling) (void)hipEventRecord(ctx->ev0, ctx->stream);
+        if (!ctx->profiling) return;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+        (void)hipEventRecord(e0, ctx->stream);
     }
     ~prof_scope()
     {
-        if (!ctx->profiling) return;
-        (void)hipEventRecord(ctx->ev1, ctx->stream);
-        (void)hipEventSynchronize(ctx->ev1);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-        stp_kstat& s = stat_for(ctx, name);
-        s.launches++; s.ms += ms; s.bytes += bytes;
+        if (!ctx->profiling || !e0) return;
+        (void)hipEventRecord(e1, ctx->stream);
+        stp_pending p;
+        p.e0 = e0; p.e1 = e1; p.name = name; p.bytes = bytes;
+        ctx->pending.push_back(p);
     }
 };
+
+static void resolve_pending(stp_ctx* ctx)
+{
+    for (auto& p : ctx->pending) {
+        (void)hipEventSynchronize(p.e1);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            stp_kstat& s = stat_for(ctx, p.name);
+            s.launches++; s.ms += ms; s.bytes += p.bytes;
+        }
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+    }
+    ctx->pending.clear();
+}
 
 extern "C" {
 #pragma GCC visibility push(default)
@@ -339,6 +364,7 @@ void stp_ctx_destroy(stp_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    resolve_pending(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -678,6 +704,7 @@ int stp_set_profiling(stp_ctx* ctx, int on)
 int stp_get_stats(stp_ctx* ctx, stp_kernel_stat* out, int32_t capacity, int32_t* count)
 {
     if (!ctx || !count) return STP_E_ARG;
+    resolve_pending(ctx);
     *count = (int32_t)ctx->stats.size();
     if ((int32_t)ctx->stats.size() > capacity) return STP_E_CAPACITY;
     for (size_t i = 0; i < ctx->stats.size(); i++) {
@@ -693,6 +720,7 @@ int stp_get_stats(stp_ctx* ctx, stp_kernel_stat* out, int32_t capacity, int32_t*
 int stp_reset_stats(stp_ctx* ctx)
 {
     if (!ctx) return STP_E_ARG;
+    resolve_pending(ctx);
     ctx->stats.clear();
     return STP_OK;
 }
