@@ -69,7 +69,9 @@ void stp_band_free(stp_ctx* ctx, stp_band* band);
  * search_frame's window + zero-column removal (getStripe.py:808-821) and StripeSearch's
  * medpixel (getStripe.py:885) for a batch of frames [start[f], end[f]] (inclusive bin indices,
  * end - start + 1 <= 400).  S[f] = number of kept columns, or 0 when <= 10 remain (:818).
- * nz[f*400 + k] = offset (0..399) of kept column k inside the frame. */
+ * nz[f*400 + k] = offset (0..399) of kept column k inside the frame.
+ * medpixel[f] = np.quantile(submat[submat > 0], 0.5): exact order statistics by radix select on
+ * the device, numpy's linear interpolation applied by the library on the host. */
 int stp_frames_create(stp_ctx* ctx, const stp_band* band, const int32_t* start, const int32_t* end,
                       int32_t nframes, stp_frames** out);
 int stp_frames_info(stp_ctx* ctx, const stp_frames* fr, int32_t* S_out, int16_t* nz_out /* nframes*400 */,
@@ -113,6 +115,76 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
                    int32_t bi, float* gray, uint8_t* cls /* 0,1 low,2 high */, uint8_t* edges,
                    uint8_t* vert, int32_t* col_t, int32_t* col_end, int32_t* col_ud,
                    uint8_t* testmat_ud1, uint8_t* testmat_ud2);
+
+/* ---- expected values: getStripe.mpmean (getStripe.py:178-235) --------------------------------
+ * For every 400-row frame f of the chromosome and diagonal j < 400:
+ *   part_sum[f*400 + j] = sum_i M[i][i+j] over the frame's rows i with i + j < nrows (NaN -> 0),
+ *                         accumulated in row order exactly like the reference's inner loop (:198-207)
+ *   part_cnt[f*400 + j] = number of terms.
+ * The host adds the frames in order and divides (:225-233).  n400 = ceil(nrows / 400). */
+int stp_diag_sums(stp_ctx* ctx, const stp_band* band, double* part_sum, int64_t* part_cnt, int32_t n400);
+
+/* ---- background windows: getStripe.nulldist (getStripe.py:347-378, 389-414, 447-477) ---------
+ * One sample = one randomly chosen row x of the unit matrix mat = M[row0:row0+nrow, col0:col0+ncol]
+ * (the reference's fetch at :326, NaN -> 0).  For j = 0..399 the six bs x bs window means around
+ * columns x -/+ j (+ yoff) are taken with Python slice semantics on mat and numpy's np.mean
+ * summation order, and the four "centre - flank" tables are written: T[j*n + i], T in
+ * {left_up, right_up, left_down, right_down}.  Sampling (random.Random) stays on the host. */
+typedef struct {
+    int32_t row0, nrow;   /* mat rows    = bins [row0, row0 + nrow) */
+    int32_t col0, ncol;   /* mat columns = bins [col0, col0 + ncol) */
+    int32_t x;            /* sampled row index inside mat */
+    int32_t yoff;         /* 400 for units > 0, else 0 (getStripe.py:358-360) */
+} stp_null_sample;
+/* unit_matrix (may be NULL): the host-fetched mat itself (nrow x ncol, NaN preserved), to be given
+ * when some window's Python slice wraps around (negative start: the reference's top-up branch has
+ * no 410-row margin, getStripe.py:438-440, and at 1 kb the 20-row margin is too small) -- such a
+ * window reads columns far outside the diagonal band.  With NULL the resident band is read. */
+int stp_null_windows(stp_ctx* ctx, const stp_band* band, const double* unit_matrix, const stp_null_sample* samples,
+                     int32_t n, int32_t bs, double* left_up, double* right_up, double* left_down, double* right_down);
+
+/* ---- background tables resident on the device ---------------------------------------------- */
+typedef struct stp_background stp_background;
+int stp_background_upload(stp_ctx* ctx, const double* left_up, const double* right_up, const double* left_down,
+                          const double* right_down, int32_t ncol, stp_background** out); /* each 400 x ncol */
+void stp_background_free(stp_ctx* ctx, stp_background* bg);
+
+/* ---- per-stripe p-value: getStripe.pvalue (getStripe.py:536-606) ----------------------------
+ * mat = M[row0:row1, col0:col1] (the fetch at :560); centre / left / right = mat[:, bs:-bs],
+ * mat[:, :bs], mat[:, -bs:]; row means in numpy order; rank against the background rows; median.
+ * The host decides the direction exactly like :584-597, including the inherited ("fixed")
+ * background rows when a stripe touches neither end of the diagonal. */
+typedef struct {
+    int32_t row0, row1, col0, col1;
+    int32_t mode;       /* 0 down: table *_down, row j; 1 up: table *_up, row upbase-j-1; 2 fixed */
+    int32_t upbase;     /* y2 - y1 (getStripe.py:592) */
+    int32_t fixed_row;  /* mode 2 */
+    int32_t fixed_tab;  /* mode 2: 0 = *_up tables, 1 = *_down tables */
+} stp_pv_stripe;
+int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int32_t bs,
+               const stp_pv_stripe* stripes, int64_t n, double* out_p);
+
+/* ---- Stripiness: getStripe.scoringstripes + stats.elementwise_product_sum --------------------
+ * (getStripe.py:661-759, stats.py:184-199).  Block b = 0 centre, 1 left, 2 right.
+ * Output tolerance: 1e-4 relative (floating-point statistics; order of additions may differ). */
+typedef struct {
+    int32_t row0, row1;           /* observed rows [row0, row1) = y_coord fetch            */
+    int32_t col0[3], col1[3];     /* observed columns of each block                         */
+    int32_t ex0[3];               /* first x index of each block's expected matrix (:685,691,697) */
+    int32_t ey0;                  /* y_start_index                                          */
+    int32_t mirror;               /* 0 if xs == ys else 1 (row deletion rule :716-731)       */
+    int32_t mcol0[3], mcol1[3];   /* masked relative column range [lo, hi] per block; lo > hi: none */
+    int32_t mrow0, mrow1;         /* masked relative row range                               */
+} stp_score_stripe;
+int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, const stp_score_stripe* stripes,
+                   int64_t n, double* out_g, double* out_oe_mean, double* out_oe_total);
+
+/* ---- observed mean / sum: getStripe.getMean (getStripe.py:501-534) -------------------------- */
+typedef struct {
+    int32_t row0, row1, col0, col1;
+} stp_rect;
+int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rects, int64_t n, double* out_mean,
+                    double* out_sum);
 
 /* ---- statistics / profiling ---------------------------------------------------------------
  * When profiling is on, every kernel launch is bracketed by HIP events on the ctx stream. */

@@ -160,3 +160,155 @@ def frame_dense(fetch_block, start, end):
     colsum = np.sum(D, axis=0)
     nz = np.where(colsum != 0)[0]
     return D, nz
+
+
+# ====================================================================== score path (numeric restatements)
+# These take the same explicit integer inputs as the C ABI (include/stripenn_hip.h) and use numpy
+# itself for the reductions the reference performs with numpy, so their summation order is the
+# reference's by construction.  `M(r0, r1, c0, c1)` returns the dense block with NaN preserved.
+
+def _lib_score():
+    L = lib()
+    if not hasattr(L, '_score_ready'):
+        L.so_null_windows.argtypes = [np.ctypeslib.ndpointer(np.float64, flags='C'), C.c_int64, C.c_int64,
+                                      np.ctypeslib.ndpointer(np.int64, flags='C'), C.c_int64, C.c_int, C.c_int] + \
+                                     [np.ctypeslib.ndpointer(np.float64, flags='C')] * 4
+        L.so_block_mean.restype = C.c_double
+        L.so_block_mean.argtypes = [C.c_void_p] + [C.c_int64] * 6
+        L._score_ready = True
+    return L
+
+
+def diag_sums(M, nrows):
+    """getStripe.py:198-207 per 400-row frame: row-ordered sums of each diagonal 0..399 and term counts."""
+    n400 = -(-nrows // 400)
+    ps = np.zeros((n400, 400)); pc = np.zeros((n400, 400), np.int64)
+    for f in range(n400):
+        r0, r1 = f * 400, min((f + 1) * 400, nrows)
+        c1 = min((f + 2) * 400, nrows)
+        cfm = np.array(M(r0, r1, r0, c1), dtype=np.float64)
+        cfm[np.isnan(cfm)] = 0
+        for j in range(400):
+            d = np.diagonal(cfm, offset=j)          # cfm[i, i+j] while i+j < cols
+            if len(d):
+                ps[f, j] = np.cumsum(d)[-1]           # sequential accumulation, like the Python loop
+                pc[f, j] = len(d)
+    return ps, pc
+
+
+def null_windows(M, row0, nrow, col0, ncol, xs, yoff, bs):
+    """getStripe.py:347-378: the four centre-minus-flank tables (400 x len(xs)) of one unit matrix."""
+    mat = np.ascontiguousarray(M(row0, row0 + nrow, col0, col0 + ncol), dtype=np.float64)
+    mat[np.isnan(mat)] = 0
+    xs = np.ascontiguousarray(xs, dtype=np.int64)
+    n = len(xs)
+    out = [np.zeros((400, n)) for _ in range(4)]
+    if n:
+        _lib_score().so_null_windows(mat, nrow, ncol, xs, n, int(bs), int(yoff), *out)
+    return out
+
+
+def pvalue_one(mat, bs, mode, upbase, fixed_row, fixed_tab, bg):
+    """getStripe.py:561-605 for one stripe.  mat = fetched rows x (cols incl. flanks), NaN preserved;
+    bg = (left_up, right_up, left_down, right_down)."""
+    mat = np.array(mat, dtype=np.float64)
+    parts = []
+    for sl in (slice(bs, -bs), slice(None, bs), slice(-bs, None)):
+        v = mat[:, sl]
+        v[np.isnan(v)] = 0
+        with np.errstate(invalid='ignore', divide='ignore'):
+            parts.append(np.mean(v, axis=1))
+    center, left, right = parts
+    ld, rd = center - left, center - right
+    pv = []
+    for j in range(len(center)):
+        if mode == 0:
+            d, tab = min(j, 399), 1
+        elif mode == 1:
+            d = upbase - j - 1
+            d, tab = (399 if d >= 400 else d), 0
+        else:
+            d, tab = fixed_row, fixed_tab
+        bl = bg[2 if tab else 0][d, :]
+        br = bg[3 if tab else 1][d, :]
+        p1 = np.count_nonzero(bl >= ld[j]) / np.count_nonzero(~np.isnan(bl))
+        p2 = np.count_nonzero(br >= rd[j]) / np.count_nonzero(~np.isnan(br))
+        p = max(p1, p2)
+        if p == 0:
+            p = 1 / len(bl)
+        pv.append(p)
+    return float(np.median(pv))
+
+
+def _expected(exval, x0, nx, y0, ny):
+    """expecMatrix (getStripe.py:641-659): exval[min(|x - y|, 399)]"""
+    idx = np.abs(np.arange(x0, x0 + nx)[None, :] - np.arange(y0, y0 + ny)[:, None])
+    idx[idx >= 400] = 399
+    return np.asarray(exval, dtype=np.float64)[idx]
+
+
+def stripiness_one(obs, exval, ex0, ey0, mirror, mcol, mrow):
+    """getStripe.py:684-759 for one stripe.  obs = [centre, left, right] observed blocks (NaN kept),
+    ex0[b] = first x index of block b's expected matrix, mcol[b] = (lo, hi) masked relative columns
+    (lo > hi: none), mrow likewise.  Returns (g, centerMean, centerTotal)."""
+    blocks = []
+    with np.errstate(divide='ignore', invalid='ignore'):
+        for b in range(3):
+            o = np.array(obs[b], dtype=np.float64)
+            e = _expected(exval, ex0[b], o.shape[1], ey0, o.shape[0]) + .00000001
+            m = np.divide(o, e)
+            if mcol[b][0] <= mcol[b][1]:
+                m[:, mcol[b][0]:mcol[b][1] + 1] = np.nan
+            if mrow[0] <= mrow[1]:
+                m[mrow[0]:mrow[1] + 1, :] = np.nan
+            blocks.append(m)
+        rowdel = []
+        for b in range(3):
+            dead = [x for x in range(blocks[b].shape[1]) if np.isnan(blocks[b][:, x]).all()]
+            if dead:
+                blocks[b] = np.delete(blocks[b], dead, axis=1)
+                rowdel += dead if not mirror else [blocks[b].shape[0] - 1 - x for x in dead]
+        rowdel = np.unique(rowdel)
+        if len(rowdel):
+            blocks = [np.delete(m, rowdel.astype(int), axis=0) for m in blocks]
+        for m in blocks:
+            m[np.isnan(m)] = 0
+        cm, lm, rm = [np.mean(m, axis=1) for m in blocks]
+        center = blocks[0]
+        rows = np.where(~np.isnan(center))[0]
+        ctot = np.sum(center[rows])
+        cmean = np.mean(center[rows])
+        n = len(cm)
+        gxl, gxr, gy = [], [], []
+        for i in range(1, n - 1):
+            t = 0
+            t += (-1 * lm[i - 1] + -2 * lm[i]) + -1 * lm[i + 1]
+            t += (1 * cm[i - 1] + 2 * cm[i]) + 1 * cm[i + 1]
+            gxl.append(t)
+            t = 0
+            t += (1 * cm[i - 1] + 2 * cm[i]) + 1 * cm[i + 1]
+            t += (-1 * rm[i - 1] + -2 * rm[i]) + -1 * rm[i + 1]
+            gxr.append(t)
+            t = 0
+            t += (1 * lm[i - 1] + 0 * lm[i]) + -1 * lm[i + 1]
+            t += (2 * cm[i - 1] + 0 * cm[i]) + -2 * cm[i + 1]
+            t += (1 * rm[i - 1] + 0 * rm[i]) + -1 * rm[i + 1]
+            if t < 0:
+                t *= -1
+            gy.append(t)
+        gx = np.minimum(gxl, gxr)
+        diff = [a - b for a, b in zip(gx, gy)]
+        diff = [x for x in diff if x >= 0 or x < 0]
+        g = float(np.nanmedian(cm) * np.mean(diff))
+    return g, cmean, ctot
+
+
+def stripe_mean_one(block):
+    """getStripe.py:518-521"""
+    with np.errstate(invalid='ignore'):
+        return np.nanmean(block), np.nansum(block)
+
+
+def medpixel(D):
+    """getStripe.py:885"""
+    return float(np.quantile(D[D > 0], 0.5))

@@ -1,0 +1,139 @@
+"""End-to-end goldens: the unmodified reference getStripe class driven in the call order of
+stripenn.compute (stripenn.py:120-159) and score.getScore (score.py:49-60) on a small synthetic
+genome.  Imported by gen_golden.py (python3.9 only).  stripenn.py / score.py themselves cannot be
+imported here because they `import cooler` (absent); only their call ORDER is restated.
+"""
+import os, sys, hashlib, io, contextlib
+import numpy as np
+import pandas as pd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+from stripenn_amd import synth
+import stripenn.getStripe as gs_mod
+
+E2E_SIZES = [1400 * 5000 - 3210, 900 * 5000 - 777]
+E2E_NAMES = ['chr1', 'chr2']
+E2E_SEED0 = 31
+E2E_MAXPIXEL = [0.95, 0.98]
+E2E_PRNG_SEED = 123456789
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@contextlib.contextmanager
+def quiet():
+    so, se = sys.stdout, sys.stderr
+    sys.stdout = io.StringIO(); sys.stderr = io.StringIO()
+    try:
+        yield
+    finally:
+        sys.stdout, sys.stderr = so, se
+
+
+class Info:
+    pass
+
+
+def df_to_store(store, prefix, df, cols_int, cols_float, cols_str):
+    store[prefix + 'n'] = len(df)
+    for c in cols_int:
+        store[prefix + c] = df[c].to_numpy(dtype=np.int64)
+    for c in cols_float:
+        store[prefix + c.replace('/', '_')] = df[c].to_numpy(dtype=np.float64)
+    for c in cols_str:
+        store[prefix + c] = np.array([str(v) for v in df[c]], dtype='U16')
+
+
+def run(core, tag):
+    resol = 5000
+    names, sizes, sel = synth.make_genome(E2E_SIZES, resol, seed0=E2E_SEED0, names=E2E_NAMES)
+    obj = gs_mod.getStripe(sel, resol, 10, 8, 2.0, list(names), list(names), np.array(sizes), np.array(sizes), core,
+                           3, E2E_PRNG_SEED)
+    info = Info(); info.chromsizes = pd.Series(sizes, index=names)
+    store = {'resol': resol, 'sizes': np.array(sizes), 'names': np.array(names), 'seed0': E2E_SEED0,
+             'maxpixel': np.array(E2E_MAXPIXEL), 'prng_seed': E2E_PRNG_SEED, 'core': core}
+    with quiet():
+        MP = obj.getQuantile_original(info, names, E2E_MAXPIXEL)       # stripenn.py:126
+        EV = obj.mpmean()                                              # stripenn.py:128
+        bg = obj.nulldist()                                            # stripenn.py:130
+    for nm in names:
+        store['MP_' + nm] = MP[nm]
+        store['EV_' + nm] = np.array(EV[nm], dtype=np.float64)
+    for k, t in zip(('lu', 'ru', 'ld', 'rd'), bg):
+        store['bg_%s_sha' % k] = sha(t)
+        store['bg_%s_shape' % k] = np.array(t.shape)
+        store['bg_%s_cols' % k] = np.ascontiguousarray(t[:, ::37])      # sample of columns for diagnostics
+    if core != 1:
+        np.savez_compressed(os.path.join(OUT, 'e2e_%s.npz' % tag), **store)
+        print('e2e', tag, 'bg shapes', [t.shape for t in bg])
+        return
+    cols = ['chr', 'pos1', 'pos2', 'chr2', 'pos3', 'pos4', 'length', 'width', 'total', 'Mean', 'maxpixel', 'num',
+            'start', 'end', 'x', 'y', 'h', 'w', 'medpixel', 'pvalue']
+    result_table = pd.DataFrame(columns=cols)
+    ints = ['pos1', 'pos2', 'pos3', 'pos4', 'length', 'width', 'num', 'start', 'end', 'x', 'y', 'h', 'w']
+    flts = ['total', 'Mean', 'medpixel', 'pvalue']
+    for i, perc in enumerate(E2E_MAXPIXEL):                            # stripenn.py:134-138
+        with quiet():
+            res = obj.extract(MP, i, perc, *bg)
+        df_to_store(store, 'ex%d_' % i, res, ints, flts, ['chr', 'maxpixel'])
+        result_table = pd.concat([result_table, res])
+        print('e2e extract', perc, len(res))
+    with quiet():
+        result_table = gs_mod.getStripe.RemoveRedundant(obj, df=result_table, by='pvalue')   # stripenn.py:144
+        s = obj.scoringstripes(result_table, EV, '0')                                         # stripenn.py:147
+    df_to_store(store, 'rr_', result_table, ints, flts, ['chr', 'maxpixel'])
+    store['rr_g'] = np.array(s[0], dtype=np.float64)
+    store['rr_oe_mean'] = np.array(s[1], dtype=np.float64)
+    store['rr_oe_total'] = np.array(s[2], dtype=np.float64)
+    rt = result_table.drop(columns=['total', 'num', 'start', 'end', 'x', 'y', 'h', 'w', 'medpixel'])
+    rt.insert(rt.shape[1], 'Stripiness', s[0], True)
+    filt = rt[rt['pvalue'] < 0.1].sort_values(by=['Stripiness'], ascending=False)
+    b1, b2 = io.StringIO(), io.StringIO()
+    rt.to_csv(b1, sep='\t', header=True, index=False)
+    filt.to_csv(b2, sep='\t', header=True, index=False)
+    store['tsv_unfiltered'] = np.array(b1.getvalue())
+    store['tsv_filtered'] = np.array(b2.getvalue())
+    # masked scoring (stripenn --mask): same table, a mask inside chr1.  The reference's masking()
+    # raises IndexError when the mask reaches the last column of a block (getStripe.py:625-633 uses
+    # L = ncols + 1), so candidate masks are tried until the reference itself accepts one.
+    p1 = int(result_table['pos1'].iloc[0])
+    for off0, off1 in ((-30000, -20000), (-40000, -30000), (-25000, -15000), (60000, 65000)):
+        mask = 'chr1:%d-%d' % (p1 + off0, p1 + off1)
+        try:
+            with quiet():
+                sm = obj.scoringstripes(result_table, EV, mask)
+            break
+        except IndexError:
+            sm = None
+    store['mask'] = np.array(mask if sm is not None else '')
+    if sm is not None:
+        store['rr_g_masked'] = np.array(sm[0], dtype=np.float64)
+    print('mask used', mask, sm is not None)
+    # score path (score.py:49-60): fresh object with minH=10, maxW=8, canny=2.5, bfilter=1
+    table = rt[['chr', 'pos1', 'pos2', 'chr2', 'pos3', 'pos4']].reset_index(drop=True)
+    obj2 = gs_mod.getStripe(sel, resol, 10, 8, 2.5, list(names), list(names), np.array(sizes), np.array(sizes), core,
+                            1, E2E_PRNG_SEED)
+    with quiet():
+        EV2 = obj2.mpmean()
+        bg2 = obj2.nulldist()
+        pval = obj2.pvalue(*bg2, table)
+        MEAN, SUM = obj2.getMean(table)
+        s2, MEANOE, TOTALOE = obj2.scoringstripes(table, EV2, '0')
+    store['sc_pvalue'] = np.array(pval, dtype=np.float64)
+    store['sc_mean'] = np.array(MEAN, dtype=np.float64)
+    store['sc_sum'] = np.array(SUM, dtype=np.float64)
+    store['sc_g'] = np.array(s2, dtype=np.float64)
+    store['sc_oe_mean'] = np.array(MEANOE, dtype=np.float64)
+    store['sc_oe_total'] = np.array(TOTALOE, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, 'e2e_%s.npz' % tag), **store)
+    print('e2e', tag, 'final rows', len(rt), 'filtered', len(filt))
+
+
+def e2e_goldens():
+    run(1, 'seq')      # numcores=1: the PRNG stream runs on across chromosomes
+    run(2, 'par')      # numcores>1: loky pickles self, every chromosome restarts from the seed

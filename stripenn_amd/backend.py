@@ -1,0 +1,122 @@
+"""HIP backend: the façade's view of libstripenn_hip.so (one context, one resident band per chromosome).
+
+The façade (stripenn_amd/getStripe.py) talks to this small interface only, so the CPU test-suite
+can exercise the façade's host logic with a checker backend that lives under tests/ (built on the
+oracle).  The product constructs HipBackend and nothing else: no CPU fallback exists here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import hip
+
+NULL_SAMPLE_DTYPE = np.dtype([('row0', np.int32), ('nrow', np.int32), ('col0', np.int32), ('ncol', np.int32),
+                              ('x', np.int32), ('yoff', np.int32)])
+PV_STRIPE_DTYPE = np.dtype([('row0', np.int32), ('row1', np.int32), ('col0', np.int32), ('col1', np.int32),
+                            ('mode', np.int32), ('upbase', np.int32), ('fixed_row', np.int32), ('fixed_tab', np.int32)])
+SCORE_STRIPE_DTYPE = np.dtype([('row0', np.int32), ('row1', np.int32), ('col0', np.int32, (3,)), ('col1', np.int32, (3,)),
+                               ('ex0', np.int32, (3,)), ('ey0', np.int32), ('mirror', np.int32),
+                               ('mcol0', np.int32, (3,)), ('mcol1', np.int32, (3,)), ('mrow0', np.int32),
+                               ('mrow1', np.int32)])
+RECT_DTYPE = np.dtype([('row0', np.int32), ('row1', np.int32), ('col0', np.int32), ('col1', np.int32)])
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class HipBackend:
+    name = 'hip'
+
+    def __init__(self, device=0):
+        self.ctx = hip.Context(device)
+        L = self.ctx.L
+        vp = C.c_void_p
+        L.stp_diag_sums.argtypes = [vp, vp, vp, vp, C.c_int32]
+        L.stp_null_windows.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, vp]
+        L.stp_background_upload.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.POINTER(vp)]
+        L.stp_background_free.argtypes = [vp, vp]
+        L.stp_background_free.restype = None
+        L.stp_pvalue.argtypes = [vp, vp, vp, C.c_int32, vp, C.c_int64, vp]
+        L.stp_stripiness.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]
+        L.stp_stripe_mean.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
+        self._bg = None
+        self._bg_key = None
+
+    # ---- chromosome band
+    def open_chrom(self, band_host):
+        return self.ctx.band_upload(band_host)
+
+    def close_chrom(self, band):
+        band.close()
+
+    def frames(self, band, starts, ends):
+        return band.frames(starts, ends)
+
+    def stripe_search(self, frames, M_levels, sigma, minH, maxW, bfilter):
+        return frames.stripe_search(M_levels, sigma=sigma, minH=minH, maxW=maxW, bfilter=bfilter)
+
+    # ---- score path
+    def diag_sums(self, band):
+        n400 = -(-band.nrows // 400)
+        ps = np.zeros((n400, 400), np.float64)
+        pc = np.zeros((n400, 400), np.int64)
+        self.ctx._chk(self.ctx.L.stp_diag_sums(self.ctx.h, band.h, _p(ps), _p(pc), n400))
+        return ps, pc
+
+    def null_windows(self, band, samples, bs, unit_matrix=None):
+        samples = np.ascontiguousarray(samples, dtype=NULL_SAMPLE_DTYPE)
+        n = len(samples)
+        out = [np.zeros((400, n), np.float64) for _ in range(4)]
+        if n:
+            um = None
+            if unit_matrix is not None:
+                um = np.ascontiguousarray(unit_matrix, dtype=np.float64)
+            self.ctx._chk(self.ctx.L.stp_null_windows(self.ctx.h, band.h, None if um is None else _p(um), _p(samples), n,
+                                                      int(bs), *[_p(o) for o in out]))
+        return out
+
+    def set_background(self, lu, ru, ld, rd):
+        key = tuple(id(t) for t in (lu, ru, ld, rd))
+        if self._bg is not None and key == self._bg_key:
+            return
+        self.clear_background()
+        tabs = [np.ascontiguousarray(t, dtype=np.float64) for t in (lu, ru, ld, rd)]
+        ncol = tabs[0].shape[1]
+        h = C.c_void_p()
+        self.ctx._chk(self.ctx.L.stp_background_upload(self.ctx.h, *[_p(t) for t in tabs], ncol, C.byref(h)))
+        self._bg, self._bg_key, self._bg_keep = h, key, (lu, ru, ld, rd)
+
+    def clear_background(self):
+        if self._bg is not None and self.ctx.h:
+            self.ctx.L.stp_background_free(self.ctx.h, self._bg)
+        self._bg = None
+        self._bg_key = None
+
+    def pvalue(self, band, bs, stripes):
+        stripes = np.ascontiguousarray(stripes, dtype=PV_STRIPE_DTYPE)
+        out = np.zeros(len(stripes), np.float64)
+        if len(stripes):
+            self.ctx._chk(self.ctx.L.stp_pvalue(self.ctx.h, band.h, self._bg, int(bs), _p(stripes), len(stripes), _p(out)))
+        return out
+
+    def stripiness(self, band, exval, stripes):
+        stripes = np.ascontiguousarray(stripes, dtype=SCORE_STRIPE_DTYPE)
+        exval = np.ascontiguousarray(exval, dtype=np.float64)
+        n = len(stripes)
+        g, m, t = np.zeros(n), np.zeros(n), np.zeros(n)
+        if n:
+            self.ctx._chk(self.ctx.L.stp_stripiness(self.ctx.h, band.h, _p(exval), _p(stripes), n, _p(g), _p(m), _p(t)))
+        return g, m, t
+
+    def stripe_mean(self, band, rects):
+        rects = np.ascontiguousarray(rects, dtype=RECT_DTYPE)
+        n = len(rects)
+        m, s = np.zeros(n), np.zeros(n)
+        if n:
+            self.ctx._chk(self.ctx.L.stp_stripe_mean(self.ctx.h, band.h, _p(rects), n, _p(m), _p(s)))
+        return m, s
+
+    def close(self):
+        self.clear_background()
+        self.ctx.close()

@@ -1,0 +1,440 @@
+// stp_score.h -- kernels of the score path: expected values (mpmean), background windows
+// (nulldist), per-stripe p-value, Stripiness, observed mean, and the per-frame medpixel.
+// Included by stripenn_hip.hip only (device code).
+//
+// Summation order: the p-value is a RANK against the background tables, so the window / row
+// means that feed it reproduce numpy's reduction order exactly (pairwise inner loop of
+// numpy/core/src/umath/loops_utils.h.src, rows accumulated in order).  Stripiness and the
+// observed mean are plain floating-point statistics (tolerance 1e-4 relative in the contract);
+// they use the same helpers where that is free.
+#pragma once
+#include "../../include/stripenn_hip.h"
+#include "stp_phases.h"
+
+#define STP_SCORE_MAXROWS 1024
+#define STP_SCORE_MAXCOLS 256
+
+struct stp_bandref {
+    const double* d;
+    int64_t nrows;
+    int W, hw;
+};
+
+// M[r][c] with NaN kept; 0 outside the band / chromosome
+__device__ __forceinline__ double band_at(const stp_bandref& B, int64_t r, int64_t c)
+{
+    int64_t dd = c - r + B.hw;
+    if (r < 0 || r >= B.nrows || c < 0 || c >= B.nrows || dd < 0 || dd >= B.W) return 0.0;
+    return B.d[r * (int64_t)B.W + dd];
+}
+__device__ __forceinline__ double band_at0(const stp_bandref& B, int64_t r, int64_t c)
+{
+    double v = band_at(B, r, c);
+    return (v != v) ? 0.0 : v;   // nantozero
+}
+
+// numpy pairwise sum of n values get(0..n)
+template <class F>
+__device__ double stp_pw_leaf(F get, int64_t o, int n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; i++) res += get(o + i);
+        return res;
+    }
+    double r0 = get(o), r1 = get(o + 1), r2 = get(o + 2), r3 = get(o + 3), r4 = get(o + 4), r5 = get(o + 5),
+           r6 = get(o + 6), r7 = get(o + 7);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += get(o + i); r1 += get(o + i + 1); r2 += get(o + i + 2); r3 += get(o + i + 3);
+        r4 += get(o + i + 4); r5 += get(o + i + 5); r6 += get(o + i + 6); r7 += get(o + i + 7);
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += get(o + i);
+    return res;
+}
+template <class F>
+__device__ double stp_pw(F get, int64_t o, int64_t n)
+{
+    if (n <= 128) return stp_pw_leaf(get, o, (int)n);
+    // explicit post-order evaluation of pw(o,n) = pw(o,n2) + pw(o+n2,n-n2), n2 = n/2 - (n/2)%8
+    int64_t so[24], sn[24];
+    double sv[24];
+    int state[24];
+    int sp = 0;
+    so[0] = o; sn[0] = n; state[0] = 0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        int64_t cn = sn[sp], co = so[sp];
+        if (cn <= 128) { ret = stp_pw_leaf(get, co, (int)cn); sp--; continue; }
+        int64_t n2 = cn / 2; n2 -= n2 % 8;
+        if (state[sp] == 0) { state[sp] = 1; so[sp + 1] = co; sn[sp + 1] = n2; state[sp + 1] = 0; sp++; }
+        else if (state[sp] == 1) { sv[sp] = ret; state[sp] = 2; so[sp + 1] = co + n2; sn[sp + 1] = cn - n2; state[sp + 1] = 0; sp++; }
+        else { ret = sv[sp] + ret; sp--; }
+    }
+    return ret;
+}
+
+__device__ __forceinline__ void stp_pyslice(int64_t a, int64_t b, int64_t n, int64_t* lo, int64_t* hi)
+{
+    if (a < 0) { a += n; if (a < 0) a = 0; }
+    if (a > n) a = n;
+    if (b < 0) { b += n; if (b < 0) b = 0; }
+    if (b > n) b = n;
+    if (b < a) b = a;
+    *lo = a; *hi = b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// getStripe.mpmean (getStripe.py:198-207): per 400-row frame, per diagonal j, the row-ordered sum
+__global__ __launch_bounds__(448) void k_diag_sums(stp_bandref B, double* __restrict__ psum, long long* __restrict__ pcnt)
+{
+    const int f = blockIdx.x, j = threadIdx.x;
+    if (j >= STP_NDIAG) return;
+    const int64_t r0 = (int64_t)f * 400;
+    double s = 0.0;
+    long long c = 0;
+    for (int i = 0; i < 400; i++) {
+        int64_t r = r0 + i;
+        if (r >= B.nrows || r + j >= B.nrows) break;
+        double v = B.d[r * (int64_t)B.W + B.hw + j];
+        if (v != v) v = 0.0;
+        s += v;
+        c++;
+    }
+    psum[(size_t)f * STP_NDIAG + j] = s;
+    pcnt[(size_t)f * STP_NDIAG + j] = c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// getStripe.nulldist window means (getStripe.py:347-378).  mat = M[row0:row0+nrow, col0:col0+ncol]
+// with NaN -> 0; python slice semantics on mat's extents; np.mean order (needs bs*bs <= 8192).
+
+// `dense` (may be null): the unit matrix itself, nrow x ncol row-major, NaN preserved.  It is supplied
+// by the host for batches in which a Python slice wraps around (negative start) and therefore reads
+// columns far outside the diagonal band; otherwise the resident band is read.
+__device__ double null_block_mean(const stp_bandref& B, const double* __restrict__ dense, const stp_null_sample& s,
+                                  int64_t r0, int64_t r1, int64_t c0, int64_t c1)
+{
+    int64_t rl, rh, cl, ch;
+    stp_pyslice(r0, r1, s.nrow, &rl, &rh);
+    stp_pyslice(c0, c1, s.ncol, &cl, &ch);
+    const int64_t cnt = (rh - rl) * (ch - cl);
+    double acc = 0.0;
+    if (cnt > 0) {
+        // numpy buffers the strided slice (<= 8192 elements) and runs one pairwise loop over the
+        // row-major flattened block
+        const int64_t w = ch - cl;
+        if (dense) {
+            const double* base = dense + rl * (int64_t)s.ncol + cl;
+            const int64_t nc = s.ncol;
+            acc = stp_pw([&](int64_t k) { double v = base[(k / w) * nc + (k % w)]; return (v != v) ? 0.0 : v; }, 0, cnt);
+        } else {
+            const int64_t gr0 = s.row0 + rl, gc0 = s.col0 + cl;
+            acc = stp_pw([&](int64_t k) { return band_at0(B, gr0 + k / w, gc0 + k % w); }, 0, cnt);
+        }
+    }
+    return acc / (double)cnt;
+}
+
+__global__ __launch_bounds__(256) void k_null_windows(stp_bandref B, const double* __restrict__ dense,
+                                                       const stp_null_sample* __restrict__ samp, int n, int bs,
+                                                       double* __restrict__ lu, double* __restrict__ ru,
+                                                       double* __restrict__ ld, double* __restrict__ rd)
+{
+    const int i = blockIdx.x;
+    const stp_null_sample s = samp[i];
+    const int up = bs / 2, down = bs - up;
+    const int64_t x = s.x;
+    for (int it = threadIdx.x; it < 2 * STP_NDIAG; it += blockDim.x) {
+        const int j = it >> 1, dn = it & 1;
+        const int64_t y = (dn ? x + j : x - j) + s.yoff;
+        double l = null_block_mean(B, dense, s, x - up - bs, x - up, y - up, y + down);
+        double c = null_block_mean(B, dense, s, x - up, x + down, y - up, y + down);
+        double r = null_block_mean(B, dense, s, x + down, x + down + bs, y - up, y + down);
+        double* L = dn ? ld : lu;
+        double* R = dn ? rd : ru;
+        L[(size_t)j * n + i] = c - l;
+        R[(size_t)j * n + i] = c - r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// getStripe.pvalue (getStripe.py:552-605) for one stripe per workgroup
+
+__device__ __forceinline__ double wave_sum_i(int v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return (double)v;
+}
+
+// median of vals[0..n) (np.median: mean of the two middle order statistics)
+__device__ double block_median(const double* vals, int n, double* s_res)
+{
+    const int k0 = (n - 1) / 2, k1 = n / 2;
+    if (threadIdx.x == 0) { s_res[0] = 0.0; s_res[1] = 0.0; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double v = vals[i];
+        int less = 0, leq = 0;
+        for (int k = 0; k < n; k++) { less += vals[k] < v; leq += vals[k] <= v; }
+        if (less <= k0 && k0 < leq) s_res[0] = v;
+        if (less <= k1 && k1 < leq) s_res[1] = v;
+    }
+    __syncthreads();
+    return (k0 == k1) ? s_res[0] : (s_res[0] + s_res[1]) / 2.0;
+}
+
+__global__ __launch_bounds__(256) void k_pvalue(stp_bandref B, const double* __restrict__ bg /* lu,ru,ld,rd: 4 x 400 x ncol */,
+                                                 int ncolbg, int bs, const stp_pv_stripe* __restrict__ st, double* __restrict__ out)
+{
+    __shared__ double pv[STP_SCORE_MAXROWS];
+    __shared__ double s_res[2];
+    const stp_pv_stripe s = st[blockIdx.x];
+    const int h = s.row1 - s.row0;
+    const int ncol = s.col1 - s.col0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const size_t TS = (size_t)STP_NDIAG * ncolbg;
+    int64_t cl, ch, ll, lh, rl, rh;
+    stp_pyslice(bs, -bs, ncol, &cl, &ch);        // mat[:, bs:-bs]
+    stp_pyslice(0, bs, ncol, &ll, &lh);          // mat[:, :bs]
+    stp_pyslice(-bs, ncol, ncol, &rl, &rh);      // mat[:, -bs:]
+    for (int j = wv; j < h; j += nw) {
+        const int64_t gr = s.row0 + j;
+        double ldv = 0.0, rdv = 0.0;
+        if (lane == 0) {
+            auto get = [&](int64_t k) { return band_at0(B, gr, s.col0 + k); };
+            double c = stp_pw(get, cl, ch - cl) / (double)(ch - cl);
+            double l = stp_pw(get, ll, lh - ll) / (double)(lh - ll);
+            double r = stp_pw(get, rl, rh - rl) / (double)(rh - rl);
+            ldv = c - l; rdv = c - r;
+        }
+        ldv = __shfl(ldv, 0); rdv = __shfl(rdv, 0);
+        int d, tab;
+        if (s.mode == 0) { d = j; tab = 1; }
+        else if (s.mode == 1) { d = s.upbase - j - 1; tab = 0; }
+        else { d = s.fixed_row; tab = s.fixed_tab; }
+        if (s.mode != 2 && d >= 400) d = 399;
+        if (d < 0) d += STP_NDIAG;               // python negative index on the table (never for real stripes)
+        const double* bl = bg + (size_t)(tab ? 2 : 0) * TS + (size_t)d * ncolbg;
+        const double* br = bg + (size_t)(tab ? 3 : 1) * TS + (size_t)d * ncolbg;
+        int cL = 0, vL = 0, cR = 0, vR = 0;
+        for (int k = lane; k < ncolbg; k += 64) {
+            double a = bl[k], b = br[k];
+            cL += a >= ldv; vL += (a == a);
+            cR += b >= rdv; vR += (b == b);
+        }
+        double p1 = wave_sum_i(cL) / wave_sum_i(vL);
+        double p2 = wave_sum_i(cR) / wave_sum_i(vR);
+        double p = (p2 > p1) ? p2 : p1;          // python max(p1, p2)
+        if (p == 0.0) p = 1.0 / (double)ncolbg;
+        if (lane == 0) pv[j] = p;
+    }
+    __syncthreads();
+    double med = block_median(pv, h, s_res);
+    if (threadIdx.x == 0) out[blockIdx.x] = med;
+}
+
+// ---------------------------------------------------------------------------------------------
+// getStripe.scoringstripes.iterate_idx (getStripe.py:661-759) for one stripe per workgroup
+
+__global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double* __restrict__ exval,
+                                                     const stp_score_stripe* __restrict__ st, double* __restrict__ out_g,
+                                                     double* __restrict__ out_mean, double* __restrict__ out_total)
+{
+    __shared__ double ex[STP_NDIAG];
+    __shared__ double rowm[3][STP_SCORE_MAXROWS];
+    __shared__ double diff[STP_SCORE_MAXROWS];
+    __shared__ int16_t keepc[3][STP_SCORE_MAXCOLS];
+    __shared__ int16_t keepr[STP_SCORE_MAXROWS];
+    __shared__ uint8_t rowdel[STP_SCORE_MAXROWS];
+    __shared__ int nkc[3], nkr;
+    __shared__ double s_res[2];
+    __shared__ double s_tot;
+    const stp_score_stripe s = st[blockIdx.x];
+    const int h = s.row1 - s.row0;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < STP_NDIAG; i += nt) ex[i] = exval[i];
+    for (int i = tid; i < h; i += nt) rowdel[i] = 0;
+    __syncthreads();
+    // observed / expected with masking; NaN where the observed pixel is NaN or masked
+    auto oe = [&](int b, int r, int c) -> double {
+        bool masked = (c >= s.mcol0[b] && c <= s.mcol1[b]) || (r >= s.mrow0 && r <= s.mrow1);
+        if (masked) return NAN;
+        double o = band_at(B, s.row0 + r, s.col0[b] + c);
+        int idx = (s.ex0[b] + c) - (s.ey0 + r);
+        if (idx < 0) idx = -idx;
+        if (idx >= 400) idx = 399;
+        double e = ex[idx] + .00000001;
+        return o / e;
+    };
+    // all-NaN columns (:709-711) and the rows they delete (:713-733)
+    if (tid < 3) nkc[tid] = 0;
+    __syncthreads();
+    for (int b = 0; b < 3; b++) {
+        const int w = s.col1[b] - s.col0[b];
+        for (int c = tid; c < w; c += nt) {
+            bool allnan = true;
+            for (int r = 0; r < h && allnan; r++) { double v = oe(b, r, c); allnan = (v != v); }
+            keepc[b][c] = allnan ? 0 : 1;
+            if (allnan) {
+                int rd = s.mirror ? (h - 1 - c) : c;
+                if (rd < 0) rd += h;
+                if (rd >= 0 && rd < h) rowdel[rd] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int b = 0; b < 3; b++) {
+            const int w = s.col1[b] - s.col0[b];
+            int n = 0;
+            for (int c = 0; c < w; c++) if (keepc[b][c]) keepc[b][n++] = (int16_t)c;
+            nkc[b] = n;
+        }
+        int n = 0;
+        for (int r = 0; r < h; r++) if (!rowdel[r]) keepr[n++] = (int16_t)r;
+        nkr = n;
+        s_tot = 0.0;
+    }
+    __syncthreads();
+    const int hk = nkr;
+    // row means after nantozero (:739-745), numpy pairwise order over the kept columns
+    for (int it = tid; it < 3 * hk; it += nt) {
+        const int b = it / hk, q = it - b * hk, r = keepr[q];
+        const int n = nkc[b];
+        double sum = stp_pw([&](int64_t k) { double v = oe(b, r, keepc[b][k]); return (v != v) ? 0.0 : v; }, 0, n);
+        rowm[b][q] = sum / (double)n;
+    }
+    __syncthreads();
+    // centerTotal / centerMean (:747-748): sum over center[rows repeated once per kept column]
+    if (tid == 0) {
+        const int n = nkc[0];
+        double T = 0.0;
+        for (int q = 0; q < hk; q++) T += rowm[0][q] * (double)n;   // row sums
+        s_tot = T;
+    }
+    // Sobel-like scores (:750-756, stats.py:184-199)
+    for (int i = tid + 1; i < hk - 1; i += nt) {
+        const double* cm = rowm[0]; const double* lm = rowm[1]; const double* rm = rowm[2];
+        double gxl = 0.0, gxr = 0.0, gy = 0.0;
+        gxl += (-1.0 * lm[i - 1] + -2.0 * lm[i]) + -1.0 * lm[i + 1];
+        gxl += (1.0 * cm[i - 1] + 2.0 * cm[i]) + 1.0 * cm[i + 1];
+        gxr += (1.0 * cm[i - 1] + 2.0 * cm[i]) + 1.0 * cm[i + 1];
+        gxr += (-1.0 * rm[i - 1] + -2.0 * rm[i]) + -1.0 * rm[i + 1];
+        gy += (1.0 * lm[i - 1] + 0.0 * lm[i]) + -1.0 * lm[i + 1];
+        gy += (2.0 * cm[i - 1] + 0.0 * cm[i]) + -2.0 * cm[i + 1];
+        gy += (1.0 * rm[i - 1] + 0.0 * rm[i]) + -1.0 * rm[i + 1];
+        if (gy < 0) gy *= -1;
+        double gx = (gxl < gxr || gxl != gxl) ? gxl : gxr;   // np.minimum (NaN propagates)
+        if (gxr != gxr) gx = gxr;
+        diff[i - 1] = gx - gy;
+    }
+    __syncthreads();
+    const int nd = hk - 2 > 0 ? hk - 2 : 0;
+    double med = 0.0;
+    // np.nanmedian(centerm): compact the non-NaN values into rowm[1] (left means are no longer needed)
+    __shared__ int s_nm;
+    if (tid == 0) {
+        int n = 0;
+        for (int q = 0; q < hk; q++) { double v = rowm[0][q]; if (v == v) rowm[1][n++] = v; }
+        s_nm = n;
+    }
+    __syncthreads();
+    if (s_nm > 0) med = block_median(rowm[1], s_nm, s_res);
+    else med = NAN;
+    if (tid == 0) {
+        // diff = [x for x in diff if x >= 0 or x < 0]; np.mean(diff)
+        int n = 0;
+        for (int q = 0; q < nd; q++) { double v = diff[q]; if (v == v) diff[n++] = v; }
+        double avg = stp_pw([&](int64_t k) { return diff[k]; }, 0, n) / (double)n;
+        out_g[blockIdx.x] = med * avg;
+        const int nc = nkc[0];
+        out_total[blockIdx.x] = s_tot * (double)nc;
+        out_mean[blockIdx.x] = (s_tot * (double)nc) / ((double)hk * nc * nc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// getStripe.getMean (getStripe.py:518-521): nanmean / nansum of the observed stripe pixels
+
+__global__ __launch_bounds__(256) void k_stripe_mean(stp_bandref B, const stp_rect* __restrict__ rc, double* __restrict__ out_mean,
+                                                      double* __restrict__ out_sum)
+{
+    __shared__ double ssum[256];
+    __shared__ long long scnt[256];
+    const stp_rect r = rc[blockIdx.x];
+    const int h = r.row1 - r.row0, w = r.col1 - r.col0;
+    double s = 0.0;
+    long long c = 0;
+    for (int64_t i = threadIdx.x; i < (int64_t)h * w; i += blockDim.x) {
+        double v = band_at(B, r.row0 + i / w, r.col0 + i % w);
+        if (v == v) { s += v; c++; }
+    }
+    ssum[threadIdx.x] = s; scnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { ssum[threadIdx.x] += ssum[threadIdx.x + o]; scnt[threadIdx.x] += scnt[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out_sum[blockIdx.x] = ssum[0]; out_mean[blockIdx.x] = ssum[0] / (double)scnt[0]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// StripeSearch's medpixel = np.quantile(submat[submat > 0], 0.5) (getStripe.py:885): exact order
+// statistics by an 8-pass radix select over the frame's positive pixels (positive doubles order
+// like their bit patterns).  out[f*3 + {0,1,2}] = a[(N-1)//2], a[N//2], N.
+__global__ __launch_bounds__(1024) void k_medpixel(stp_bandref B, const int32_t* __restrict__ fstart,
+                                                    const int32_t* __restrict__ fn0, double* __restrict__ out)
+{
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned int s_k, s_n;
+    const int f = blockIdx.x;
+    const int64_t st = fstart[f];
+    const int n0 = fn0[f];
+    const int64_t tot = (int64_t)n0 * n0;
+    // count positives
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    unsigned int loc = 0;
+    for (int64_t i = threadIdx.x; i < tot; i += blockDim.x) {
+        int r = (int)(i / n0), c = (int)(i - (int64_t)r * n0);
+        double v = B.d[(st + r) * (int64_t)B.W + (c - r + B.hw)];
+        loc += (v > 0.0);
+    }
+    atomicAdd(&s_n, loc);
+    __syncthreads();
+    const unsigned int N = s_n;
+    double res[2] = {NAN, NAN};
+    for (int which = 0; which < 2 && N > 0; which++) {
+        unsigned int k = which ? N / 2 : (N - 1) / 2;
+        unsigned long long prefix = 0;
+        for (int pass = 0; pass < 8; pass++) {
+            const int shift = 56 - 8 * pass;
+            for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+            __syncthreads();
+            for (int64_t i = threadIdx.x; i < tot; i += blockDim.x) {
+                int r = (int)(i / n0), c = (int)(i - (int64_t)r * n0);
+                double v = B.d[(st + r) * (int64_t)B.W + (c - r + B.hw)];
+                if (!(v > 0.0)) continue;
+                unsigned long long key = (unsigned long long)__double_as_longlong(v);
+                bool match = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
+                if (match) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned int acc = 0;
+                int d = 0;
+                for (; d < 256; d++) { if (acc + hist[d] > k) break; acc += hist[d]; }
+                s_k = k - acc;
+                s_prefix = prefix | ((unsigned long long)d << shift);
+            }
+            __syncthreads();
+            k = s_k; prefix = s_prefix;
+            __syncthreads();
+        }
+        res[which] = __longlong_as_double((long long)prefix);
+    }
+    if (threadIdx.x == 0) { out[f * 3] = res[0]; out[f * 3 + 1] = res[1]; out[f * 3 + 2] = (double)N; }
+}

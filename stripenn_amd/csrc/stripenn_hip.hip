@@ -9,6 +9,7 @@
 #include <new>
 #include "../../include/stripenn_hip.h"
 #include "stp_phases.h"
+#include "stp_score.h"
 
 // ============================================================================================
 // device kernels
@@ -487,6 +488,30 @@ int stp_frames_create(stp_ctx* ctx, const stp_band* band, const int32_t* start, 
                            fr->d_n0, fr->d_S, fr->d_nz);
     }
     FRCHK(hipGetLastError());
+    {
+        // medpixel: two order statistics per frame by radix select, numpy's lerp on the host
+        double* d_med = nullptr;
+        FRCHK(hipMalloc((void**)&d_med, (size_t)n * 3 * sizeof(double)));
+        {
+            double bytes = 0;
+            for (int i = 0; i < n; i++) bytes += 8.0 * fr->h_n0[i] * fr->h_n0[i];
+            prof_scope ps(ctx, "medpixel", bytes);
+            stp_bandref B{band->d, band->nrows, band->W, band->hw};
+            hipLaunchKernelGGL(k_medpixel, dim3(n), dim3(1024), 0, ctx->stream, B, fr->d_start, fr->d_n0, d_med);
+        }
+        std::vector<double> hm((size_t)n * 3);
+        hipError_t e1 = hipMemcpyAsync(hm.data(), d_med, hm.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_med);
+        FRCHK(e1);
+        for (int i = 0; i < n; i++) {
+            const double a = hm[3 * i], b = hm[3 * i + 1], N = hm[3 * i + 2];
+            if (N < 1) { fr->h_med[i] = NAN; continue; }
+            // numpy _lerp with t = frac((N-1)*0.5): t = 0 -> a ; t = 0.5 -> b - (b-a)*(1-t)
+            const bool even = (((long long)N) % 2) == 0;
+            fr->h_med[i] = even ? (b - (b - a) * (1 - 0.5)) : (a + (b - a) * 0.0);
+        }
+    }
     FRCHK(hipMemcpyAsync(fr->h_S.data(), fr->d_S, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     FRCHK(hipMemcpyAsync(fr->h_nz.data(), fr->d_nz, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), hipMemcpyDeviceToHost,
                          ctx->stream));
@@ -691,6 +716,209 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
         if (col_end) col_end[c] = hc[STP_FRAME_MAX + c];
         if (col_ud) col_ud[c] = hc[2 * STP_FRAME_MAX + c];
     }
+    return STP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// score path
+struct stp_background {
+    double* d = nullptr;   // lu | ru | ld | rd, each 400 x ncol
+    int ncol = 0;
+};
+
+static stp_bandref bref(const stp_band* b) { return stp_bandref{b->d, b->nrows, b->W, b->hw}; }
+
+int stp_diag_sums(stp_ctx* ctx, const stp_band* band, double* part_sum, int64_t* part_cnt, int32_t n400)
+{
+    if (!ctx || !band || !part_sum || !part_cnt) return STP_E_ARG;
+    if (n400 != (int32_t)((band->nrows + 399) / 400)) return set_err(ctx, STP_E_ARG, "n400 must be ceil(nrows/400)");
+    HIPCHK(hipSetDevice(ctx->device));
+    dev_buf bs, bc;
+    const size_t n = (size_t)n400 * STP_NDIAG;
+    HIPCHK(bs.alloc(n * sizeof(double)));
+    HIPCHK(bc.alloc(n * sizeof(long long)));
+    {
+        prof_scope ps(ctx, "diag_sums", 8.0 * 400.0 * (double)band->nrows);
+        hipLaunchKernelGGL(k_diag_sums, dim3(n400), dim3(448), 0, ctx->stream, bref(band), (double*)bs.p, (long long*)bc.p);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(part_sum, bs.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(part_cnt, bc.p, n * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return STP_OK;
+}
+
+int stp_null_windows(stp_ctx* ctx, const stp_band* band, const double* unit_matrix, const stp_null_sample* samples,
+                     int32_t n, int32_t bs, double* lu, double* ru, double* ld, double* rd)
+{
+    if (!ctx || !band || !samples || n <= 0 || !lu || !ru || !ld || !rd) return STP_E_ARG;
+    if (unit_matrix)
+        for (int i = 1; i < n; i++)
+            if (samples[i].row0 != samples[0].row0 || samples[i].nrow != samples[0].nrow ||
+                samples[i].col0 != samples[0].col0 || samples[i].ncol != samples[0].ncol)
+                return set_err(ctx, STP_E_ARG, "with a unit matrix all samples of a call must share its geometry");
+    if (bs < 1 || bs * bs > 8192) return set_err(ctx, STP_E_UNSUPPORTED, "background size must satisfy bs*bs <= 8192");
+    for (int i = 0; i < n; i++) {
+        const stp_null_sample& s = samples[i];
+        if (s.nrow <= 0 || s.ncol <= 0 || s.row0 < 0 || s.col0 < 0 || s.row0 + s.nrow > band->nrows ||
+            s.col0 + s.ncol > band->nrows)
+            return set_err(ctx, STP_E_ARG, "null sample " + std::to_string(i) + ": unit matrix outside the chromosome");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    dev_buf bS, bO, bD;
+    const size_t tn = (size_t)STP_NDIAG * n;
+    if (unit_matrix) {
+        const size_t mb = (size_t)samples[0].nrow * samples[0].ncol * sizeof(double);
+        HIPCHK(bD.alloc(mb));
+        HIPCHK(hipMemcpyAsync(bD.p, unit_matrix, mb, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(bS.alloc((size_t)n * sizeof(stp_null_sample)));
+    HIPCHK(bO.alloc(4 * tn * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(bS.p, samples, (size_t)n * sizeof(stp_null_sample), hipMemcpyHostToDevice, ctx->stream));
+    double* o = (double*)bO.p;
+    {
+        prof_scope ps(ctx, "null_windows", 8.0 * (3.0 * bs) * (800.0 + bs) * n);
+        hipLaunchKernelGGL(k_null_windows, dim3(n), dim3(256), 0, ctx->stream, bref(band), (const double*)(unit_matrix ? bD.p : nullptr),
+                           (const stp_null_sample*)bS.p, n, bs, o, o + tn, o + 2 * tn, o + 3 * tn);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(lu, o, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ru, o + tn, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ld, o + 2 * tn, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(rd, o + 3 * tn, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return STP_OK;
+}
+
+int stp_background_upload(stp_ctx* ctx, const double* lu, const double* ru, const double* ld, const double* rd,
+                          int32_t ncol, stp_background** out)
+{
+    if (!ctx || !lu || !ru || !ld || !rd || ncol <= 0 || !out) return STP_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    stp_background* bg = new (std::nothrow) stp_background();
+    if (!bg) return STP_E_NOMEM;
+    const size_t tn = (size_t)STP_NDIAG * ncol;
+    if (hipMalloc((void**)&bg->d, 4 * tn * sizeof(double)) != hipSuccess) { delete bg; return set_err(ctx, STP_E_NOMEM, "hipMalloc(background)"); }
+    bg->ncol = ncol;
+    const double* src[4] = {lu, ru, ld, rd};
+    for (int t = 0; t < 4; t++) {
+        hipError_t e = hipMemcpyAsync(bg->d + t * tn, src[t], tn * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(bg->d); delete bg; return set_err(ctx, STP_E_HIP, "background upload failed"); }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out = bg;
+    return STP_OK;
+}
+
+void stp_background_free(stp_ctx* ctx, stp_background* bg)
+{
+    if (!bg) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (bg->d) (void)hipFree(bg->d);
+    delete bg;
+}
+
+static int check_rect(stp_ctx* ctx, const stp_band* band, int64_t i, int r0, int r1, int c0, int c1, int maxrows, int maxcols)
+{
+    if (r0 < 0 || c0 < 0 || r1 > band->nrows || c1 > band->nrows || r1 <= r0 || c1 < c0)
+        return set_err(ctx, STP_E_ARG, "stripe " + std::to_string(i) + ": region outside the chromosome");
+    if (r1 - r0 > maxrows || c1 - c0 > maxcols)
+        return set_err(ctx, STP_E_UNSUPPORTED, "stripe " + std::to_string(i) + ": longer than 1024 bins or wider than 256 bins");
+    // every pixel must lie inside the stored band
+    if ((int64_t)c1 - 1 - r0 >= band->hw || (int64_t)r1 - 1 - c0 > band->hw)
+        return set_err(ctx, STP_E_ARG, "stripe " + std::to_string(i) + ": region leaves the +-halfwidth band; upload a wider band");
+    return STP_OK;
+}
+
+int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int32_t bs, const stp_pv_stripe* st, int64_t n,
+               double* out_p)
+{
+    if (!ctx || !band || !bg || !st || !out_p || n < 0 || bs < 1) return STP_E_ARG;
+    if (n == 0) return STP_OK;
+    for (int64_t i = 0; i < n; i++) {
+        int rc = check_rect(ctx, band, i, st[i].row0, st[i].row1, st[i].col0, st[i].col1, STP_SCORE_MAXROWS, 1 << 20);
+        if (rc) return rc;
+        if (st[i].mode < 0 || st[i].mode > 2 || (st[i].mode == 2 && (st[i].fixed_row < 0 || st[i].fixed_row >= STP_NDIAG)))
+            return set_err(ctx, STP_E_ARG, "stripe " + std::to_string(i) + ": bad direction mode");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    dev_buf bS, bO;
+    HIPCHK(bS.alloc((size_t)n * sizeof(stp_pv_stripe)));
+    HIPCHK(bO.alloc((size_t)n * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(bS.p, st, (size_t)n * sizeof(stp_pv_stripe), hipMemcpyHostToDevice, ctx->stream));
+    {
+        double bytes = 0;
+        for (int64_t i = 0; i < n; i++) bytes += (8.0 * (st[i].col1 - st[i].col0) + 16000.0) * (st[i].row1 - st[i].row0);
+        prof_scope ps(ctx, "pvalue", bytes);
+        hipLaunchKernelGGL(k_pvalue, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bg->d, bg->ncol, bs,
+                           (const stp_pv_stripe*)bS.p, (double*)bO.p);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_p, bO.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return STP_OK;
+}
+
+int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, const stp_score_stripe* st, int64_t n,
+                   double* out_g, double* out_mean, double* out_total)
+{
+    if (!ctx || !band || !exval400 || !st || !out_g || !out_mean || !out_total || n < 0) return STP_E_ARG;
+    if (n == 0) return STP_OK;
+    for (int64_t i = 0; i < n; i++)
+        for (int b = 0; b < 3; b++) {
+            int rc = check_rect(ctx, band, i, st[i].row0, st[i].row1, st[i].col0[b], st[i].col1[b], STP_SCORE_MAXROWS,
+                                STP_SCORE_MAXCOLS);
+            if (rc) return rc;
+        }
+    HIPCHK(hipSetDevice(ctx->device));
+    dev_buf bS, bE, bO;
+    HIPCHK(bS.alloc((size_t)n * sizeof(stp_score_stripe)));
+    HIPCHK(bE.alloc(STP_NDIAG * sizeof(double)));
+    HIPCHK(bO.alloc((size_t)n * 3 * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(bS.p, st, (size_t)n * sizeof(stp_score_stripe), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(bE.p, exval400, STP_NDIAG * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    double* o = (double*)bO.p;
+    {
+        double bytes = 0;
+        for (int64_t i = 0; i < n; i++)
+            for (int b = 0; b < 3; b++) bytes += 8.0 * (st[i].col1[b] - st[i].col0[b]) * (st[i].row1 - st[i].row0);
+        prof_scope ps(ctx, "stripiness", bytes);
+        hipLaunchKernelGGL(k_stripiness, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bE.p,
+                           (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_g, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_mean, o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_total, o + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return STP_OK;
+}
+
+int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rc, int64_t n, double* out_mean, double* out_sum)
+{
+    if (!ctx || !band || !rc || !out_mean || !out_sum || n < 0) return STP_E_ARG;
+    if (n == 0) return STP_OK;
+    for (int64_t i = 0; i < n; i++) {
+        int r = check_rect(ctx, band, i, rc[i].row0, rc[i].row1, rc[i].col0, rc[i].col1, 1 << 20, 1 << 20);
+        if (r) return r;
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    dev_buf bS, bO;
+    HIPCHK(bS.alloc((size_t)n * sizeof(stp_rect)));
+    HIPCHK(bO.alloc((size_t)n * 2 * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(bS.p, rc, (size_t)n * sizeof(stp_rect), hipMemcpyHostToDevice, ctx->stream));
+    double* o = (double*)bO.p;
+    {
+        double bytes = 0;
+        for (int64_t i = 0; i < n; i++) bytes += 8.0 * (rc[i].col1 - rc[i].col0) * (rc[i].row1 - rc[i].row0);
+        prof_scope ps(ctx, "stripe_mean", bytes);
+        hipLaunchKernelGGL(k_stripe_mean, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const stp_rect*)bS.p, o, o + n);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out_mean, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_sum, o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return STP_OK;
 }
 

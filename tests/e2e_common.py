@@ -1,0 +1,129 @@
+"""Shared end-to-end check: the façade (stripenn_amd.getStripe) driven in the call order of the
+reference's stripenn.compute (stripenn.py:120-159) and score.getScore (score.py:49-60), compared
+with tables produced by the unmodified reference (tests/golden/e2e_seq.npz)."""
+import hashlib
+import io
+import os
+
+import numpy as np
+import pandas as pd
+
+from stripenn_amd import synth, getStripe as GS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INTS = ['pos1', 'pos2', 'pos3', 'pos4', 'length', 'width', 'num', 'start', 'end', 'x', 'y', 'h', 'w']
+REL_TOL = 1e-4     # north star: Mean / pvalue / Stripiness within 1e-4 relative
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def load(tag='seq'):
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'e2e_%s.npz' % tag))
+    st = np.load(os.path.join(ROOT, 'tests', 'golden', 'stages_chr7.npz'))
+    names = [str(x) for x in g['names']]
+    sizes = g['sizes']
+    _, _, sel = synth.make_genome(list(sizes), int(g['resol']), seed0=int(g['seed0']), names=names)
+    return g, st, names, sizes, sel
+
+
+def close(a, b, exact):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    if exact:
+        return np.array_equal(a, b, equal_nan=True)
+    return np.allclose(a, b, rtol=REL_TOL, atol=0, equal_nan=True)
+
+
+def check_table(g, prefix, df, float_exact):
+    assert int(g[prefix + 'n']) == len(df), (prefix, int(g[prefix + 'n']), len(df))
+    for c in INTS:      # positions / sizes: always bit-exact
+        assert np.array_equal(df[c].to_numpy(dtype=np.int64), g[prefix + c]), (prefix, c)
+    assert [str(v) for v in df['chr']] == [str(v) for v in g[prefix + 'chr']]
+    assert [str(v) for v in df['maxpixel']] == [str(v) for v in g[prefix + 'maxpixel']]
+    for c in ('total', 'Mean', 'medpixel', 'pvalue'):
+        assert close(df[c], g[prefix + c], float_exact), (prefix, c)
+
+
+class Info:
+    pass
+
+
+def run_compute(make_backend, float_exact, core=1):
+    """Returns nothing; asserts every intermediate and the final TSVs against the reference."""
+    g, st, names, sizes, sel = load('seq')
+    resol = int(g['resol'])
+    obj = GS.getStripe(sel, resol, 10, 8, 2.0, names, names, sizes, sizes, core, 3, int(g['prng_seed']),
+                       backend=make_backend(np.ascontiguousarray(st['gw_2p0'])))
+    info = Info(); info.chromsizes = pd.Series(sizes, index=names)
+    MP = obj.getQuantile_original(info, names, list(g['maxpixel']))
+    for n in names:
+        assert np.array_equal(MP[n], g['MP_' + n])
+    EV = obj.mpmean()
+    for n in names:
+        assert np.array_equal(np.array(EV[n]), g['EV_' + n]), 'expected values differ'
+    bg = obj.nulldist()
+    for t, k in zip(bg, ('lu', 'ru', 'ld', 'rd')):
+        assert tuple(g['bg_%s_shape' % k]) == t.shape
+        assert sha(t) == str(g['bg_%s_sha' % k]), 'background table %s differs from the reference' % k
+    rt = pd.DataFrame(columns=GS.EXTRACT_COLUMNS + ['pvalue'])
+    for i, perc in enumerate(g['maxpixel']):
+        res = obj.extract(MP, i, float(perc), *bg)
+        check_table(g, 'ex%d_' % i, res, float_exact)
+        rt = pd.concat([rt, res])
+    rt = obj.RemoveRedundant(df=rt, by='pvalue')
+    check_table(g, 'rr_', rt, float_exact)
+    s = obj.scoringstripes(rt, EV, '0')
+    assert close(s[0], g['rr_g'], float_exact), 'Stripiness differs'
+    assert close(s[1], g['rr_oe_mean'], False) and close(s[2], g['rr_oe_total'], False)
+    out = rt.drop(columns=['total', 'num', 'start', 'end', 'x', 'y', 'h', 'w', 'medpixel'])
+    out.insert(out.shape[1], 'Stripiness', s[0], True)
+    filt = out[out['pvalue'] < 0.1].sort_values(by=['Stripiness'], ascending=False)
+    b1, b2 = io.StringIO(), io.StringIO()
+    out.to_csv(b1, sep='\t', header=True, index=False)
+    filt.to_csv(b2, sep='\t', header=True, index=False)
+    ref1 = pd.read_csv(io.StringIO(str(g['tsv_unfiltered'])), sep='\t')
+    ref2 = pd.read_csv(io.StringIO(str(g['tsv_filtered'])), sep='\t')
+    got1 = pd.read_csv(io.StringIO(b1.getvalue()), sep='\t')
+    got2 = pd.read_csv(io.StringIO(b2.getvalue()), sep='\t')
+    for ref, got in ((ref1, got1), (ref2, got2)):
+        assert list(ref.columns) == list(got.columns)
+        for c in ('chr', 'pos1', 'pos2', 'chr2', 'pos3', 'pos4', 'length', 'width', 'maxpixel'):
+            assert ref[c].tolist() == got[c].tolist(), c       # filtered stripe calls identical
+        for c in ('Mean', 'pvalue', 'Stripiness'):
+            assert close(got[c], ref[c], float_exact), c
+    if float_exact:
+        assert b1.getvalue() == str(g['tsv_unfiltered']) and b2.getvalue() == str(g['tsv_filtered'])
+    mask = str(g['mask'])
+    if mask:
+        sm = obj.scoringstripes(rt, EV, mask)
+        assert close(sm[0], g['rr_g_masked'], float_exact)
+    return obj, out
+
+
+def run_score(make_backend, float_exact):
+    g, st, names, sizes, sel = load('seq')
+    resol = int(g['resol'])
+    ref = pd.read_csv(io.StringIO(str(g['tsv_unfiltered'])), sep='\t')
+    table = ref[['chr', 'pos1', 'pos2', 'chr2', 'pos3', 'pos4']].reset_index(drop=True)
+    obj2 = GS.getStripe(sel, resol, 10, 8, 2.5, names, names, sizes, sizes, 1, 1, int(g['prng_seed']),
+                        backend=make_backend(np.ascontiguousarray(st['gw_2p5'])))
+    EV2 = obj2.mpmean()
+    bg2 = obj2.nulldist()
+    pval = obj2.pvalue(*bg2, table)
+    MEAN, SUM = obj2.getMean(table)
+    s2, MOE, TOE = obj2.scoringstripes(table, EV2, '0')
+    assert close(pval, g['sc_pvalue'], float_exact)
+    assert close(MEAN, g['sc_mean'], False) and close(SUM, g['sc_sum'], False)
+    assert close(s2, g['sc_g'], float_exact)
+    assert close(MOE, g['sc_oe_mean'], False) and close(TOE, g['sc_oe_total'], False)
+
+
+def run_par_background(make_backend):
+    """numcores > 1: every chromosome restarts the PRNG from the seed (loky pickles self)."""
+    g, st, names, sizes, sel = load('par')
+    obj = GS.getStripe(sel, int(g['resol']), 10, 8, 2.0, names, names, sizes, sizes, int(g['core']), 3,
+                       int(g['prng_seed']), backend=make_backend(None))
+    bg = obj.nulldist()
+    for t, k in zip(bg, ('lu', 'ru', 'ld', 'rd')):
+        assert sha(t) == str(g['bg_%s_sha' % k]), 'background table %s differs (numcores>1 PRNG rule)' % k

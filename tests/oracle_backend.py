@@ -1,0 +1,114 @@
+"""Checker backend for the façade (TESTS ONLY): the same interface as stripenn_amd.backend.HipBackend,
+implemented with the CPU oracle.  Lets the CPU test-suite run the façade's host logic (frames, pools,
+PRNG order, region arithmetic, RemoveRedundant, table assembly) against the reference's goldens."""
+import numpy as np
+
+from oracle import oracle as O
+from stripenn_amd import hip
+
+
+class _Band:
+    def __init__(self, band):
+        self.a = np.ascontiguousarray(band, dtype=np.float64)
+        self.nrows, W = self.a.shape
+        self.hw = W // 2
+
+    def block(self, r0, r1, c0, c1):
+        rr = np.arange(r0, r1)[:, None]
+        cc = np.arange(c0, c1)[None, :]
+        d = cc - rr + self.hw
+        ok = (d >= 0) & (d < 2 * self.hw) & (rr >= 0) & (rr < self.nrows) & (cc >= 0) & (cc < self.nrows)
+        return np.where(ok, self.a[np.clip(rr, 0, self.nrows - 1), np.clip(d, 0, 2 * self.hw - 1)], 0.0)
+
+    def close(self):
+        pass
+
+
+class _Frames:
+    def __init__(self, band, starts, ends):
+        self.band = band
+        self.n = len(starts)
+        self.S = np.zeros(self.n, np.int32)
+        self.nz = np.zeros((self.n, 400), np.int16)
+        self.medpixel = np.zeros(self.n)
+        self.D = []
+        for f in range(self.n):
+            D, nz = O.frame_dense(band.block, int(starts[f]), int(ends[f]))
+            if len(nz) > 10:
+                self.S[f] = len(nz)
+                self.nz[f, :len(nz)] = nz
+                Dc = np.ascontiguousarray(D[np.ix_(nz, nz)])
+                self.medpixel[f] = O.medpixel(Dc)
+                self.D.append(Dc)
+            else:
+                self.D.append(None)
+
+    def close(self):
+        pass
+
+
+class OracleBackend:
+    name = 'oracle'
+
+    def __init__(self, gauss_w=None):
+        self.gauss_w = gauss_w
+        self.bg = None
+
+    def open_chrom(self, band_host):
+        return _Band(band_host)
+
+    def close_chrom(self, band):
+        pass
+
+    def frames(self, band, starts, ends):
+        return _Frames(band, starts, ends)
+
+    def stripe_search(self, frames, M_levels, sigma, minH, maxW, bfilter):
+        out = []
+        for f in range(frames.n):
+            if frames.D[f] is None:
+                continue
+            for li, M in enumerate(M_levels):
+                recs, tot = O.stripe_search(frames.D[f], float(M), sigma=sigma, minH=minH, maxW=maxW, bf=bfilter,
+                                            gw=self.gauss_w)
+                for k in range(len(recs)):
+                    b, ud, x, y, w, h = (int(v) for v in recs[k])
+                    out.append((f, li, b, ud, x, y, w, h, float(tot[k])))
+        return np.array(out, dtype=hip.REC_DTYPE)
+
+    def diag_sums(self, band):
+        return O.diag_sums(band.block, band.nrows)
+
+    def null_windows(self, band, samples, bs, unit_matrix=None):
+        n = len(samples)
+        if n == 0:
+            return [np.zeros((400, 0)) for _ in range(4)]
+        s0 = samples[0]
+        src = band.block if unit_matrix is None else (lambda r0, r1, c0, c1: unit_matrix)
+        return O.null_windows(src, int(s0['row0']), int(s0['nrow']), int(s0['col0']), int(s0['ncol']),
+                              samples['x'].astype(np.int64), int(s0['yoff']), bs)
+
+    def set_background(self, lu, ru, ld, rd):
+        self.bg = (np.asarray(lu), np.asarray(ru), np.asarray(ld), np.asarray(rd))
+
+    def pvalue(self, band, bs, stripes):
+        return np.array([O.pvalue_one(band.block(int(s['row0']), int(s['row1']), int(s['col0']), int(s['col1'])), bs,
+                                      int(s['mode']), int(s['upbase']), int(s['fixed_row']), int(s['fixed_tab']), self.bg)
+                         for s in stripes])
+
+    def stripiness(self, band, exval, stripes):
+        g, m, t = [], [], []
+        for s in stripes:
+            obs = [band.block(int(s['row0']), int(s['row1']), int(s['col0'][b]), int(s['col1'][b])) for b in range(3)]
+            r = O.stripiness_one(obs, exval, [int(v) for v in s['ex0']], int(s['ey0']), int(s['mirror']),
+                                 [(int(s['mcol0'][b]), int(s['mcol1'][b])) for b in range(3)],
+                                 (int(s['mrow0']), int(s['mrow1'])))
+            g.append(r[0]); m.append(r[1]); t.append(r[2])
+        return np.array(g), np.array(m), np.array(t)
+
+    def stripe_mean(self, band, rects):
+        r = [O.stripe_mean_one(band.block(int(q['row0']), int(q['row1']), int(q['col0']), int(q['col1']))) for q in rects]
+        return np.array([a for a, _ in r]), np.array([b for _, b in r])
+
+    def close(self):
+        pass

@@ -1,0 +1,101 @@
+"""CPU replay (tests/emu) of the HIP kernels' phase code vs the oracle: the kernel logic is checked
+bit for bit before anything runs on a GPU.  The emulator is test-only code."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class ER(C.Structure):
+    _fields_ = [('ud', C.c_int32), ('x', C.c_int32), ('y', C.c_int32), ('w', C.c_int32), ('h', C.c_int32),
+                ('total', C.c_double)]
+
+
+@pytest.fixture(scope='module')
+def emu():
+    subprocess.check_call(['make', '-s', '-C', os.path.join(HERE, 'emu')])
+    E = C.CDLL(os.path.join(HERE, 'emu', 'libstp_emu.so'))
+    E.emu_lines.restype = C.c_int
+    E.emu_compact.restype = C.c_int
+    return E
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _unpack(words, S):
+    b = np.unpackbits(words.view(np.uint8).reshape(400, 56), axis=1, bitorder='little')
+    return b[:S, :S]
+
+
+@pytest.mark.parametrize('ci', [0, 2, 4, 5])
+def test_emulated_kernels_match_oracle(emu, golden_stages, chr7, ci):
+    g = golden_stages
+    hw, W = 512, 1024
+    band = chr7.band(hw)
+    gw = np.ascontiguousarray(g['gw_2p0'])
+    bvals = np.ascontiguousarray(g['bvals'])
+    p = 'c%d_' % ci
+    start, end, S, M = int(g[p + 'start']), int(g[p + 'end']), int(g[p + 'S']), float(g[p + 'M'])
+    nz = np.zeros(400, np.int16)
+    assert emu.emu_compact(_p(band), W, hw, C.c_int64(start), end - start + 1, _p(nz)) == S
+    assert np.array_equal(nz[:S], g[p + 'nz'])
+    gray = np.zeros((6, 400, 400), np.float32)
+    emu.emu_gray(_p(band), W, hw, C.c_int64(start), _p(nz), S, C.c_double(M), _p(bvals), 6, 1, _p(gray))
+    D, nzo = O.frame_dense(chr7.block, start, end)
+    D = np.ascontiguousarray(D[np.ix_(nzo, nzo)])
+    gp = O.gplane(D, M)
+    nrec = 0
+    exp_recs, exp_tot = O.stripe_search(D, M, gw=gw)
+    got = []
+    for bi in range(6):
+        og = O.gray(gp, bvals[bi])
+        assert np.array_equal(og, gray[bi, :S, :S])
+        low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64)
+        emu.emu_canny(_p(gray[bi]), S, 8, _p(gw), _p(low), _p(high))
+        oe, dbg = O.canny(og, gw, 8, debug=True)
+        assert np.array_equal(_unpack(low, S).astype(np.uint8) + _unpack(high, S), dbg['cls'])
+        dbgw = np.zeros(4 * 2800, np.uint64); cols = np.zeros(1200, np.int16); recs = (ER * 128)(); sw = C.c_int(0)
+        n = emu.emu_lines(_p(low), _p(high), _p(band), W, hw, C.c_int64(start), _p(nz), S, 10, 8, _p(dbgw), _p(cols), recs,
+                          128, C.byref(sw))
+        assert np.array_equal(_unpack(dbgw[:2800], S), oe)
+        ov = O.vertical_line(oe)
+        assert np.array_equal(_unpack(dbgw[2800:5600], S), ov)
+        t_, e_, u_ = O.columns(ov, 10)
+        assert np.array_equal(cols[:S], t_) and np.array_equal(cols[400:400 + S], e_) and np.array_equal(cols[800:800 + S], u_)
+        tm1, _ = O.join_dbg(oe, ov, 1, 10, 8)
+        tm2, _ = O.join_dbg(oe, ov, 2, 10, 8)
+        assert np.array_equal(_unpack(dbgw[5600:8400], S), tm1) and np.array_equal(_unpack(dbgw[8400:], S), tm2)
+        got += [(bi, recs[k].ud, recs[k].x, recs[k].y, recs[k].w, recs[k].h, recs[k].total) for k in range(n)]
+    exp = [tuple(int(v) for v in exp_recs[k]) + (float(exp_tot[k]),) for k in range(len(exp_recs))]
+    assert got == exp
+
+
+def test_vertical_line_bitsliced_random(emu):
+    """The bit-sliced verticalLine / hysteresis phases on random masks vs the oracle's per-pixel code."""
+    rng = np.random.default_rng(5)
+    for S in (400, 129, 64, 37):
+        low = (rng.random((S, S)) < 0.25)
+        high = low & (rng.random((S, S)) < 0.2)
+        def pack(m):
+            full = np.zeros((400, 448), np.uint8); full[:S, :S] = m
+            return np.packbits(full, axis=1, bitorder='little').view(np.uint64).reshape(-1).copy()
+        lw, hg = pack(low), pack(high)
+        band = np.zeros((S + 8, 1024)); nz = np.arange(400, dtype=np.int16)
+        dbgw = np.zeros(4 * 2800, np.uint64); cols = np.zeros(1200, np.int16); recs = (ER * 128)(); sw = C.c_int(0)
+        emu.emu_lines(_p(lw), _p(hg), _p(band), 1024, 512, C.c_int64(0), _p(nz), S, 10, 8, _p(dbgw), _p(cols), recs, 128,
+                      C.byref(sw))
+        # oracle hysteresis: components of low containing a high pixel
+        from scipy import ndimage as ndi
+        lab, n = ndi.label(low, np.ones((3, 3)))
+        good = np.zeros(n + 1, bool); good[np.unique(lab[high])] = True; good[0] = False
+        edges = good[lab]
+        assert np.array_equal(_unpack(dbgw[:2800], S).astype(bool), edges)
+        assert np.array_equal(_unpack(dbgw[2800:5600], S), O.vertical_line(edges.astype(np.uint8)))

@@ -1,0 +1,44 @@
+"""Host logic of the façade (frames, pools, PRNG order, region arithmetic, RemoveRedundant, table
+assembly, TSV text) against the reference's end-to-end goldens, with the oracle as compute backend.
+The same checks run with the HIP backend in test_gpu_e2e.py."""
+import warnings
+
+import numpy as np
+
+import e2e_common as E
+from oracle_backend import OracleBackend
+
+warnings.filterwarnings('ignore')
+
+
+def _mk(gw):
+    return OracleBackend(gauss_w=gw)
+
+
+def test_compute_pipeline_matches_reference_exactly():
+    E.run_compute(_mk, float_exact=True)
+
+
+def test_score_pipeline_matches_reference_exactly():
+    E.run_score(_mk, float_exact=True)
+
+
+def test_background_with_numcores_gt1():
+    E.run_par_background(_mk)
+
+
+def test_remove_redundant_semantics():
+    import pandas as pd
+    from stripenn_amd import getStripe as GS
+    obj = GS.getStripe.__new__(GS.getStripe)
+    df = pd.DataFrame({'chr': ['a'] * 4, 'pos1': [1, 1, 500001, 1], 'pos2': [20000, 25000, 520000, 20000],
+                       'pos3': [1, 1, 500001, 1], 'pos4': [400000, 300000, 900000, 400000], 'h': [80, 60, 80, 80],
+                       'w': [4, 5, 4, 4], 'num': [0, 0, 2, 1], 'pvalue': [0.05, 0.01, 0.2, 0.05]})
+    out = obj.RemoveRedundant(df, 'size')
+    # rows 0/1 overlap: ratios 20 vs 12 -> row 1 dropped; rows 0/3 tie (<=) -> the first (row 0) dropped
+    assert out.index.tolist() == [2, 3]
+    out = obj.RemoveRedundant(df, 'pvalue')
+    assert out.index.tolist() == [1, 2]
+    import pytest
+    with pytest.raises(ValueError):
+        obj.RemoveRedundant(df, 'other')
