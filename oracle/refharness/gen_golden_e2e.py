@@ -22,6 +22,11 @@ E2E_PRNG_SEED = 123456789
 
 
 def sha(a):
+    """sha256 of the array bytes with every NaN replaced by the canonical quiet NaN (0/0 gives -NaN on
+    x86 and +NaN on the GPU; the payload/sign of a NaN is not part of the contract)."""
+    a = np.asarray(a)
+    if a.dtype.kind == 'f':
+        a = np.where(np.isnan(a), np.float64('nan').astype(a.dtype), a)
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 

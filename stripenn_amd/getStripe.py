@@ -194,83 +194,105 @@ class getStripe:
         """getStripe.py:238-499.  Sample-size arithmetic, pools and random.Random draws on the host in
         the reference's order; the 2.4 M window means in k_null_windows.  PRNG rule: numcores == 1
         keeps one stream across chromosomes (joblib runs in-process); numcores > 1 restarts from the
-        seed for every chromosome (loky pickles `self`), like the reference."""
+        seed for every chromosome (loky pickles `self`), like the reference.
+        The three phases below are also called one by one by the multi-GPU driver (shard.py)."""
         t0 = time.time()
-        resol = self.resol
+        chromnames2 = self.null_candidates()
+        n_available_col = [self.null_available_cols(c) for c in chromnames2]
+        chromnames2, samplesize = self.null_samplesizes(chromnames2, n_available_col)
+        parts = [self.null_tables(c, chromnames2, samplesize) for c in chromnames2]
+        out = self.null_concat(parts)
+        self.timing['nulldist_s'] = time.time() - t0
+        return out
+
+    def null_candidates(self):
+        """:242-247 chromosomes whose size share gives at least one of the 1000 samples"""
         with np.errstate(divide='ignore', invalid='ignore'):
             samplesize = (self.all_chromsizes / np.sum(self.all_chromsizes)) * 1000
             samplesize = np.uint64(samplesize)
             notzero = np.where(samplesize != 0)
-            chromnames2 = [self.all_chromnames[i] for i in notzero[0]]
+            return [self.all_chromnames[i] for i in notzero[0]]
 
-            n_available_col = []
-            for chrom in chromnames2:                                  # :249-276
-                chrom = str(chrom)
-                chrsize, itera, unitsize = self._unit_geometry(chrom)
-                poolsum = 0
-                for it in range(itera):
-                    a = int(unitsize * resol * it + 1)
-                    b = int(unitsize * resol * (it + 1))
-                    if a > b:
-                        a, b = b, a
-                    pos = '%s:%d-%d' % (chrom, a, b)
-                    mat = nantozero(np.array(self.unbalLib.fetch(pos, pos), dtype=np.float64))
-                    matsum = np.sum(mat, axis=1)
-                    poolsum += int(len(matsum) - np.count_nonzero(matsum == 0))
-                n_available_col.append(poolsum)
+    def null_available_cols(self, chrom):
+        """:249-273 number of non-empty rows over the chromosome's units"""
+        resol = self.resol
+        chrom = str(chrom)
+        chrsize, itera, unitsize = self._unit_geometry(chrom)
+        poolsum = 0
+        for it in range(itera):
+            a = int(unitsize * resol * it + 1)
+            b = int(unitsize * resol * (it + 1))
+            if a > b:
+                a, b = b, a
+            pos = '%s:%d-%d' % (chrom, a, b)
+            mat = nantozero(np.array(self.unbalLib.fetch(pos, pos), dtype=np.float64))
+            matsum = np.sum(mat, axis=1)
+            poolsum += int(len(matsum) - np.count_nonzero(matsum == 0))
+        return poolsum
 
-            samplesize = (n_available_col / np.sum(n_available_col)) * 1000     # :278-283
+    def null_samplesizes(self, chromnames2, n_available_col):
+        """:278-283 (the sample-size array keeps its unfiltered indexing, as in the reference)"""
+        with np.errstate(divide='ignore', invalid='ignore'):
+            samplesize = (n_available_col / np.sum(n_available_col)) * 1000
             samplesize = np.uint64(samplesize)
             dif = 1000 - int(np.sum(samplesize))
             notzero = np.where(samplesize != 0)
             chromnames2 = [chromnames2[i] for i in notzero[0]]
             samplesize[0] = np.uint64(int(samplesize[0]) + dif)
+        return chromnames2, samplesize
 
-            bs = int(50000 / resol)
-            tabs = [[], [], [], []]
-            for chrom in chromnames2:                                  # main_null_calc, :285-479
-                chrom = str(chrom)
-                prng = self.prng if self.core == 1 else random.Random(self.seed)
-                c = chromnames2.index(chrom)
-                ss = samplesize[c]                                     # (index into the unfiltered array, :295-298)
-                chrsize, itera, unitsize = self._unit_geometry(chrom)
-                band = self._band(chrom)
-                n_pool = []
-                collected = 0
-                sss = int(ss / itera)
-                last_it = -1
-                for it in range(itera):
-                    last_it = it
-                    p1, p2, r0, r1, c0, c1 = self._unit_regions(chrom, it, chrsize, unitsize)
-                    mat = nantozero(np.array(self.unbalLib.fetch(p1, p2), dtype=np.float64))
-                    nrow = mat.shape[0]
-                    matsum = np.sum(mat, axis=1)
-                    zero = set(np.where(matsum == 0)[0].tolist())
-                    pool = [x for x in range(nrow) if x not in zero]
-                    pool = [x for x in pool if x > 20 and x < (unitsize - 20)]
-                    if it == 0:
-                        pool = [x for x in pool if x > 410 and x < mat.shape[1]]
-                    n_pool.append(len(pool))
-                    if len(pool) == 0:
-                        continue
-                    k = len(pool) if len(pool) < sss else sss
-                    randval = prng.choices(pool, k=k)
-                    collected += self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if it > 0 else 0, bs, mat)
-                depl = int(ss) - collected                             # :416-477
-                if depl > 0:
-                    rich = int(np.argmax(n_pool))
-                    p1, p2, r0, r1, c0, c1 = self._unit_regions(chrom, rich, chrsize, unitsize)
-                    mat = nantozero(np.array(self.unbalLib.fetch(p1, p2), dtype=np.float64))
-                    nrow = mat.shape[0]
-                    matsum = np.sum(mat, axis=1)
-                    zero = set(np.where(matsum == 0)[0].tolist())
-                    pool = [x for x in range(nrow) if x not in zero]
-                    pool = [x for x in pool if x > 20 and x < (unitsize - 20)]
-                    randval = prng.choices(pool, k=depl)
-                    # the reference tests the loop variable `it` left over from the unit loop (:458)
-                    self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if last_it > 0 else 0, bs, mat)
-            out = [np.column_stack([np.zeros((400, 0))] + t) for t in tabs]
-        self.timing['nulldist_s'] = time.time() - t0
+    def null_tables(self, chrom, chromnames2, samplesize):
+        """main_null_calc (:285-479) for one chromosome -> four 400 x ss tables"""
+        resol = self.resol
+        bs = int(50000 / resol)
+        tabs = [[], [], [], []]
+        with np.errstate(divide='ignore', invalid='ignore'):
+            chrom = str(chrom)
+            prng = self.prng if self.core == 1 else random.Random(self.seed)
+            c = chromnames2.index(chrom)
+            ss = samplesize[c]                                     # (index into the unfiltered array, :295-298)
+            chrsize, itera, unitsize = self._unit_geometry(chrom)
+            band = self._band(chrom)
+            n_pool = []
+            collected = 0
+            sss = int(ss / itera)
+            last_it = -1
+            for it in range(itera):
+                last_it = it
+                p1, p2, r0, r1, c0, c1 = self._unit_regions(chrom, it, chrsize, unitsize)
+                mat = nantozero(np.array(self.unbalLib.fetch(p1, p2), dtype=np.float64))
+                nrow = mat.shape[0]
+                matsum = np.sum(mat, axis=1)
+                zero = set(np.where(matsum == 0)[0].tolist())
+                pool = [x for x in range(nrow) if x not in zero]
+                pool = [x for x in pool if x > 20 and x < (unitsize - 20)]
+                if it == 0:
+                    pool = [x for x in pool if x > 410 and x < mat.shape[1]]
+                n_pool.append(len(pool))
+                if len(pool) == 0:
+                    continue
+                k = len(pool) if len(pool) < sss else sss
+                randval = prng.choices(pool, k=k)
+                collected += self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if it > 0 else 0, bs, mat)
+            depl = int(ss) - collected                             # :416-477
+            if depl > 0:
+                rich = int(np.argmax(n_pool))
+                p1, p2, r0, r1, c0, c1 = self._unit_regions(chrom, rich, chrsize, unitsize)
+                mat = nantozero(np.array(self.unbalLib.fetch(p1, p2), dtype=np.float64))
+                nrow = mat.shape[0]
+                matsum = np.sum(mat, axis=1)
+                zero = set(np.where(matsum == 0)[0].tolist())
+                pool = [x for x in range(nrow) if x not in zero]
+                pool = [x for x in pool if x > 20 and x < (unitsize - 20)]
+                randval = prng.choices(pool, k=depl)
+                # the reference tests the loop variable `it` left over from the unit loop (:458)
+                self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if last_it > 0 else 0, bs, mat)
+        return [np.column_stack([np.zeros((400, 0))] + t) for t in tabs]
+
+    @staticmethod
+    def null_concat(parts):
+        """:483-496"""
+        out = [np.column_stack([np.zeros((400, 0))] + [p[k] for p in parts]) for k in range(4)]
         return out[0], out[1], out[2], out[3]
 
     def _null_batch(self, band, tabs, randval, r0, r1, c0, c1, yoff, bs, mat):

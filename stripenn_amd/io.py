@@ -1,0 +1,47 @@
+"""Opening the contact matrix: cooler when importable (host I/O stays cooler's, as in the reference),
+or a synthetic genome for tests / benchmarks ("synth:" URIs).
+
+    synth:chr1=7000000,chr2=4500000;resol=5000;seed=31
+"""
+import numpy as np
+import pandas as pd
+
+from . import synth
+
+
+class MatrixInfo:
+    """The few attributes of cooler.Cooler the reference's drivers read (stripenn.py:80-118)."""
+
+    def __init__(self, chromnames, chromsizes, binsize, norm_columns, selector_factory):
+        self.chromnames = list(chromnames)
+        self.chromsizes = pd.Series(np.asarray(chromsizes, dtype=np.int64), index=self.chromnames)
+        self.binsize = int(binsize)
+        self._info = {'bin-size': int(binsize)}
+        self._cols = norm_columns
+        self._sel = selector_factory
+
+    def bins(self):
+        return pd.DataFrame(columns=self._cols)
+
+    def matrix(self, balance=True):
+        return self._sel(balance)
+
+
+def open_matrix(cool):
+    if str(cool).startswith('synth:'):
+        spec = str(cool)[len('synth:'):]
+        parts = spec.split(';')
+        chroms = [kv.split('=') for kv in parts[0].split(',')]
+        opts = dict(kv.split('=') for kv in parts[1:] if kv)
+        resol = int(opts.get('resol', 5000))
+        seed = int(opts.get('seed', 1))
+        names = [c[0] for c in chroms]
+        sizes = [int(c[1]) for c in chroms]
+        _, _, sel = synth.make_genome(sizes, resol, seed0=seed, names=names)
+        return MatrixInfo(names, sizes, resol, ['chrom', 'start', 'end', 'weight', 'KR', 'VC', 'VC_SQRT'],
+                          lambda balance: sel)
+    try:
+        import cooler
+    except ImportError as e:
+        raise ImportError('cooler is required to open %r (only "synth:" inputs work without it)' % cool) from e
+    return cooler.Cooler(cool)

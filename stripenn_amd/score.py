@@ -1,0 +1,47 @@
+"""`stripenn score` driver: the reference's score.getScore (src/stripenn/score.py:7-61) on the
+MI355X stripe engine -- same table sniffing, chromosome filter, fixed parameters (minH 10, maxW 8,
+canny 2.5, bfilter 1), call order and the six appended columns."""
+import numpy as np
+import pandas as pd
+
+from . import getStripe
+from .io import open_matrix
+from .stripenn import resolve_norm
+
+
+def getScore(cool, coordinates, norm, numcores, seed, out, mask='0', device=0, backend=None):
+    bfilter = 1
+    print('Run score function')
+    table = pd.read_csv(coordinates, header=None, sep='\t')
+    el = table.iloc[0]
+    if type(el[1]) == str or type(el[2]) == str:          # score.py:13-20: a header line is present
+        table = pd.read_csv(coordinates, header=0, sep='\t')
+    table.columns = ['chr', 'pos1', 'pos2', 'chr2', 'pos3', 'pos4'] + table.columns[6:].tolist()
+
+    Lib = open_matrix(cool)
+    norm = resolve_norm(Lib, norm, weight_is_true=False)    # score.py:27-35 has no 'weight' -> True mapping
+    names = list(Lib.chromnames)
+    sizes = np.asarray(Lib.chromsizes)
+    keep = [i for i in range(len(names)) if names[i] != 'Y' and 'JH' not in names[i] and 'RANDOM' not in names[i]]
+    all_chromnames = [names[i] for i in keep]
+    all_chromsizes = np.array([sizes[i] for i in keep])
+    big = np.where(all_chromsizes > 1000000)[0]
+    all_chromnames = [all_chromnames[i] for i in big]
+    all_chromsizes = all_chromsizes[big]
+    unbalLib = Lib.matrix(balance=norm)
+    resol = Lib._info['bin-size']
+    obj = getStripe.getStripe(unbalLib, resol, 10, 8, 2.5, all_chromnames, all_chromnames, all_chromsizes,
+                              all_chromsizes, numcores, bfilter, seed, backend=backend, device=device)
+    EV = obj.mpmean()
+    bg = obj.nulldist()
+    pval = obj.pvalue(*bg, table)
+    table.insert(table.shape[1], 'pvalue_added', pval, True)
+    MEAN, SUM = obj.getMean(table)
+    s, MEANOE, TOTALOE = obj.scoringstripes(table, EV, mask)
+    table.insert(table.shape[1], 'Stripiness_added', s, True)
+    table.insert(table.shape[1], 'O_Mean_added', MEAN, True)
+    table.insert(table.shape[1], 'O_Sum_added', SUM, True)
+    table.insert(table.shape[1], 'O/E_Mean_added', MEANOE, True)
+    table.insert(table.shape[1], 'O/E_Total_added', TOTALOE, True)
+    table.to_csv(out, sep='\t', header=True, index=False)
+    return table

@@ -1,0 +1,173 @@
+"""`stripenn compute` driver: same arguments, log file, chromosome filter, step order and TSV outputs
+as the reference's stripenn.compute (src/stripenn/stripenn.py:64-163); the five steps run through
+the MI355X stripe engine (stripenn_amd/getStripe.py).  Extra keywords (not in the reference):
+`force` (non-interactive overwrite of the output directory), `device`, and `gpus` > 1 to shard the
+chromosome x maxpixel grid over several GPUs (stripenn_amd/shard.py)."""
+import errno
+import os
+import shutil
+import sys
+import time
+import warnings
+
+import numpy as np
+import pandas as pd
+
+from . import getStripe
+from .io import open_matrix
+
+RESULT_COLUMNS = ['chr', 'pos1', 'pos2', 'chr2', 'pos3', 'pos4', 'length', 'width', 'total', 'Mean', 'maxpixel', 'num',
+                  'start', 'end', 'x', 'y', 'h', 'w', 'medpixel', 'pvalue']
+HELPER_COLUMNS = ['total', 'num', 'start', 'end', 'x', 'y', 'h', 'w', 'medpixel']
+
+
+def makeOutDir(outdir, force=False):
+    """stripenn.py:12-42 (the interactive prompt is kept; force=True answers Y)."""
+    if outdir[-1] != '/':
+        outdir += '/'
+    if os.path.exists(outdir):
+        if force:
+            userinput = 'Y'
+        else:
+            print('\n%s exists. Do you want to remove all files and save new results in this folder? [Y/n]' % outdir)
+            userinput = input()
+        if userinput in ('Y', 'y'):
+            print('All directories and files in %s will be deleted.' % outdir)
+            for filename in os.listdir(outdir):
+                file_path = os.path.join(outdir, filename)
+                try:
+                    if os.path.isfile(file_path) or os.path.islink(file_path):
+                        os.unlink(file_path)
+                    elif os.path.isdir(file_path):
+                        shutil.rmtree(file_path)
+                except Exception as e:
+                    print('Failed to delete %s with the reason: %s' % (file_path, e))
+        elif userinput in ('n', 'N'):
+            print('Input another output directory. Exit.')
+            sys.exit()
+        else:
+            print('Type Y or n.\nExit.')
+            sys.exit()
+    else:
+        try:
+            os.makedirs(outdir)
+        except OSError as e:
+            if e.errno != errno.EEXIST:
+                raise
+
+
+def addlog(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, bfilter):
+    """stripenn.py:45-61 (same keys, same order)."""
+    if out[-1] != '/':
+        out += '/'
+    with open(out + 'stripenn.log', 'w') as f:
+        for k, v in (('cool', cool), ('out', out), ('norm', norm), ('chrom', chrom), ('canny', canny), ('minL', minL),
+                     ('maxW', maxW), ('maxpixel', maxpixel), ('num_cores', numcores), ('pvalue', pvalue), ('mask', mask),
+                     ('blur filter', bfilter)):
+            f.write('%s: %s\n' % (k, str(v)))
+
+
+def select_chromosomes(Lib, chrom):
+    """stripenn.py:94-116"""
+    all_chromnames = list(Lib.chromnames)
+    all_chromsizes = np.asarray(Lib.chromsizes)
+    keep = [i for i in range(len(all_chromnames))
+            if 'JH5' not in all_chromnames[i] and 'GL4' not in all_chromnames[i] and 'RANDOM' not in all_chromnames[i]
+            and all_chromnames[i] not in ('M', 'chrM', 'Y', 'chrY')]
+    all_chromnames = [all_chromnames[i] for i in keep]
+    all_chromsizes = all_chromsizes[keep]
+    chromnames, chromsizes = all_chromnames, all_chromsizes
+    if len(all_chromnames) == 0:
+        sys.exit('Exit: All chromosomes are shorter than 50kb.')
+    chroms = chrom.split(',')
+    if chroms[0] != 'all':
+        idx = []
+        warnflag = False
+        for item in chroms:
+            if item in all_chromnames:
+                idx.append(all_chromnames.index(item))
+            else:
+                warnings.warn('\nThere is no chromosomes called ' + str(item) +
+                              ' in the provided .cool file or it is shorter than 50kb.')
+                warnflag = True
+        if warnflag:
+            warnings.warn('\nThe possible chromosomes are: ' + ', '.join(all_chromnames))
+        chromnames = chroms
+        chromsizes = all_chromsizes[idx]
+    return all_chromnames, all_chromsizes, chromnames, chromsizes
+
+
+def resolve_norm(Lib, norm, weight_is_true=True):
+    """stripenn.py:81-92"""
+    PossibleNorm = Lib.bins().columns
+    if norm == 'None':
+        return False
+    if weight_is_true and norm == 'weight':
+        return True
+    if norm not in PossibleNorm:
+        print('Possible normalization methods are:')
+        print('None')
+        for n in range(3, len(PossibleNorm)):
+            print(PossibleNorm[n])
+        print('Invalid normalization method. Normalization method is forced to None')
+        return False
+    return norm
+
+
+def finish_tables(result_table, stripiness, pcut):
+    """stripenn.py:149-152"""
+    result_table = result_table.drop(columns=HELPER_COLUMNS)
+    result_table.insert(result_table.shape[1], 'Stripiness', stripiness, True)
+    res_filter = result_table[result_table['pvalue'] < pcut]
+    res_filter = res_filter.sort_values(by=['Stripiness'], ascending=False)
+    return result_table, res_filter
+
+
+def compute(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, slow, bfilter, seed,
+            force=False, device=0, gpus=1, backend=None):
+    np.seterr(divide='ignore', invalid='ignore')
+    t_start = time.time()
+    if out[-1] != '/':
+        out += '/'
+    if gpus > 1:
+        from . import shard
+        return shard.launch_compute(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, slow,
+                                    bfilter, seed, force, gpus)
+    makeOutDir(out, force)
+    addlog(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, bfilter)
+    maxpixel = list(map(float, maxpixel.split(',')))
+    minH, core, pcut = minL, numcores, pvalue
+    print('Result will be stored in %s' % out)
+
+    Lib = open_matrix(cool)
+    norm = resolve_norm(Lib, norm)
+    all_chromnames, all_chromsizes, chromnames, chromsizes = select_chromosomes(Lib, chrom)
+    unbalLib = Lib.matrix(balance=norm)
+    resol = Lib.binsize
+    obj = getStripe.getStripe(unbalLib, resol, minH, maxW, canny, all_chromnames, chromnames, all_chromsizes, chromsizes,
+                              core, bfilter, seed, backend=backend, device=device)
+    print('1. Maximum pixel value calculation ...')
+    if slow:
+        print('1.1 Slowly estimating Maximum pixel values...')
+        MP = obj.getQuantile_slow(Lib, chromnames, maxpixel)
+    else:
+        MP = obj.getQuantile_original(Lib, chromnames, maxpixel)
+    print('2. Expected value calculation ...')
+    EV = obj.mpmean()
+    print('3. Background distribution estimation ...')
+    bgleft_up, bgright_up, bgleft_down, bgright_down = obj.nulldist()
+    print('4. Finding candidate stripes from each chromosome ...')
+    result_table = pd.DataFrame(columns=RESULT_COLUMNS)
+    for i in range(len(maxpixel)):
+        perc = maxpixel[i]
+        result = obj.extract(MP, i, perc, bgleft_up, bgright_up, bgleft_down, bgright_down)
+        result_table = pd.concat([result_table, result])
+    result_table = obj.RemoveRedundant(df=result_table, by='pvalue')
+    print('5. Stripiness calculation ...')
+    s = obj.scoringstripes(result_table, EV, mask)[0]
+    result_table, res_filter = finish_tables(result_table, s, pcut)
+    result_table.to_csv(out + 'result_unfiltered.tsv', sep='\t', header=True, index=False)
+    res_filter.to_csv(out + 'result_filtered.tsv', sep='\t', header=True, index=False)
+    print('\n' + str(round((time.time() - t_start) / 60, 3)) + 'min taken.')
+    print('Check the result stored in %s' % out)
+    return 0
