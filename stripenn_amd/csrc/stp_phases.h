@@ -34,6 +34,8 @@ typedef unsigned long long stp_u64;
 #define CT_Y 32
 #define CT_X 64
 #define CT_RMAX 12
+#define CT_SP (CT_X + 5) /* pitch (doubles) of the smoothed tile: odd -> few LDS write conflicts */
+#define CT_VP (CT_Y + 5) /* pitch (floats) of the transposed vertical-pass tile */
 
 struct stp_tile {
     int S;        // compacted frame size
@@ -221,7 +223,72 @@ STP_HD void canny_p2(int tid, int nt, stp_tile T, int R, const double* w, const 
             double bl = (x >= R && x + R < T.S) ? sB[VH + yy] : stp_bleed_h(sB[yy], x, T.S, R, w);
             s = (double)f / (bl + DBL_EPSILON);       // _canny.py:49
         }
-        sS[i] = s;
+        sS[yy * CT_SP + xx] = s;
+    }
+}
+
+// ---- register-blocked Gaussian passes (compile-time radius): each thread produces a run of
+// consecutive outputs along the filter direction from a sliding window held in registers, so an
+// input is loaded and widened to f64 once instead of 2R+1 times.  Same operation order per output.
+// The vertical pass writes its result TRANSPOSED (sVT[x][y], pitch CT_VP) so that both passes read
+// LDS with consecutive lanes on consecutive words.
+#define CT_VRUN 12   /* vertical outputs per thread: (CT_Y + 4) = 3 * 12 */
+#define CT_HRUN 5    /* horizontal outputs per thread: ceil(68 / 5) = 14 runs x 36 rows = 504 items */
+template <int R>
+STP_HD void canny_p1_blk(int tid, int nt, stp_tile T, const double* w, const float* sG, float* sVT)
+{
+    const int GW = CT_X + 2 * R + 4;
+    const int NG = (CT_Y + 4) / CT_VRUN;
+    for (int i = tid; i < GW * NG; i += nt) {
+        const int xx = i % GW, yg = i / GW;
+        const int yy0 = yg * CT_VRUN;
+        const int x = T.tx0 - R - 2 + xx;
+        double win[CT_VRUN + 2 * R];
+#pragma unroll
+        for (int k = 0; k < CT_VRUN + 2 * R; k++) win[k] = (double)sG[(yy0 + k) * GW + xx];
+#pragma unroll
+        for (int q = 0; q < CT_VRUN; q++) {
+            const int y = T.ty0 - 2 + yy0 + q;
+            double o = win[q + R] * w[R];
+#pragma unroll
+            for (int k = R; k >= 1; k--) o += (win[q + R - k] + win[q + R + k]) * w[R - k];
+            float out = (y >= 0 && y < T.S && x >= 0 && x < T.S) ? (float)o : 0.0f;
+            sVT[xx * CT_VP + yy0 + q] = out;
+        }
+    }
+}
+
+template <int R>
+STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const float* sVT, const double* sB, double* sS)
+{
+    const int VH = CT_Y + 4, SW = CT_X + 4;
+    const int NG = (SW + CT_HRUN - 1) / CT_HRUN;
+    for (int i = tid; i < VH * NG; i += nt) {
+        const int yy = i % VH, xg = i / VH;
+        const int xx0 = xg * CT_HRUN;
+        const int y = T.ty0 - 2 + yy;
+        double win[CT_HRUN + 2 * R];
+#pragma unroll
+        for (int k = 0; k < CT_HRUN + 2 * R; k++) {
+            const int col = xx0 + k;                      // sVT column index = image x - (tx0 - R - 2)
+            win[k] = (col < CT_X + 2 * R + 4) ? (double)sVT[col * CT_VP + yy] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < CT_HRUN; q++) {
+            const int xx = xx0 + q;
+            if (xx >= SW) break;
+            const int x = T.tx0 - 2 + xx;
+            double s = 0.0;
+            if (y >= 0 && y < T.S && x >= 0 && x < T.S) {
+                double o = win[q + R] * w[R];
+#pragma unroll
+                for (int k = R; k >= 1; k--) o += (win[q + R - k] + win[q + R + k]) * w[R - k];
+                float f = (float)o;
+                double bl = (x >= R && x + R < T.S) ? sB[VH + yy] : stp_bleed_h(sB[yy], x, T.S, R, w);
+                s = (double)f / (bl + DBL_EPSILON);
+            }
+            sS[yy * CT_SP + xx] = s;
+        }
     }
 }
 
@@ -270,7 +337,7 @@ STP_HD double stp_hypot(double x, double y)
 STP_HD double ct_s(const double* sS, stp_tile T, int y, int x)
 {
     int ry = stp_refl(y, T.S), rx = stp_refl(x, T.S);
-    return sS[(ry - (T.ty0 - 2)) * (CT_X + 4) + (rx - (T.tx0 - 2))];
+    return sS[(ry - (T.ty0 - 2)) * CT_SP + (rx - (T.tx0 - 2))];
 }
 
 // ndi.sobel: antisymmetric pass o = x[0]*0 + (x[-1]-x[1])*(-1) (== x[1]-x[-1]); symmetric pass
@@ -313,7 +380,7 @@ STP_HD int ct_nms(const double* sS, const double* sM, stp_tile T, int y, int x)
     const int MW = CT_X + 2;
     const double* mp = sM + (y - (T.ty0 - 1)) * MW + (x - (T.tx0 - 1));
     double m = mp[0];
-    if (!(m > 0.0)) return 0;
+    if (!(m >= 0.1)) return 0;      // below the low threshold the class is 0 whatever the local-max test says
     double gi, gj;
     ct_sobel(sS, T, y, x, &gi, &gj);
     double ai = fabs(gi), aj = fabs(gj);

@@ -185,50 +185,90 @@ __device__ double block_median(const double* vals, int n, double* s_res)
     return (k0 == k1) ? s_res[0] : (s_res[0] + s_res[1]) / 2.0;
 }
 
-__global__ __launch_bounds__(256) void k_pvalue(stp_bandref B, const double* __restrict__ bg /* lu,ru,ld,rd: 4 x 400 x ncol */,
-                                                 int ncolbg, int bs, const stp_pv_stripe* __restrict__ st, double* __restrict__ out)
+// Background rows sorted once per upload (ascending, NaN last): the rank "#(b >= x)" of :599-600
+// becomes nvalid - lower_bound(x).  One workgroup per table row, bitonic sort of <= 2048 values in LDS.
+#define STP_BG_MAXCOL 2048
+__global__ __launch_bounds__(512) void k_bg_sort(const double* __restrict__ bg, int ncol, double* __restrict__ sorted,
+                                                  int* __restrict__ nvalid)
+{
+    __shared__ double v[STP_BG_MAXCOL];
+    __shared__ int s_nv;
+    const size_t row = blockIdx.x;
+    if (threadIdx.x == 0) s_nv = 0;
+    __syncthreads();
+    int loc = 0;
+    for (int i = threadIdx.x; i < STP_BG_MAXCOL; i += blockDim.x) {
+        double x = (i < ncol) ? bg[row * ncol + i] : NAN;
+        if (x == x) loc++;
+        v[i] = (x == x) ? x : INFINITY;      // NaN and padding sort to the end (+inf sentinels; counted out by nvalid)
+    }
+    atomicAdd(&s_nv, loc);
+    __syncthreads();
+    for (int k = 2; k <= STP_BG_MAXCOL; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < STP_BG_MAXCOL; i += blockDim.x) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    double a = v[i], b = v[ixj];
+                    bool up = ((i & k) == 0);
+                    if ((a > b) == up) { v[i] = b; v[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < ncol; i += blockDim.x) sorted[row * ncol + i] = v[i];
+    if (threadIdx.x == 0) nvalid[row] = s_nv;
+}
+
+// number of valid background values >= x  (0 when x is NaN, like numpy's comparison)
+__device__ __forceinline__ int bg_count_ge(const double* __restrict__ srt, int nv, double x)
+{
+    if (x != x) return 0;
+    int lo = 0, hi = nv;                      // first index with srt[idx] >= x
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (srt[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return nv - lo;
+}
+
+__global__ __launch_bounds__(256) void k_pvalue(stp_bandref B, const double* __restrict__ srt /* sorted lu,ru,ld,rd */,
+                                                 const int* __restrict__ nvalid, int ncolbg, int bs,
+                                                 const stp_pv_stripe* __restrict__ st, double* __restrict__ out)
 {
     __shared__ double pv[STP_SCORE_MAXROWS];
+    __shared__ double part[3][STP_SCORE_MAXROWS];
     __shared__ double s_res[2];
     const stp_pv_stripe s = st[blockIdx.x];
     const int h = s.row1 - s.row0;
     const int ncol = s.col1 - s.col0;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const size_t TS = (size_t)STP_NDIAG * ncolbg;
-    int64_t cl, ch, ll, lh, rl, rh;
-    stp_pyslice(bs, -bs, ncol, &cl, &ch);        // mat[:, bs:-bs]
-    stp_pyslice(0, bs, ncol, &ll, &lh);          // mat[:, :bs]
-    stp_pyslice(-bs, ncol, ncol, &rl, &rh);      // mat[:, -bs:]
-    for (int j = wv; j < h; j += nw) {
+    int64_t lo[3], hi[3];
+    stp_pyslice(bs, -bs, ncol, &lo[0], &hi[0]);        // mat[:, bs:-bs]
+    stp_pyslice(0, bs, ncol, &lo[1], &hi[1]);          // mat[:, :bs]
+    stp_pyslice(-bs, ncol, ncol, &lo[2], &hi[2]);      // mat[:, -bs:]
+    // row means of the three column blocks: np.mean(axis=1) = per-row pairwise sum / n
+    for (int it = threadIdx.x; it < 3 * h; it += blockDim.x) {
+        const int p = it / h, j = it - p * h;
         const int64_t gr = s.row0 + j;
-        double ldv = 0.0, rdv = 0.0;
-        if (lane == 0) {
-            auto get = [&](int64_t k) { return band_at0(B, gr, s.col0 + k); };
-            double c = stp_pw(get, cl, ch - cl) / (double)(ch - cl);
-            double l = stp_pw(get, ll, lh - ll) / (double)(lh - ll);
-            double r = stp_pw(get, rl, rh - rl) / (double)(rh - rl);
-            ldv = c - l; rdv = c - r;
-        }
-        ldv = __shfl(ldv, 0); rdv = __shfl(rdv, 0);
+        const int64_t n = hi[p] - lo[p];
+        part[p][j] = stp_pw([&](int64_t k) { return band_at0(B, gr, s.col0 + k); }, lo[p], n) / (double)n;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < h; j += blockDim.x) {
+        const double ldv = part[0][j] - part[1][j], rdv = part[0][j] - part[2][j];
         int d, tab;
         if (s.mode == 0) { d = j; tab = 1; }
         else if (s.mode == 1) { d = s.upbase - j - 1; tab = 0; }
         else { d = s.fixed_row; tab = s.fixed_tab; }
         if (s.mode != 2 && d >= 400) d = 399;
         if (d < 0) d += STP_NDIAG;               // python negative index on the table (never for real stripes)
-        const double* bl = bg + (size_t)(tab ? 2 : 0) * TS + (size_t)d * ncolbg;
-        const double* br = bg + (size_t)(tab ? 3 : 1) * TS + (size_t)d * ncolbg;
-        int cL = 0, vL = 0, cR = 0, vR = 0;
-        for (int k = lane; k < ncolbg; k += 64) {
-            double a = bl[k], b = br[k];
-            cL += a >= ldv; vL += (a == a);
-            cR += b >= rdv; vR += (b == b);
-        }
-        double p1 = wave_sum_i(cL) / wave_sum_i(vL);
-        double p2 = wave_sum_i(cR) / wave_sum_i(vR);
+        const size_t rl = (size_t)(tab ? 2 : 0) * STP_NDIAG + d, rr = (size_t)(tab ? 3 : 1) * STP_NDIAG + d;
+        const int vL = nvalid[rl], vR = nvalid[rr];
+        const double p1 = (double)bg_count_ge(srt + rl * ncolbg, vL, ldv) / (double)vL;
+        const double p2 = (double)bg_count_ge(srt + rr * ncolbg, vR, rdv) / (double)vR;
         double p = (p2 > p1) ? p2 : p1;          // python max(p1, p2)
         if (p == 0.0) p = 1.0 / (double)ncolbg;
-        if (lane == 0) pv[j] = p;
+        pv[j] = p;
     }
     __syncthreads();
     double med = block_median(pv, h, s_res);

@@ -80,11 +80,14 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
 }
 
 // K-B: Canny up to the classified local maxima, one tile of one image per workgroup.
+// RT > 0: compile-time Gaussian radius with register-blocked passes; RT == 0: generic radius.
+template <int RT>
 __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
-                                                int imgs_per_frame, int R, const double* __restrict__ gw,
+                                                int imgs_per_frame, int Rrun, const double* __restrict__ gw,
                                                 stp_u64* __restrict__ low, stp_u64* __restrict__ high)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int R = RT > 0 ? RT : Rrun;
     const int img = blockIdx.y;
     const int f = f0 + img / imgs_per_frame;
     const int S = fS[f];
@@ -97,20 +100,26 @@ __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, c
     // layout: [sW | sB | sS | sG | sV]; sM and sC alias sG/sV once those are dead
     double* sW = (double*)smem;                                   // 2*CT_RMAX+1 -> 32 slots
     double* sB = sW + 32;                                         // 2*VH
-    double* sS = sB + 2 * VH;                                     // VH*(CT_X+4)
-    float* sG = (float*)(sS + VH * (CT_X + 4));                   // GH*GW
-    float* sV = sG + GH * GW;                                     // VH*GW
-    double* sM = (double*)sG;                                     // (CT_Y+2)*(CT_X+2) f64 <= (GH+VH)*GW f32
+    double* sS = sB + 2 * VH;                                     // VH*CT_SP
+    float* sG = (float*)(sS + VH * CT_SP);                        // GH*GW
+    float* sV = sG + GH * GW;                                     // max(VH*GW, GW*CT_VP)
+    double* sM = (double*)sG;                                     // (CT_Y+2)*(CT_X+2) f64, aliases sG/sV
     uint8_t* sC = (uint8_t*)(sM + (CT_Y + 2) * (CT_X + 2));
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid < 2 * R + 1) sW[tid] = gw[tid];
     const float* gimg = gray + (size_t)img * (STP_PITCH * STP_PITCH);
     canny_p0(tid, nt, gimg, T, R, sG);
+    canny_p1b(tid, nt, T, R, gw, sB);
     __syncthreads();
-    canny_p1(tid, nt, T, R, sW, sG, sV);
-    canny_p1b(tid, nt, T, R, sW, sB);
-    __syncthreads();
-    canny_p2(tid, nt, T, R, sW, sV, sB, sS);
+    if constexpr (RT > 0) {
+        canny_p1_blk<RT>(tid, nt, T, sW, sG, sV);
+        __syncthreads();
+        canny_p2_blk<RT>(tid, nt, T, sW, sV, sB, sS);
+    } else {
+        canny_p1(tid, nt, T, R, sW, sG, sV);
+        __syncthreads();
+        canny_p2(tid, nt, T, R, sW, sV, sB, sS);
+    }
     __syncthreads();
     canny_p3(tid, nt, T, sS, sM);
     __syncthreads();
@@ -122,8 +131,9 @@ __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, c
 static size_t canny_smem_bytes(int R)
 {
     const int GW = CT_X + 2 * R + 4, GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
-    size_t fixed = (32 + 2 * VH + VH * (CT_X + 4)) * sizeof(double);
-    size_t gv = (size_t)(GH + VH) * GW * sizeof(float);
+    size_t fixed = (32 + 2 * VH + VH * CT_SP) * sizeof(double);
+    size_t vsz = (size_t)VH * GW > (size_t)GW * CT_VP ? (size_t)VH * GW : (size_t)GW * CT_VP;
+    size_t gv = ((size_t)GH * GW + vsz) * sizeof(float);
     size_t mc = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(double) + CT_Y * CT_X;
     return fixed + (gv > mc ? gv : mc);
 }
@@ -221,6 +231,51 @@ __global__ __launch_bounds__(512) void k_lines(const stp_u64* __restrict__ low, 
     if (tid == 0) rec_count[img] = nrec;
 }
 
+// Record compaction: per-image slots -> one dense array in the reference's row order (image index
+// = (frame, level, brightness) order; slot order inside an image).  One workgroup, 1024 lanes.
+__global__ __launch_bounds__(1024) void k_compact_recs(const stp_drec* __restrict__ recs, const int32_t* __restrict__ cnt,
+                                                        int nimg, int f0, int nlev, int nb, stp_stripe_rec* __restrict__ out,
+                                                        long long cap, long long* __restrict__ total_overflow)
+{
+    __shared__ int s_part[1024];
+    __shared__ int s_over;
+    const int tid = threadIdx.x;
+    const int per = (nimg + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(nimg, i0 + per);
+    if (tid == 0) s_over = 0;
+    __syncthreads();
+    int loc = 0;
+    for (int i = i0; i < i1; i++) {
+        int c = cnt[i];
+        if (c > STP_RCAP) { c = STP_RCAP; s_over = 1; }
+        loc += c;
+    }
+    s_part[tid] = loc;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {           // inclusive scan
+        int v = (tid >= o) ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    long long pos = s_part[tid] - loc;
+    const int ipf = nlev * nb;
+    for (int i = i0; i < i1; i++) {
+        int c = cnt[i];
+        if (c > STP_RCAP) c = STP_RCAP;
+        const int fl = i / ipf, lev = (i % ipf) / nb, bi = i % nb;
+        for (int k = 0; k < c; k++, pos++) {
+            if (pos >= cap) continue;
+            const stp_drec d = recs[(size_t)i * STP_RCAP + k];
+            stp_stripe_rec r;
+            r.frame = f0 + fl; r.level = lev; r.b_index = bi; r.ud = d.ud;
+            r.x = d.x; r.y = d.y; r.w = d.w; r.h = d.h; r.total = d.total;
+            out[pos] = r;
+        }
+    }
+    if (tid == 1023) { total_overflow[0] = s_part[1023]; total_overflow[1] = s_over; }
+}
+
 // ============================================================================================
 // host side
 // ============================================================================================
@@ -237,9 +292,15 @@ struct stp_pending {
     double bytes;
 };
 
+enum { WS_GRAY = 0, WS_LOW, WS_HIGH, WS_RECS, WS_CNT, WS_OUT, WS_TOTAL, WS_PARAMS, WS_NSLOTS };
+
 struct stp_ctx {
     int device = 0;
     std::vector<stp_pending> pending;
+    void* ws[WS_NSLOTS] = {nullptr};       // grow-only device workspace, reused across calls
+    size_t ws_bytes[WS_NSLOTS] = {0};
+    void* pin = nullptr;                   // pinned host staging buffer (records)
+    size_t pin_bytes = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
@@ -264,6 +325,32 @@ struct stp_frames {
     std::vector<int16_t> h_nz;
     std::vector<double> h_med;
 };
+
+static hipError_t ws_get(stp_ctx* ctx, int slot, size_t bytes, void** out)
+{
+    if (ctx->ws_bytes[slot] < bytes) {
+        if (ctx->ws[slot]) (void)hipFree(ctx->ws[slot]);
+        ctx->ws[slot] = nullptr; ctx->ws_bytes[slot] = 0;
+        hipError_t e = hipMalloc(&ctx->ws[slot], bytes);
+        if (e != hipSuccess) return e;
+        ctx->ws_bytes[slot] = bytes;
+    }
+    *out = ctx->ws[slot];
+    return hipSuccess;
+}
+
+static hipError_t pin_get(stp_ctx* ctx, size_t bytes, void** out)
+{
+    if (ctx->pin_bytes < bytes) {
+        if (ctx->pin) (void)hipHostFree(ctx->pin);
+        ctx->pin = nullptr; ctx->pin_bytes = 0;
+        hipError_t e = hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        ctx->pin_bytes = bytes;
+    }
+    *out = ctx->pin;
+    return hipSuccess;
+}
 
 static int set_err(stp_ctx* c, int code, const std::string& m)
 {
@@ -366,6 +453,8 @@ void stp_ctx_destroy(stp_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     resolve_pending(ctx);
+    for (int i = 0; i < WS_NSLOTS; i++) if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -573,8 +662,16 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     {
         prof_scope ps(ctx, "canny", ipx * 5.0);          // stage B: 4 B read + 1 B written
         const int tiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
-        hipLaunchKernelGGL(k_canny, dim3(tiles, (unsigned)nimg), dim3(256), canny_smem_bytes(R), ctx->stream, d_gray,
-                           fr->d_S, f0, ipf, R, d_w, d_low, d_high);
+        const dim3 cg(tiles, (unsigned)nimg);
+        if (R == 8)
+            hipLaunchKernelGGL(k_canny<8>, cg, dim3(256), canny_smem_bytes(R), ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
+                               d_low, d_high);
+        else if (R == 10)
+            hipLaunchKernelGGL(k_canny<10>, cg, dim3(256), canny_smem_bytes(R), ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
+                               d_low, d_high);
+        else
+            hipLaunchKernelGGL(k_canny<0>, cg, dim3(256), canny_smem_bytes(R), ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
+                               d_low, d_high);
     }
     HIPCHK(hipGetLastError());
     {
@@ -599,45 +696,52 @@ int stp_stripe_search(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
     if (chunk < 1) chunk = 1;
     if (chunk > fr->n) chunk = fr->n;
     const size_t cimg = (size_t)chunk * ipf;
-    dev_buf bM, bB, bW, bGray, bLow, bHigh, bRecs, bCnt;
-    HIPCHK(bM.alloc(n_levels * sizeof(double)));
-    HIPCHK(bB.alloc(nb * sizeof(double)));
-    HIPCHK(bW.alloc((2 * prm->gauss_radius + 1) * sizeof(double)));
-    HIPCHK(bGray.alloc(cimg * STP_PITCH * STP_PITCH * sizeof(float)));
-    HIPCHK(bLow.alloc(cimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
-    HIPCHK(bHigh.alloc(cimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
-    HIPCHK(bRecs.alloc(cimg * STP_RCAP * sizeof(stp_drec)));
-    HIPCHK(bCnt.alloc(cimg * sizeof(int32_t)));
-    HIPCHK(hipMemcpyAsync(bM.p, M_levels, n_levels * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(bB.p, prm->bright, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(bW.p, prm->gauss_w, (2 * prm->gauss_radius + 1) * sizeof(double), hipMemcpyHostToDevice,
-                          ctx->stream));
-    std::vector<int32_t> h_cnt(cimg);
-    std::vector<stp_drec> h_recs(cimg * STP_RCAP);
+    const size_t ocap = cimg * 32;                       // dense records per chunk kept on the device
+    void *pGray, *pLow, *pHigh, *pRecs, *pCnt, *pOut, *pTot, *pPar;
+    HIPCHK(ws_get(ctx, WS_GRAY, cimg * STP_PITCH * STP_PITCH * sizeof(float), &pGray));
+    HIPCHK(ws_get(ctx, WS_LOW, cimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), &pLow));
+    HIPCHK(ws_get(ctx, WS_HIGH, cimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), &pHigh));
+    HIPCHK(ws_get(ctx, WS_RECS, cimg * STP_RCAP * sizeof(stp_drec), &pRecs));
+    HIPCHK(ws_get(ctx, WS_CNT, cimg * sizeof(int32_t), &pCnt));
+    HIPCHK(ws_get(ctx, WS_OUT, ocap * sizeof(stp_stripe_rec), &pOut));
+    HIPCHK(ws_get(ctx, WS_TOTAL, 2 * sizeof(long long), &pTot));
+    const int nwt = 2 * prm->gauss_radius + 1;
+    HIPCHK(ws_get(ctx, WS_PARAMS, (size_t)(n_levels + nb + nwt) * sizeof(double), &pPar));
+    double* dM = (double*)pPar;
+    double* dB = dM + n_levels;
+    double* dW = dB + nb;
+    HIPCHK(hipMemcpyAsync(dM, M_levels, n_levels * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dB, prm->bright, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dW, prm->gauss_w, nwt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    void* pin = nullptr;
+    HIPCHK(pin_get(ctx, ocap * sizeof(stp_stripe_rec) + 64, &pin));
+    long long* h_tot = (long long*)pin;
+    stp_stripe_rec* h_out = (stp_stripe_rec*)((char*)pin + 64);
     int64_t total = 0;
     bool overflow = false;
     for (int f0 = 0; f0 < fr->n; f0 += chunk) {
         const int nf = (fr->n - f0 < chunk) ? fr->n - f0 : chunk;
         const size_t nimg = (size_t)nf * ipf;
-        rc = run_chain(ctx, fr, prm, f0, nf, (const double*)bM.p, n_levels, (const double*)bB.p, (const double*)bW.p,
-                       (float*)bGray.p, (stp_u64*)bLow.p, (stp_u64*)bHigh.p, (stp_drec*)bRecs.p, (int32_t*)bCnt.p, 0,
-                       nullptr, nullptr);
+        rc = run_chain(ctx, fr, prm, f0, nf, dM, n_levels, dB, dW, (float*)pGray, (stp_u64*)pLow, (stp_u64*)pHigh,
+                       (stp_drec*)pRecs, (int32_t*)pCnt, 0, nullptr, nullptr);
         if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(h_cnt.data(), bCnt.p, nimg * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(h_recs.data(), bRecs.p, nimg * STP_RCAP * sizeof(stp_drec), hipMemcpyDeviceToHost,
-                              ctx->stream));
+        {
+            prof_scope ps(ctx, "compact_recs", (double)nimg * 4.0);
+            hipLaunchKernelGGL(k_compact_recs, dim3(1), dim3(1024), 0, ctx->stream, (const stp_drec*)pRecs,
+                               (const int32_t*)pCnt, (int)nimg, f0, n_levels, nb, (stp_stripe_rec*)pOut, (long long)ocap,
+                               (long long*)pTot);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_tot, pTot, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        for (size_t im = 0; im < nimg; im++) {
-            int n = h_cnt[im];
-            if (n > STP_RCAP) { overflow = true; n = STP_RCAP; }
-            const int fl = (int)(im / ipf), lev = (int)((im % ipf) / nb), bi = (int)(im % nb);
-            for (int k = 0; k < n; k++) {
-                if (total < cap) {
-                    const stp_drec& d = h_recs[im * STP_RCAP + k];
-                    stp_stripe_rec& r = out[total];
-                    r.frame = f0 + fl; r.level = lev; r.b_index = bi; r.ud = d.ud;
-                    r.x = d.x; r.y = d.y; r.w = d.w; r.h = d.h; r.total = d.total;
-                }
+        const long long n = h_tot[0];
+        if (h_tot[1]) overflow = true;
+        if ((size_t)n > ocap) return set_err(ctx, STP_E_CAPACITY, "more than 32 candidate stripes per image on average");
+        if (n > 0) {
+            HIPCHK(hipMemcpyAsync(h_out, pOut, (size_t)n * sizeof(stp_stripe_rec), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            for (long long k = 0; k < n; k++) {
+                if (total < cap) out[total] = h_out[k];
                 total++;
             }
         }
@@ -723,7 +827,9 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
 // ---------------------------------------------------------------------------------------------
 // score path
 struct stp_background {
-    double* d = nullptr;   // lu | ru | ld | rd, each 400 x ncol
+    double* d = nullptr;        // lu | ru | ld | rd, each 400 x ncol
+    double* sorted = nullptr;   // the same rows sorted ascending (NaN last)
+    int* nvalid = nullptr;      // non-NaN count of each of the 1600 rows
     int ncol = 0;
 };
 
@@ -806,6 +912,18 @@ int stp_background_upload(stp_ctx* ctx, const double* lu, const double* ru, cons
         hipError_t e = hipMemcpyAsync(bg->d + t * tn, src[t], tn * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) { (void)hipFree(bg->d); delete bg; return set_err(ctx, STP_E_HIP, "background upload failed"); }
     }
+    if (ncol > STP_BG_MAXCOL) { (void)hipFree(bg->d); delete bg; return set_err(ctx, STP_E_UNSUPPORTED, "background tables wider than 2048 columns"); }
+    if (hipMalloc((void**)&bg->sorted, 4 * tn * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&bg->nvalid, 4 * STP_NDIAG * sizeof(int)) != hipSuccess) {
+        stp_background_free(ctx, bg);
+        return set_err(ctx, STP_E_NOMEM, "hipMalloc(sorted background)");
+    }
+    {
+        prof_scope ps(ctx, "bg_sort", 16.0 * 4 * tn);
+        hipLaunchKernelGGL(k_bg_sort, dim3(4 * STP_NDIAG), dim3(512), 0, ctx->stream, (const double*)bg->d, ncol, bg->sorted,
+                           bg->nvalid);
+    }
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *out = bg;
     return STP_OK;
@@ -816,6 +934,8 @@ void stp_background_free(stp_ctx* ctx, stp_background* bg)
     if (!bg) return;
     if (ctx) (void)hipSetDevice(ctx->device);
     if (bg->d) (void)hipFree(bg->d);
+    if (bg->sorted) (void)hipFree(bg->sorted);
+    if (bg->nvalid) (void)hipFree(bg->nvalid);
     delete bg;
 }
 
@@ -851,8 +971,8 @@ int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int
         double bytes = 0;
         for (int64_t i = 0; i < n; i++) bytes += (8.0 * (st[i].col1 - st[i].col0) + 16000.0) * (st[i].row1 - st[i].row0);
         prof_scope ps(ctx, "pvalue", bytes);
-        hipLaunchKernelGGL(k_pvalue, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bg->d, bg->ncol, bs,
-                           (const stp_pv_stripe*)bS.p, (double*)bO.p);
+        hipLaunchKernelGGL(k_pvalue, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bg->sorted, (const int*)bg->nvalid,
+                           bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_p, bO.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

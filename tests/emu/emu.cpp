@@ -39,11 +39,11 @@ void emu_gray(const double* band, int W, int hw, int64_t st, const int16_t* nz, 
         }
 }
 
-void emu_canny(const float* gray /* pitch 400 */, int S, int R, const double* w, stp_u64* low, stp_u64* high)
+void emu_canny2(const float* gray /* pitch 400 */, int S, int R, const double* w, stp_u64* low, stp_u64* high, int blocked)
 {
     const int GW = ct_gw(R), GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
-    std::vector<float> sG(GH * GW), sV(VH * GW);
-    std::vector<double> sB(2 * VH), sS(VH * (CT_X + 4)), sM((CT_Y + 2) * (CT_X + 2));
+    std::vector<float> sG(GH * GW), sV(VH * GW > GW * CT_VP ? VH * GW : GW * CT_VP);
+    std::vector<double> sB(2 * VH), sS(VH * CT_SP), sM((CT_Y + 2) * (CT_X + 2));
     std::vector<uint8_t> sC(CT_Y * CT_X);
     memset(low, 0, sizeof(stp_u64) * STP_FRAME_MAX * STP_NW);
     memset(high, 0, sizeof(stp_u64) * STP_FRAME_MAX * STP_NW);
@@ -51,13 +51,26 @@ void emu_canny(const float* gray /* pitch 400 */, int S, int R, const double* w,
         for (int tx0 = 0; tx0 < S; tx0 += CT_X) {
             stp_tile T; T.S = S; T.ty0 = ty0; T.tx0 = tx0;
             canny_p0(0, 1, gray, T, R, sG.data());
-            canny_p1(0, 1, T, R, w, sG.data(), sV.data());
             canny_p1b(0, 1, T, R, w, sB.data());
-            canny_p2(0, 1, T, R, w, sV.data(), sB.data(), sS.data());
+            if (R == 8 && blocked) {
+                canny_p1_blk<8>(0, 1, T, w, sG.data(), sV.data());
+                canny_p2_blk<8>(0, 1, T, w, sV.data(), sB.data(), sS.data());
+            } else if (R == 10 && blocked) {
+                canny_p1_blk<10>(0, 1, T, w, sG.data(), sV.data());
+                canny_p2_blk<10>(0, 1, T, w, sV.data(), sB.data(), sS.data());
+            } else {
+                canny_p1(0, 1, T, R, w, sG.data(), sV.data());
+                canny_p2(0, 1, T, R, w, sV.data(), sB.data(), sS.data());
+            }
             canny_p3(0, 1, T, sS.data(), sM.data());
             canny_p4(0, 1, T, sS.data(), sM.data(), sC.data());
             canny_p5(0, 1, T, sC.data(), low, high);
         }
+}
+
+void emu_canny(const float* gray, int S, int R, const double* w, stp_u64* low, stp_u64* high)
+{
+    emu_canny2(gray, S, R, w, low, high, 1);
 }
 
 struct emu_rec { int32_t ud, x, y, w, h; double total; };
