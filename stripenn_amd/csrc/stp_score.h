@@ -308,36 +308,52 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
         double e = ex[idx] + .00000001;
         return o / e;
     };
-    // all-NaN columns (:709-711) and the rows they delete (:713-733)
+    // all-NaN columns (:709-711): a column is alive when any of its pixels is not NaN (all lanes work
+    // on pixels; a benign write race sets the flag)
     if (tid < 3) nkc[tid] = 0;
+    for (int b = 0; b < 3; b++)
+        for (int c = tid; c < STP_SCORE_MAXCOLS; c += nt) keepc[b][c] = 0;
     __syncthreads();
     for (int b = 0; b < 3; b++) {
         const int w = s.col1[b] - s.col0[b];
-        for (int c = tid; c < w; c += nt) {
-            bool allnan = true;
-            for (int r = 0; r < h && allnan; r++) { double v = oe(b, r, c); allnan = (v != v); }
-            keepc[b][c] = allnan ? 0 : 1;
-            if (allnan) {
-                int rd = s.mirror ? (h - 1 - c) : c;
-                if (rd < 0) rd += h;
-                if (rd >= 0 && rd < h) rowdel[rd] = 1;
-            }
+        for (int i = tid; i < w * h; i += nt) {
+            const int r = i / w, c = i - r * w;
+            const double v = oe(b, r, c);
+            if (v == v) keepc[b][c] = 1;
         }
     }
     __syncthreads();
+    // the rows dead columns delete (:713-733), compaction of kept columns / rows
     if (tid == 0) {
+        int anydel = 0;
         for (int b = 0; b < 3; b++) {
             const int w = s.col1[b] - s.col0[b];
             int n = 0;
-            for (int c = 0; c < w; c++) if (keepc[b][c]) keepc[b][n++] = (int16_t)c;
+            for (int c = 0; c < w; c++) {
+                if (keepc[b][c]) keepc[b][n++] = (int16_t)c;
+                else {
+                    int rd = s.mirror ? (h - 1 - c) : c;
+                    if (rd < 0) rd += h;
+                    if (rd >= 0 && rd < h) { rowdel[rd] = 1; anydel = 1; }
+                }
+            }
             nkc[b] = n;
         }
-        int n = 0;
-        for (int r = 0; r < h; r++) if (!rowdel[r]) keepr[n++] = (int16_t)r;
-        nkr = n;
+        int n = h;
+        if (anydel) {
+            n = 0;
+            for (int r = 0; r < h; r++) if (!rowdel[r]) keepr[n++] = (int16_t)r;
+        }
+        nkr = anydel ? n : -h;       // negative: identity map, filled in parallel below
         s_tot = 0.0;
     }
     __syncthreads();
+    if (nkr < 0) {
+        for (int r = tid; r < h; r += nt) keepr[r] = (int16_t)r;
+        __syncthreads();
+        if (tid == 0) nkr = h;
+        __syncthreads();
+    }
     const int hk = nkr;
     // row means after nantozero (:739-745), numpy pairwise order over the kept columns
     for (int it = tid; it < 3 * hk; it += nt) {
@@ -348,11 +364,19 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
     }
     __syncthreads();
     // centerTotal / centerMean (:747-748): sum over center[rows repeated once per kept column]
-    if (tid == 0) {
+    // (tolerance statistic: tree reduction of the row sums)
+    {
+        double loc = 0.0;
         const int n = nkc[0];
-        double T = 0.0;
-        for (int q = 0; q < hk; q++) T += rowm[0][q] * (double)n;   // row sums
-        s_tot = T;
+        for (int q = tid; q < hk; q += nt) loc += rowm[0][q] * (double)n;
+        diff[tid] = loc;             // diff[] is free until the scores below (nt <= MAXROWS)
+        __syncthreads();
+        for (int o = nt >> 1; o > 0; o >>= 1) {
+            if (tid < o) diff[tid] += diff[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) s_tot = diff[0];
+        __syncthreads();
     }
     // Sobel-like scores (:750-756, stats.py:184-199)
     for (int i = tid + 1; i < hk - 1; i += nt) {
@@ -422,59 +446,95 @@ __global__ __launch_bounds__(256) void k_stripe_mean(stp_bandref B, const stp_re
 
 // ---------------------------------------------------------------------------------------------
 // StripeSearch's medpixel = np.quantile(submat[submat > 0], 0.5) (getStripe.py:885): exact order
-// statistics by an 8-pass radix select over the frame's positive pixels (positive doubles order
-// like their bit patterns).  out[f*3 + {0,1,2}] = a[(N-1)//2], a[N//2], N.
+// statistics over the frame's positive pixels (positive doubles order like their bit patterns).
+// a[k0], k0 = (N-1)/2, by a 5-pass radix select with 13-bit digits (8192-bin LDS histogram, bins
+// scanned in parallel); a[k1], k1 = N/2, from one more pass: it equals a[k0] when more than k1 values
+// are <= a[k0], else the smallest value above a[k0].  out[f*3 + {0,1,2}] = a[k0], a[k1], N.
+#define STP_MED_BINS 8192
 __global__ __launch_bounds__(1024) void k_medpixel(stp_bandref B, const int32_t* __restrict__ fstart,
                                                     const int32_t* __restrict__ fn0, double* __restrict__ out)
 {
-    __shared__ unsigned int hist[256];
-    __shared__ unsigned long long s_prefix;
-    __shared__ unsigned int s_k, s_n;
-    const int f = blockIdx.x;
+    __shared__ unsigned int hist[STP_MED_BINS];
+    __shared__ unsigned int part[1024];
+    __shared__ unsigned long long s_prefix, s_min;
+    __shared__ unsigned int s_k, s_n, s_le;
+    const int f = blockIdx.x, tid = threadIdx.x;
     const int64_t st = fstart[f];
     const int n0 = fn0[f];
     const int64_t tot = (int64_t)n0 * n0;
-    // count positives
-    if (threadIdx.x == 0) s_n = 0;
+    auto load = [&](int64_t i) -> double {
+        const int r = (int)(i / n0), c = (int)(i - (int64_t)r * n0);
+        return B.d[(st + r) * (int64_t)B.W + (c - r + B.hw)];
+    };
+    if (tid == 0) { s_n = 0; s_le = 0; s_min = ~0ull; }
     __syncthreads();
     unsigned int loc = 0;
-    for (int64_t i = threadIdx.x; i < tot; i += blockDim.x) {
-        int r = (int)(i / n0), c = (int)(i - (int64_t)r * n0);
-        double v = B.d[(st + r) * (int64_t)B.W + (c - r + B.hw)];
-        loc += (v > 0.0);
-    }
+    for (int64_t i = tid; i < tot; i += 1024) loc += (load(i) > 0.0);
     atomicAdd(&s_n, loc);
     __syncthreads();
     const unsigned int N = s_n;
-    double res[2] = {NAN, NAN};
-    for (int which = 0; which < 2 && N > 0; which++) {
-        unsigned int k = which ? N / 2 : (N - 1) / 2;
-        unsigned long long prefix = 0;
-        for (int pass = 0; pass < 8; pass++) {
-            const int shift = 56 - 8 * pass;
-            for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    if (N == 0) {
+        if (tid == 0) { out[f * 3] = NAN; out[f * 3 + 1] = NAN; out[f * 3 + 2] = 0.0; }
+        return;
+    }
+    unsigned int k = (N - 1) / 2;
+    unsigned long long prefix = 0;
+    const int shifts[5] = {51, 38, 25, 12, 0};
+    const int widths[5] = {13, 13, 13, 13, 12};
+    for (int pass = 0; pass < 5; pass++) {
+        const int shift = shifts[pass], nbins = 1 << widths[pass];
+        for (int i = tid; i < STP_MED_BINS; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < tot; i += 1024) {
+            const double v = load(i);
+            if (!(v > 0.0)) continue;
+            const unsigned long long key = (unsigned long long)__double_as_longlong(v);
+            const int hs = shift + widths[pass];
+            const bool match = (pass == 0) || ((key >> hs) == (prefix >> hs));
+            if (match) atomicAdd(&hist[(key >> shift) & (nbins - 1)], 1u);
+        }
+        __syncthreads();
+        // parallel scan: 8 bins per lane -> partial sums -> inclusive scan -> locate the bin of rank k
+        unsigned int mine = 0;
+        for (int b = 0; b < 8; b++) mine += hist[tid * 8 + b];
+        part[tid] = mine;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            unsigned int v = (tid >= o) ? part[tid - o] : 0;
             __syncthreads();
-            for (int64_t i = threadIdx.x; i < tot; i += blockDim.x) {
-                int r = (int)(i / n0), c = (int)(i - (int64_t)r * n0);
-                double v = B.d[(st + r) * (int64_t)B.W + (c - r + B.hw)];
-                if (!(v > 0.0)) continue;
-                unsigned long long key = (unsigned long long)__double_as_longlong(v);
-                bool match = (pass == 0) || ((key >> (shift + 8)) == (prefix >> (shift + 8)));
-                if (match) atomicAdd(&hist[(key >> shift) & 0xFF], 1u);
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned int acc = 0;
-                int d = 0;
-                for (; d < 256; d++) { if (acc + hist[d] > k) break; acc += hist[d]; }
-                s_k = k - acc;
-                s_prefix = prefix | ((unsigned long long)d << shift);
-            }
-            __syncthreads();
-            k = s_k; prefix = s_prefix;
+            part[tid] += v;
             __syncthreads();
         }
-        res[which] = __longlong_as_double((long long)prefix);
+        const unsigned int incl = part[tid], excl = incl - mine;
+        if (excl <= k && k < incl) {              // exactly one lane
+            unsigned int acc = excl;
+            int d = tid * 8;
+            for (;; d++) { if (acc + hist[d] > k) break; acc += hist[d]; }
+            s_k = k - acc;
+            s_prefix = prefix | ((unsigned long long)d << shift);
+        }
+        __syncthreads();
+        k = s_k; prefix = s_prefix;
+        __syncthreads();
     }
-    if (threadIdx.x == 0) { out[f * 3] = res[0]; out[f * 3 + 1] = res[1]; out[f * 3 + 2] = (double)N; }
+    const unsigned long long key0 = prefix;
+    unsigned int le = 0;
+    unsigned long long mn = ~0ull;
+    for (int64_t i = tid; i < tot; i += 1024) {
+        const double v = load(i);
+        if (!(v > 0.0)) continue;
+        const unsigned long long key = (unsigned long long)__double_as_longlong(v);
+        if (key <= key0) le++;
+        else if (key < mn) mn = key;
+    }
+    atomicAdd(&s_le, le);
+    atomicMin(&s_min, mn);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int k1 = N / 2;
+        const unsigned long long key1 = (s_le > k1) ? key0 : s_min;
+        out[f * 3] = __longlong_as_double((long long)key0);
+        out[f * 3 + 1] = __longlong_as_double((long long)key1);
+        out[f * 3 + 2] = (double)N;
+    }
 }

@@ -79,12 +79,66 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
     }
 }
 
+// Tile load with every global load in flight at once: fixed trip count, clamped address and a
+// select instead of a branch (a branchy loop serialises the ~17 loads of a thread, ~8 us per tile).
+template <int R>
+struct canny_tile_regs {
+    static constexpr int GW = CT_X + 2 * R + 4, GH = CT_Y + 2 * R + 4, N = GH * GW, IT = (N + 255) / 256;
+    float v[IT];
+    // issue every global load of this thread's share of the tile (no wait)
+    __device__ __forceinline__ void issue(int tid, const float* __restrict__ gimg, stp_tile T)
+    {
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = tid + k * 256;
+            const int yy = i / GW, xx = i - yy * GW;
+            const int y = T.ty0 - R - 2 + yy, x = T.tx0 - R - 2 + xx;
+            const int yc = min(max(y, 0), T.S - 1), xc = min(max(x, 0), T.S - 1);
+            const float g = gimg[yc * STP_PITCH + xc];
+            v[k] = (y == yc && x == xc) ? g : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void commit(int tid, float* sG) const
+    {
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = tid + k * 256;
+            if (i < N) sG[i] = v[k];
+        }
+    }
+};
+
+template <int R>
+__device__ __forceinline__ void canny_load_tile(int tid, const float* __restrict__ gimg, stp_tile T, float* sG)
+{
+    canny_tile_regs<R> r;
+    r.issue(tid, gimg, T);
+    r.commit(tid, sG);
+}
+
+// NMS class of the tile's pixels and bit-plane packing by wave ballot (lane = x, CT_X == 64)
+__device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double* sS, const double* sM,
+                                               stp_u64* __restrict__ low_img, stp_u64* __restrict__ high_img)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int yy = wv; yy < CT_Y; yy += 4) {
+        const int y = T.ty0 + yy, x = T.tx0 + lane;
+        int c = 0;
+        if (y < T.S && x < T.S) c = ct_nms(sS, sM, T, y, x);
+        const stp_u64 lo = __ballot(c >= 1), hi = __ballot(c == 2);
+        if (lane == 0 && y < T.S) {
+            low_img[y * STP_NW + (T.tx0 >> 6)] = lo;
+            high_img[y * STP_NW + (T.tx0 >> 6)] = hi;
+        }
+    }
+}
+
 // K-B: Canny up to the classified local maxima, one tile of one image per workgroup.
 // RT > 0: compile-time Gaussian radius with register-blocked passes; RT == 0: generic radius.
 template <int RT>
 __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
                                                 int imgs_per_frame, int Rrun, const double* __restrict__ gw,
-                                                stp_u64* __restrict__ low, stp_u64* __restrict__ high)
+                                                stp_u64* __restrict__ low, stp_u64* __restrict__ high, int dbg_stop)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int R = RT > 0 ? RT : Rrun;
@@ -96,6 +150,7 @@ __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, c
     stp_tile T;
     T.S = S; T.ty0 = (blockIdx.x / tpr) * CT_Y; T.tx0 = (blockIdx.x % tpr) * CT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
+    if (dbg_stop == -1) return;                                   // timing-only: pure dispatch cost
     const int GW = ct_gw(R), GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
     // layout: [sW | sB | sS | sG | sV]; sM and sC alias sG/sV once those are dead
     double* sW = (double*)smem;                                   // 2*CT_RMAX+1 -> 32 slots
@@ -108,12 +163,16 @@ __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, c
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid < 2 * R + 1) sW[tid] = gw[tid];
     const float* gimg = gray + (size_t)img * (STP_PITCH * STP_PITCH);
-    canny_p0(tid, nt, gimg, T, R, sG);
+    if constexpr (RT > 0) canny_load_tile<RT>(tid, gimg, T, sG);
+    else canny_p0(tid, nt, gimg, T, R, sG);
+    if (dbg_stop == -2) return;                                   // timing-only: tile load without p1b
     canny_p1b(tid, nt, T, R, gw, sB);
     __syncthreads();
+    if (dbg_stop == 1) { if (tid == 0) low[(size_t)img * 2800] = (stp_u64)sG[5]; return; }   // timing-only ablation
     if constexpr (RT > 0) {
         canny_p1_blk<RT>(tid, nt, T, sW, sG, sV);
         __syncthreads();
+        if (dbg_stop == 2) { if (tid == 0) low[(size_t)img * 2800] = (stp_u64)sV[5]; return; }
         canny_p2_blk<RT>(tid, nt, T, sW, sV, sB, sS);
     } else {
         canny_p1(tid, nt, T, R, sW, sG, sV);
@@ -121,14 +180,15 @@ __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, c
         canny_p2(tid, nt, T, R, sW, sV, sB, sS);
     }
     __syncthreads();
+    if (dbg_stop == 3) { if (tid == 0) low[(size_t)img * 2800] = (stp_u64)sS[5]; return; }
     canny_p3(tid, nt, T, sS, sM);
     __syncthreads();
-    canny_p4(tid, nt, T, sS, sM, sC);
-    __syncthreads();
-    canny_p5(tid, nt, T, sC, low + (size_t)img * (STP_FRAME_MAX * STP_NW), high + (size_t)img * (STP_FRAME_MAX * STP_NW));
+    if (dbg_stop == 4) { if (tid == 0) low[(size_t)img * 2800] = (stp_u64)sM[5]; return; }
+    (void)sC;
+    canny_nms_pack(tid, T, sS, sM, low + (size_t)img * (STP_FRAME_MAX * STP_NW), high + (size_t)img * (STP_FRAME_MAX * STP_NW));
 }
 
-static size_t canny_smem_bytes(int R)
+static __host__ __device__ size_t canny_smem_bytes(int R)
 {
     const int GW = CT_X + 2 * R + 4, GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
     size_t fixed = (32 + 2 * VH + VH * CT_SP) * sizeof(double);
@@ -136,6 +196,61 @@ static size_t canny_smem_bytes(int R)
     size_t gv = ((size_t)GH * GW + vsz) * sizeof(float);
     size_t mc = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(double) + CT_Y * CT_X;
     return fixed + (gv > mc ? gv : mc);
+}
+
+// K-B, pipelined form (compile-time radius): one workgroup per (tile, frame, level) walks the
+// brightness images of that tile; the next image's grey tile is prefetched into registers while the
+// current one is filtered (global-load latency was additive with compute in the one-tile-per-
+// workgroup form).  Blocks are mapped XCD-aware: blocks b, b+8, b+16, ... share an XCD (round-robin
+// dispatch), so they are given consecutive tiles of the same (frame, level) and the overlapping
+// halos of neighbouring tiles are served by that XCD's L2.
+template <int RT>
+__global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
+                                                     int nf, int nlev, int nb, const double* __restrict__ gw,
+                                                     stp_u64* __restrict__ low, stp_u64* __restrict__ high)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int R = RT;
+    constexpr int TPI = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);   // 91
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int pair = xcd + 8 * (j / TPI), tile = j % TPI;
+    if (pair >= nf * nlev) return;
+    const int fl = pair / nlev, lev = pair - fl * nlev;
+    const int S = fS[f0 + fl];
+    if (S == 0) return;
+    constexpr int tpr = (STP_FRAME_MAX + CT_X - 1) / CT_X;
+    stp_tile T;
+    T.S = S; T.ty0 = (tile / tpr) * CT_Y; T.tx0 = (tile % tpr) * CT_X;
+    if (T.ty0 >= S || T.tx0 >= S) return;
+    constexpr int GW = CT_X + 2 * R + 4, GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
+    double* sW = (double*)smem;
+    double* sB = sW + 32;
+    double* sS = sB + 2 * VH;
+    float* sG = (float*)(sS + VH * CT_SP);
+    float* sV = sG + GH * GW;
+    double* sM = (double*)sG;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid < 2 * R + 1) sW[tid] = gw[tid];
+    const size_t img0 = ((size_t)fl * nlev + lev) * nb;
+    canny_tile_regs<R> nxt;
+    nxt.issue(tid, gray + img0 * (STP_PITCH * STP_PITCH), T);
+    canny_p1b(tid, nt, T, R, gw, sB);          // bleed-over factors depend on the tile geometry only
+    nxt.commit(tid, sG);
+    __syncthreads();
+    for (int bi = 0; bi < nb; bi++) {
+        const size_t img = img0 + bi;
+        if (bi + 1 < nb) nxt.issue(tid, gray + (img + 1) * (STP_PITCH * STP_PITCH), T);   // in flight during the filters
+        canny_p1_blk<R>(tid, nt, T, sW, sG, sV);
+        __syncthreads();
+        canny_p2_blk<R>(tid, nt, T, sW, sV, sB, sS);
+        __syncthreads();
+        canny_p3(tid, nt, T, sS, sM);           // sM aliases sG / sV (both dead now)
+        __syncthreads();
+        canny_nms_pack(tid, T, sS, sM, low + img * (STP_FRAME_MAX * STP_NW), high + img * (STP_FRAME_MAX * STP_NW));
+        __syncthreads();
+        if (bi + 1 < nb) nxt.commit(tid, sG);
+        __syncthreads();
+    }
 }
 
 struct stp_drec {
@@ -663,15 +778,23 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         prof_scope ps(ctx, "canny", ipx * 5.0);          // stage B: 4 B read + 1 B written
         const int tiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
         const dim3 cg(tiles, (unsigned)nimg);
-        if (R == 8)
+        static const int dbg_stop = getenv("STP_CANNY_STOP") ? atoi(getenv("STP_CANNY_STOP")) : 0;  // profiling ablation only
+        const unsigned pgrid = (unsigned)(((nf * nlev + 7) / 8) * 8 * tiles);
+        if (R == 8 && dbg_stop == 0)
+            hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_smem_bytes(R), ctx->stream, d_gray,
+                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high);
+        else if (R == 10 && dbg_stop == 0)
+            hipLaunchKernelGGL(k_canny_pipe<10>, dim3(pgrid), dim3(256), canny_smem_bytes(R), ctx->stream, d_gray,
+                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high);
+        else if (R == 8)
             hipLaunchKernelGGL(k_canny<8>, cg, dim3(256), canny_smem_bytes(R), ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
-                               d_low, d_high);
+                               d_low, d_high, dbg_stop);
         else if (R == 10)
             hipLaunchKernelGGL(k_canny<10>, cg, dim3(256), canny_smem_bytes(R), ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
-                               d_low, d_high);
+                               d_low, d_high, dbg_stop);
         else
             hipLaunchKernelGGL(k_canny<0>, cg, dim3(256), canny_smem_bytes(R), ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
-                               d_low, d_high);
+                               d_low, d_high, dbg_stop);
     }
     HIPCHK(hipGetLastError());
     {
