@@ -520,6 +520,41 @@ STP_HD int lines_hyst_sweep(int tid, int nt, int S, const stp_u64* sLow, stp_u64
     return changed;
 }
 
+// Strip form of the sweep: one item = one word-column x 8 consecutive rows, walked downwards and then
+// upwards in place, so a sweep carries a connection across >= 8 rows (vertical edges -- the stripes
+// themselves -- needed one sweep per row with the plain form).  Same fix-point (the closure is unique).
+#define STP_HYST_STRIP 8
+STP_HD stp_u64 lines_hyst_row(int S, int r, int w, const stp_u64* sLow, stp_u64* sE, int* changed)
+{
+    const stp_u64 lowv = sLow[r * STP_NW + w];
+    const stp_u64 cur = sE[r * STP_NW + w];
+    if (!lowv) return cur;
+    stp_u64 n = 0;
+    for (int dr = -1; dr <= 1; dr++) {
+        const int rr = r + dr;
+        if (rr < 0 || rr >= S) continue;
+        const stp_u64* row = sE + rr * STP_NW;
+        n |= row[w] | bm_shl1(row, w) | bm_shr1(row, w);
+    }
+    const stp_u64 seed = n & lowv;
+    if (!seed) return cur;
+    const stp_u64 nv = stp_runfill(lowv, seed) | cur;
+    if (nv != cur) { sE[r * STP_NW + w] = nv; *changed = 1; }
+    return nv;
+}
+STP_HD int lines_hyst_sweep_strip(int tid, int nt, int S, const stp_u64* sLow, stp_u64* sE)
+{
+    int changed = 0;
+    const int nstrip = (S + STP_HYST_STRIP - 1) / STP_HYST_STRIP;
+    for (int i = tid; i < nstrip * STP_NW; i += nt) {
+        const int st = i / STP_NW, w = i - st * STP_NW;
+        const int r0 = st * STP_HYST_STRIP, r1 = (r0 + STP_HYST_STRIP < S) ? r0 + STP_HYST_STRIP : S;
+        for (int r = r0; r < r1; r++) lines_hyst_row(S, r, w, sLow, sE, &changed);
+        for (int r = r1 - 2; r >= r0; r--) lines_hyst_row(S, r, w, sLow, sE, &changed);
+    }
+    return changed;
+}
+
 STP_HD void stp_fa(stp_u64 x, stp_u64 y, stp_u64 c, stp_u64* s, stp_u64* co)
 {
     stp_u64 t = x ^ y;
@@ -599,12 +634,20 @@ STP_HD void lines_block(int tid, int nt, int S, int minH, const stp_u64* sV, con
         int count = 0, MAX = 0, END = 0, J = 0, buffer = 0;
         const int wi = c >> 6;
         const stp_u64 bit = 1ull << (c & 63);
-        for (int i = 0; i < S; i++) {
-            if (sV3[i * STP_NW + wi] & bit) { count++; J = i; }
-            else if (buffer < 5) buffer++;
-            else {
-                if (count > MAX) { MAX = count; END = J; }
-                count = 0; buffer = 0;
+        for (int i0 = 0; i0 < S; i0 += 8) {          // 8 independent LDS reads in flight per step
+            stp_u64 wd[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) wd[k] = (i0 + k < S) ? sV3[(i0 + k) * STP_NW + wi] : 0ull;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int i = i0 + k;
+                if (i >= S) break;
+                if (wd[k] & bit) { count++; J = i; }
+                else if (buffer < 5) buffer++;
+                else {
+                    if (count > MAX) { MAX = count; END = J; }
+                    count = 0; buffer = 0;
+                }
             }
         }
         if (count > MAX) { MAX = count; END = J; }
@@ -718,23 +761,65 @@ STP_HD void lines_colstat(int tid, int nt, int S, const stp_u64* sT, int16_t* cn
         const int wi = c >> 6;
         const stp_u64 bit = 1ull << (c & 63);
         int n = 0, mn = S, mx = -1;
-        for (int y = 0; y < S; y++)
-            if (sT[y * STP_NW + wi] & bit) { n++; if (mn == S) mn = y; mx = y; }
+        for (int y0 = 0; y0 < S; y0 += 8) {
+            stp_u64 wd[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) wd[k] = (y0 + k < S) ? sT[(y0 + k) * STP_NW + wi] : 0ull;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (wd[k] & bit) { const int y = y0 + k; n++; if (mn == S) mn = y; mx = y; }
+        }
         cnt[c] = (int16_t)n; minr[c] = (int16_t)mn; maxr[c] = (int16_t)mx;
     }
+}
+
+// Ordered compaction of the columns with >= 3 pixels (getStripe.py:994) in two phases around a
+// barrier: per-wave counts, then positions.  wcnt: 8 ints.  On the CPU replay (nt == 1) phase 1 does
+// nothing and phase 2 is the plain loop.
+STP_HD void lines_cols_count(int tid, int nt, int S, const int16_t* cnt, int* wcnt)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool f = (tid < S) && (cnt[tid] >= 3);
+    const stp_u64 m = __ballot(f);
+    if ((tid & 63) == 0 && (tid >> 6) < 8) wcnt[tid >> 6] = __popcll(m);
+#else
+    (void)tid; (void)nt; (void)S; (void)cnt; (void)wcnt;
+#endif
+}
+STP_HD void lines_cols_place(int tid, int nt, int S, const int16_t* cnt, const int* wcnt, int16_t* cidx, int16_t* clen,
+                             int* nrow_out)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool f = (tid < S) && (cnt[tid] >= 3);
+    const stp_u64 m = __ballot(f);
+    const int wv = tid >> 6, lane = tid & 63;
+    int base = 0, total = 0;
+    for (int i = 0; i < 8; i++) { if (i < wv) base += wcnt[i]; total += wcnt[i]; }
+    if (f) {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        cidx[pos] = (int16_t)tid; clen[pos] = cnt[tid];
+    }
+    if (tid == 0) *nrow_out = total;
+#else
+    (void)nt; (void)wcnt;
+    if (tid == 0) {
+        int nrow = 0;
+        for (int c = 0; c < S; c++)
+            if (cnt[c] >= 3) { cidx[nrow] = (int16_t)c; clen[nrow] = cnt[c]; nrow++; }
+        *nrow_out = nrow;
+    }
+#endif
 }
 
 struct stp_lrec { int16_t ud, x, y, w, h; };
 
 // getStripe.py:994-1078 for one ud: column grouping (incl. the stale-[Current] behaviour of the
 // loop at :1019-1028), X = sorted(set(meanX)), neighbour pairing.  Executed by ONE thread.
-// scratch: cidx[S], clen[S] (int16), xs[S+2] (int16).  Returns the new record count.
-STP_HD int lines_group_pairs(int S, int ud, int maxW, const int16_t* cnt, const int16_t* minr, const int16_t* maxr,
-                             int16_t* cidx, int16_t* clen, int16_t* xs, stp_lrec* recs, int nrec, int cap)
+// cidx/clen[0..nrow): the columns with >= 3 pixels and their counts (lines_cols_place); scratch xs[S+2].
+// Returns the new record count.
+STP_HD int lines_group_pairs(int S, int ud, int maxW, int nrow, const int16_t* minr, const int16_t* maxr,
+                             const int16_t* cidx, const int16_t* clen, int16_t* xs, stp_lrec* recs, int nrec, int cap)
 {
-    int nrow = 0;
-    for (int c = 0; c < S; c++)
-        if (cnt[c] >= 3) { cidx[nrow] = (int16_t)c; clen[nrow] = cnt[c]; nrow++; }
     // meanX values are integers in [0, S): mark them in a bitmap (set semantics + sorted order)
     stp_u64 seen[STP_NW];
     for (int w = 0; w < STP_NW; w++) seen[w] = 0;

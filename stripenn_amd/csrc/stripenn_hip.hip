@@ -266,7 +266,8 @@ __global__ __launch_bounds__(512) void k_lines(const stp_u64* __restrict__ low, 
                                                 const int16_t* __restrict__ fnz, int f0, int imgs_per_frame,
                                                 int minH, int maxW, stp_drec* __restrict__ recs,
                                                 int32_t* __restrict__ rec_count, int want_dbg,
-                                                stp_u64* __restrict__ dbg /* E,V,T1,T2 */, int16_t* __restrict__ dbg_cols)
+                                                stp_u64* __restrict__ dbg /* E,V,T1,T2 */, int16_t* __restrict__ dbg_cols,
+                                                int dbg_stop)
 {
     __shared__ stp_u64 buf0[STP_FRAME_MAX * STP_NW];   // low -> V3 -> testmat
     __shared__ stp_u64 buf1[STP_FRAME_MAX * STP_NW];   // E (edges)
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(512) void k_lines(const stp_u64* __restrict__ low, 
     __shared__ int16_t cidx[STP_FRAME_MAX], clen[STP_FRAME_MAX], xs[STP_FRAME_MAX + 8];
     __shared__ stp_lrec lrec[STP_RCAP];
     __shared__ double rs[STP_FRAME_MAX];
-    __shared__ int s_nrec;
+    __shared__ int s_nrec, s_nrow, s_wcnt[8];
     const int img = blockIdx.x;
     const int f = f0 + img / imgs_per_frame;
     const int S = fS[f];
@@ -291,17 +292,21 @@ __global__ __launch_bounds__(512) void k_lines(const stp_u64* __restrict__ low, 
     for (int i = tid; i < S; i += nt) s_nz[i] = fnz[(size_t)f * STP_FRAME_MAX + i];
     lines_load(tid, nt, S, limg, himg, buf0, buf1);
     __syncthreads();
+    if (dbg_stop == 1) { if (tid == 0) rec_count[img] = (int)buf1[3]; return; }      // timing-only ablation
     for (int it = 0; it < 4 * STP_FRAME_MAX * STP_FRAME_MAX; it++) {
-        int ch = lines_hyst_sweep(tid, nt, S, buf0, buf1);
+        int ch = lines_hyst_sweep_strip(tid, nt, S, buf0, buf1);
         if (!__syncthreads_or(ch)) break;
     }
+    if (dbg_stop == 2) { if (tid == 0) rec_count[img] = (int)buf1[3]; return; }
     lines_vline(tid, nt, S, buf1, buf2);
     __syncthreads();
     lines_v3(tid, nt, S, buf2, buf0);
     __syncthreads();
+    if (dbg_stop == 3) { if (tid == 0) rec_count[img] = (int)buf0[3]; return; }
     lines_block(tid, nt, S, minH, buf2, buf0, colT, colEnd, colUd);
     if (tid == 0) s_nrec = 0;
     __syncthreads();
+    if (dbg_stop == 4) { if (tid == 0) rec_count[img] = colT[3]; return; }
     if (want_dbg) {
         stp_u64* d = dbg + (size_t)img * 4 * (STP_FRAME_MAX * STP_NW);
         for (int i = tid; i < S * STP_NW; i += nt) { d[i] = buf1[i]; d[STP_FRAME_MAX * STP_NW + i] = buf2[i]; }
@@ -321,10 +326,15 @@ __global__ __launch_bounds__(512) void k_lines(const stp_u64* __restrict__ low, 
             for (int i = tid; i < S * STP_NW; i += nt) d[i] = buf0[i];
         }
         __syncthreads();
-        if (tid == 0)
-            s_nrec = lines_group_pairs(S, ud, maxW, cnt, minr, maxr, cidx, clen, xs, lrec, s_nrec, STP_RCAP);
+        lines_cols_count(tid, nt, S, cnt, s_wcnt);
+        __syncthreads();
+        lines_cols_place(tid, nt, S, cnt, s_wcnt, cidx, clen, &s_nrow);
+        __syncthreads();
+        if (tid == 0 && dbg_stop != 6)
+            s_nrec = lines_group_pairs(S, ud, maxW, s_nrow, minr, maxr, cidx, clen, xs, lrec, s_nrec, STP_RCAP);
         __syncthreads();
     }
+    if (dbg_stop == 5 || dbg_stop == 6) { if (tid == 0) rec_count[img] = 0; return; }
     const int nrec = s_nrec;
     const int nst = nrec < STP_RCAP ? nrec : STP_RCAP;
     stp_drec* out = recs + (size_t)img * STP_RCAP;
@@ -798,10 +808,11 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     }
     HIPCHK(hipGetLastError());
     {
+        static const int lines_stop = getenv("STP_LINES_STOP") ? atoi(getenv("STP_LINES_STOP")) : 0;  // profiling ablation only
         prof_scope ps(ctx, "lines", ipx * 9.0);          // stages C-F: 2 + 2 + 1 + 4 B per image px
         hipLaunchKernelGGL(k_lines, dim3((unsigned)nimg), dim3(512), 0, ctx->stream, d_low, d_high, band->d, band->W,
                            band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, ipf, prm->minH, prm->maxW, d_recs, d_cnt,
-                           want_dbg, d_dbg, d_dbgc);
+                           want_dbg, d_dbg, d_dbgc, lines_stop);
     }
     HIPCHK(hipGetLastError());
     return STP_OK;

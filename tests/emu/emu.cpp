@@ -87,7 +87,7 @@ int emu_lines(const stp_u64* low, const stp_u64* high, const double* band, int W
     std::vector<double> rs(400);
     lines_load(0, 1, S, low, high, buf0.data(), buf1.data());
     int sweeps = 0;
-    while (lines_hyst_sweep(0, 1, S, buf0.data(), buf1.data())) sweeps++;
+    while (lines_hyst_sweep_strip(0, 1, S, buf0.data(), buf1.data())) sweeps++;
     if (sweeps_out) *sweeps_out = sweeps;
     lines_vline(0, 1, S, buf1.data(), buf2.data());
     lines_v3(0, 1, S, buf2.data(), buf0.data());
@@ -102,7 +102,10 @@ int emu_lines(const stp_u64* low, const stp_u64* high, const double* band, int W
         lines_refine(0, 1, S, buf1.data(), buf2.data(), buf0.data());
         lines_colstat(0, 1, S, buf0.data(), cnt.data(), minr.data(), maxr.data());
         memcpy(dbg + (size_t)(1 + ud) * BW, buf0.data(), BW * 8);
-        nrec = lines_group_pairs(S, ud, maxW, cnt.data(), minr.data(), maxr.data(), cidx.data(), clen.data(), xs.data(),
+        int nrow = 0, wcnt[8] = {0};
+        lines_cols_count(0, 1, S, cnt.data(), wcnt);
+        lines_cols_place(0, 1, S, cnt.data(), wcnt, cidx.data(), clen.data(), &nrow);
+        nrec = lines_group_pairs(S, ud, maxW, nrow, minr.data(), maxr.data(), cidx.data(), clen.data(), xs.data(),
                                  lrec.data(), nrec, STP_RCAP);
     }
     int nst = nrec < STP_RCAP ? nrec : STP_RCAP;
