@@ -133,6 +133,61 @@ STP_HD void gray_p2(int tid, int nt, stp_tile T, int a, const double* sadj, floa
     }
 }
 
+// ---- wave-strip form of the per-brightness part (bfilter = 3): the 32 x 64 tile is cut into four
+// 8-row strips, one per wave, lane = column.  A wave writes the adj values of ITS strip (+1 halo row
+// above / below, +1 halo column left / right) into its own LDS slice and then blurs them, so the
+// brightness loop needs no workgroup barrier; the blur keeps the row-major tap order of cv.filter2D.
+// sg: (GT_Y+2) x (GT_X+2) g plane of the whole tile; sadjw: 10 x (GT_X+2) doubles of this wave.
+#define GS_ROWS 8
+STP_HD void gray_wadj(int lane, int strip, double b, const double* sg, double* sadjw)
+{
+    const int WW = GT_X + 2;
+    const double k = (1.0 - 0.0) / (b - 0.0);
+    const double* g0 = sg + (strip * GS_ROWS) * WW;          // strip rows -1 .. 8 are sg rows strip*8 .. +9
+#pragma unroll
+    for (int r = 0; r < GS_ROWS + 2; r++) sadjw[r * WW + lane + 1] = stp_bright_px(g0[r * WW + lane + 1], b, k);
+    if (lane < 2 * (GS_ROWS + 2)) {                           // the two halo columns
+        const int r = lane >> 1, c = (lane & 1) ? WW - 1 : 0;
+        sadjw[r * WW + c] = stp_bright_px(g0[r * WW + c], b, k);
+    }
+}
+STP_HD void gray_wblur(int lane, int strip, stp_tile T, const double* sadjw, float* __restrict__ gray_img)
+{
+    const int WW = GT_X + 2;
+    const double kv = 1.0 / 9.0;
+    double rb = 0.0;
+    for (int t = 0; t < 9; t++) rb = rb + kv * 1.0;
+    if (rb < 0.0) rb = 0.0;
+    if (rb > 1.0) rb = 1.0;
+    const float r32 = (float)rb;
+    const int x = T.tx0 + lane;
+    double w0[3], w1[3], w2[3];                               // three rows of the 3-column window
+#pragma unroll
+    for (int c = 0; c < 3; c++) { w0[c] = sadjw[0 * WW + lane + c]; w1[c] = sadjw[1 * WW + lane + c]; }
+#pragma unroll
+    for (int q = 0; q < GS_ROWS; q++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) w2[c] = sadjw[(q + 2) * WW + lane + c];
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc = acc + kv * w0[c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc = acc + kv * w1[c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc = acc + kv * w2[c];
+        if (acc < 0.0) acc = 0.0;
+        if (acc > 1.0) acc = 1.0;
+        const float g32 = (float)acc;
+        float v = r32 * 0.299f;
+        v = v + g32 * 0.587f;
+        v = v + g32 * 0.114f;
+        const int y = T.ty0 + strip * GS_ROWS + q;
+        if (y < T.S && x < T.S) gray_img[y * STP_PITCH + x] = v;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { w0[c] = w1[c]; w1[c] = w2[c]; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernel B (k_canny): grey -> Gaussian (f32 rounding after each axis) -> /bleed -> Sobel ->
 // hypot -> NMS -> class bit-planes.   skimage 0.18.3 _canny.py:53-280, scipy ni_filters.c.

@@ -68,8 +68,55 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
     T.S = S; T.ty0 = (blockIdx.x / tpr) * GT_Y; T.tx0 = (blockIdx.x % tpr) * GT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
     const int tid = threadIdx.x, nt = blockDim.x;
-    gray_p0(tid, nt, band, W, hw, (int64_t)fstart[f], fnz + (size_t)f * STP_FRAME_MAX, T, a, Mlev[lev], sg);
+    if (a == 1) {
+        // bfilter 3 (default): compaction map of the tile's rows / columns staged in LDS, then all band
+        // loads of a lane issued back to back (fixed trip count, no dependent global index loads)
+        __shared__ int16_t s_ny[GT_Y + 2], s_nx[GT_X + 2];
+        const int16_t* nzf = fnz + (size_t)f * STP_FRAME_MAX;
+        if (tid < GT_Y + 2) s_ny[tid] = nzf[stp_refl101(min(T.ty0 + tid - 1, S), S)];
+        if (tid >= 64 && tid < 64 + GT_X + 2) s_nx[tid - 64] = nzf[stp_refl101(min(T.tx0 + (tid - 64) - 1, S), S)];
+        __syncthreads();
+        constexpr int HH = GT_Y + 2, WW = GT_X + 2, N = HH * WW, IT = (N + 255) / 256;
+        const int64_t st = fstart[f];
+        const double M = Mlev[lev];
+        double v[IT];
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = min(tid + k * 256, N - 1);
+            const int yy = i / WW, xx = i - yy * WW;
+            const int oy = s_ny[yy], ox = s_nx[xx];
+            v[k] = band[(st + oy) * (int64_t)W + (ox - oy + hw)];
+        }
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = tid + k * 256;
+            if (i < N) {
+                const int yy = i / WW, xx = i - yy * WW;
+                const bool in = (T.ty0 + yy - 1 < S + 1) && (T.tx0 + xx - 1 < S + 1);
+                double d = v[k];
+                if (d != d) d = 0.0;
+                sg[i] = in ? stp_gplane_px(d, M) : 0.0;
+            }
+        }
+    } else {
+        gray_p0(tid, nt, band, W, hw, (int64_t)fstart[f], fnz + (size_t)f * STP_FRAME_MAX, T, a, Mlev[lev], sg);
+    }
     __syncthreads();
+    if (a == 1) {
+        // wave-strip form: no workgroup barrier in the brightness loop (LDS ops of one wave are in order)
+        const int lane = tid & 63, strip = tid >> 6;
+        double* sadjw = sadj + strip * ((GS_ROWS + 2) * (GT_X + 2));
+        for (int bi = 0; bi < nb; bi++) {
+            const size_t img = ((size_t)fl * nlev + lev) * nb + bi;
+            gray_wadj(lane, strip, bvals[bi], sg, sadjw);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            gray_wblur(lane, strip, T, sadjw, gray + img * (size_t)(STP_PITCH * STP_PITCH));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     for (int bi = 0; bi < nb; bi++) {
         gray_p1(tid, nt, a, bvals[bi], sg, sadj);
         __syncthreads();

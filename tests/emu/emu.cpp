@@ -33,8 +33,16 @@ void emu_gray(const double* band, int W, int hw, int64_t st, const int16_t* nz, 
             stp_tile T; T.S = S; T.ty0 = ty0; T.tx0 = tx0;
             gray_p0(0, 1, band, W, hw, st, nz, T, a, M, sg.data());
             for (int bi = 0; bi < nb; bi++) {
-                gray_p1(0, 1, a, bvals[bi], sg.data(), sadj.data());
-                gray_p2(0, 1, T, a, sadj.data(), gray + (size_t)bi * STP_PITCH * STP_PITCH);
+                if (a == 1) {       // wave-strip form (the device path for bfilter 3): lanes replayed one by one
+                    for (int strip = 0; strip < GT_Y / GS_ROWS; strip++) {
+                        double* sw = sadj.data() + strip * ((GS_ROWS + 2) * (GT_X + 2));
+                        for (int lane = 0; lane < 64; lane++) gray_wadj(lane, strip, bvals[bi], sg.data(), sw);
+                        for (int lane = 0; lane < 64; lane++) gray_wblur(lane, strip, T, sw, gray + (size_t)bi * STP_PITCH * STP_PITCH);
+                    }
+                } else {
+                    gray_p1(0, 1, a, bvals[bi], sg.data(), sadj.data());
+                    gray_p2(0, 1, T, a, sadj.data(), gray + (size_t)bi * STP_PITCH * STP_PITCH);
+                }
             }
         }
 }
