@@ -313,6 +313,42 @@ STP_HD void canny_p1_blk(int tid, int nt, stp_tile T, const double* w, const flo
     }
 }
 
+// vertical pass reading the grey image directly (no LDS copy of the tile): consecutive lanes read
+// consecutive columns of one image row (coalesced); rows shared by neighbouring groups come from L1/L2.
+template <int R>
+STP_HD void canny_p1_blk_g(int tid, int nt, stp_tile T, const double* w, const float* __restrict__ gimg, float* sVT)
+{
+    const int GW = CT_X + 2 * R + 4;
+    const int NG = (CT_Y + 4) / CT_VRUN;
+    for (int i = tid; i < GW * NG; i += nt) {
+        const int xx = i % GW, yg = i / GW;
+        const int yy0 = yg * CT_VRUN;
+        const int x = T.tx0 - R - 2 + xx;
+        const int xc = x < 0 ? 0 : (x > T.S - 1 ? T.S - 1 : x);
+        const bool xin = (x == xc);
+        float raw[CT_VRUN + 2 * R];
+#pragma unroll
+        for (int k = 0; k < CT_VRUN + 2 * R; k++) {        // all loads issued before any use
+            const int y = T.ty0 - R - 2 + yy0 + k;
+            const int yc = y < 0 ? 0 : (y > T.S - 1 ? T.S - 1 : y);
+            const float g = gimg[yc * STP_PITCH + xc];
+            raw[k] = (xin && y == yc) ? g : 0.0f;
+        }
+        double win[CT_VRUN + 2 * R];
+#pragma unroll
+        for (int k = 0; k < CT_VRUN + 2 * R; k++) win[k] = (double)raw[k];
+#pragma unroll
+        for (int q = 0; q < CT_VRUN; q++) {
+            const int y = T.ty0 - 2 + yy0 + q;
+            double o = win[q + R] * w[R];
+#pragma unroll
+            for (int k = R; k >= 1; k--) o += (win[q + R - k] + win[q + R + k]) * w[R - k];
+            float out = (y >= 0 && y < T.S && xin) ? (float)o : 0.0f;
+            sVT[xx * CT_VP + yy0 + q] = out;
+        }
+    }
+}
+
 template <int R>
 STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const float* sVT, const double* sB, double* sS)
 {

@@ -245,12 +245,22 @@ static __host__ __device__ size_t canny_smem_bytes(int R)
     return fixed + (gv > mc ? gv : mc);
 }
 
-// K-B, pipelined form (compile-time radius): one workgroup per (tile, frame, level) walks the
-// brightness images of that tile; the next image's grey tile is prefetched into registers while the
-// current one is filtered (global-load latency was additive with compute in the one-tile-per-
-// workgroup form).  Blocks are mapped XCD-aware: blocks b, b+8, b+16, ... share an XCD (round-robin
-// dispatch), so they are given consecutive tiles of the same (frame, level) and the overlapping
+// K-B, per-tile brightness loop (compile-time radius): one workgroup per (tile, frame, level) walks the
+// brightness images of that tile (the bleed-over factors and all index arithmetic are shared).  The
+// vertical pass reads the grey image straight from global memory into registers, so LDS holds only the
+// transposed vertical-pass tile (aliased later by the magnitude tile) and the smoothed tile: 38.7 KB,
+// four workgroups per CU.  Blocks are mapped XCD-aware: blocks b, b+8, b+16, ... share an XCD
+// (round-robin dispatch), so they get consecutive tiles of the same (frame, level) and the overlapping
 // halos of neighbouring tiles are served by that XCD's L2.
+static __host__ __device__ size_t canny_pipe_smem_bytes(int R)
+{
+    const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
+    size_t fixed = (32 + 2 * VH + VH * CT_SP) * sizeof(double);
+    size_t v = (size_t)GW * CT_VP * sizeof(float);
+    size_t m = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(double);
+    return fixed + (v > m ? v : m);
+}
+
 template <int RT>
 __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
                                                      int nf, int nlev, int nb, const double* __restrict__ gw,
@@ -269,33 +279,26 @@ __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gr
     stp_tile T;
     T.S = S; T.ty0 = (tile / tpr) * CT_Y; T.tx0 = (tile % tpr) * CT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
-    constexpr int GW = CT_X + 2 * R + 4, GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
+    constexpr int VH = CT_Y + 4;
     double* sW = (double*)smem;
     double* sB = sW + 32;
     double* sS = sB + 2 * VH;
-    float* sG = (float*)(sS + VH * CT_SP);
-    float* sV = sG + GH * GW;
-    double* sM = (double*)sG;
+    float* sV = (float*)(sS + VH * CT_SP);
+    double* sM = (double*)sV;                    // magnitude tile aliases the vertical-pass tile
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid < 2 * R + 1) sW[tid] = gw[tid];
-    const size_t img0 = ((size_t)fl * nlev + lev) * nb;
-    canny_tile_regs<R> nxt;
-    nxt.issue(tid, gray + img0 * (STP_PITCH * STP_PITCH), T);
-    canny_p1b(tid, nt, T, R, gw, sB);          // bleed-over factors depend on the tile geometry only
-    nxt.commit(tid, sG);
+    canny_p1b(tid, nt, T, R, gw, sB);            // bleed-over factors depend on the tile geometry only
     __syncthreads();
+    const size_t img0 = ((size_t)fl * nlev + lev) * nb;
     for (int bi = 0; bi < nb; bi++) {
         const size_t img = img0 + bi;
-        if (bi + 1 < nb) nxt.issue(tid, gray + (img + 1) * (STP_PITCH * STP_PITCH), T);   // in flight during the filters
-        canny_p1_blk<R>(tid, nt, T, sW, sG, sV);
+        canny_p1_blk_g<R>(tid, nt, T, sW, gray + img * (STP_PITCH * STP_PITCH), sV);
         __syncthreads();
         canny_p2_blk<R>(tid, nt, T, sW, sV, sB, sS);
         __syncthreads();
-        canny_p3(tid, nt, T, sS, sM);           // sM aliases sG / sV (both dead now)
+        canny_p3(tid, nt, T, sS, sM);
         __syncthreads();
         canny_nms_pack(tid, T, sS, sM, low + img * (STP_FRAME_MAX * STP_NW), high + img * (STP_FRAME_MAX * STP_NW));
-        __syncthreads();
-        if (bi + 1 < nb) nxt.commit(tid, sG);
         __syncthreads();
     }
 }
@@ -838,10 +841,10 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         static const int dbg_stop = getenv("STP_CANNY_STOP") ? atoi(getenv("STP_CANNY_STOP")) : 0;  // profiling ablation only
         const unsigned pgrid = (unsigned)(((nf * nlev + 7) / 8) * 8 * tiles);
         if (R == 8 && dbg_stop == 0)
-            hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_smem_bytes(R), ctx->stream, d_gray,
+            hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R), ctx->stream, d_gray,
                                fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high);
         else if (R == 10 && dbg_stop == 0)
-            hipLaunchKernelGGL(k_canny_pipe<10>, dim3(pgrid), dim3(256), canny_smem_bytes(R), ctx->stream, d_gray,
+            hipLaunchKernelGGL(k_canny_pipe<10>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R), ctx->stream, d_gray,
                                fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high);
         else if (R == 8)
             hipLaunchKernelGGL(k_canny<8>, cg, dim3(256), canny_smem_bytes(R), ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,

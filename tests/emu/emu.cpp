@@ -61,10 +61,10 @@ void emu_canny2(const float* gray /* pitch 400 */, int S, int R, const double* w
             canny_p0(0, 1, gray, T, R, sG.data());
             canny_p1b(0, 1, T, R, w, sB.data());
             if (R == 8 && blocked) {
-                canny_p1_blk<8>(0, 1, T, w, sG.data(), sV.data());
+                canny_p1_blk_g<8>(0, 1, T, w, gray, sV.data());
                 canny_p2_blk<8>(0, 1, T, w, sV.data(), sB.data(), sS.data());
             } else if (R == 10 && blocked) {
-                canny_p1_blk<10>(0, 1, T, w, sG.data(), sV.data());
+                canny_p1_blk_g<10>(0, 1, T, w, gray, sV.data());
                 canny_p2_blk<10>(0, 1, T, w, sV.data(), sB.data(), sS.data());
             } else {
                 canny_p1(0, 1, T, R, w, sG.data(), sV.data());
