@@ -26,6 +26,11 @@ CHR16_BINS = 19642     # mm10 chr16 (98,207,768 bp) at 5 kb
 MAXPIXEL = [0.95, 0.96, 0.97, 0.98, 0.99]
 BYTES_PER_IMAGE_PX = {'gray': 12.0, 'canny': 5.0, 'lines': 9.0}  # SURVEY.md 8(d) stages A, B, C-F
 SCORE_KERNELS = ('pvalue', 'stripiness')
+# HBM bytes per launch of the chain kernels for THIS default workload, from rocprofv3 PMC passes
+# (profiles/r01b_pmc_traffic.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, KB units, FETCH_SIZE
+# doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read inside this script.
+PMC_TRAFFIC_BYTES = {'canny': (2 * 910600 + 130100) * 1024.0, 'gray': (2 * 329500 + 1819000) * 1024.0,
+                     'lines': (2 * 88080 + 465) * 1024.0}
 
 
 def frame_table(nbins):
@@ -209,7 +214,8 @@ def main():
         d = stats[dom]
         ach = d['alg_bytes'] / d['launches'] / (d['ms'] / d['launches'] * 1e-3) / 1e9
         roof = {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                'frac': round(ach / HBM_PEAK_GBS, 4),
+                'traffic': (PMC_TRAFFIC_BYTES.get(dom) if nb == CHR16_BINS else None),
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                 'alg_bytes_per_launch': d['alg_bytes'] / d['launches'],
                 'chain': {'kernels_ms_per_step': {k: round(v['ms'] / args.steps, 4) for k, v in stats.items()},
