@@ -53,24 +53,28 @@ __device__ double stp_pw_leaf(F get, int64_t o, int n)
     for (; i < n; i++) res += get(o + i);
     return res;
 }
-template <class F>
-__device__ double stp_pw(F get, int64_t o, int64_t n)
+// BIG = false: the caller guarantees n <= 128 (one leaf, no stack, no scratch memory).
+// BIG = true : numpy's recursion pw(o,n) = pw(o,n2) + pw(o+n2,n-n2), n2 = n/2 - (n/2)%8, evaluated in
+// post-order with an explicit stack that the caller provides (LDS or private memory), depth <= 16.
+struct stp_pw_frame {
+    long long o, n;
+    double v;
+    int state;
+};
+template <bool BIG, class F>
+__device__ double stp_pw(F get, int64_t o, int64_t n, stp_pw_frame* stk = nullptr)
 {
-    if (n <= 128) return stp_pw_leaf(get, o, (int)n);
-    // explicit post-order evaluation of pw(o,n) = pw(o,n2) + pw(o+n2,n-n2), n2 = n/2 - (n/2)%8
-    int64_t so[24], sn[24];
-    double sv[24];
-    int state[24];
+    if (!BIG || n <= 128) return stp_pw_leaf(get, o, (int)n);
     int sp = 0;
-    so[0] = o; sn[0] = n; state[0] = 0;
+    stk[0].o = o; stk[0].n = n; stk[0].state = 0;
     double ret = 0.0;
     while (sp >= 0) {
-        int64_t cn = sn[sp], co = so[sp];
+        const int64_t cn = stk[sp].n, co = stk[sp].o;
         if (cn <= 128) { ret = stp_pw_leaf(get, co, (int)cn); sp--; continue; }
         int64_t n2 = cn / 2; n2 -= n2 % 8;
-        if (state[sp] == 0) { state[sp] = 1; so[sp + 1] = co; sn[sp + 1] = n2; state[sp + 1] = 0; sp++; }
-        else if (state[sp] == 1) { sv[sp] = ret; state[sp] = 2; so[sp + 1] = co + n2; sn[sp + 1] = cn - n2; state[sp + 1] = 0; sp++; }
-        else { ret = sv[sp] + ret; sp--; }
+        if (stk[sp].state == 0) { stk[sp].state = 1; stk[sp + 1].o = co; stk[sp + 1].n = n2; stk[sp + 1].state = 0; sp++; }
+        else if (stk[sp].state == 1) { stk[sp].v = ret; stk[sp].state = 2; stk[sp + 1].o = co + n2; stk[sp + 1].n = cn - n2; stk[sp + 1].state = 0; sp++; }
+        else { ret = stk[sp].v + ret; sp--; }
     }
     return ret;
 }
@@ -113,9 +117,12 @@ __global__ __launch_bounds__(448) void k_diag_sums(stp_bandref B, double* __rest
 // `dense` (may be null): the unit matrix itself, nrow x ncol row-major, NaN preserved.  It is supplied
 // by the host for batches in which a Python slice wraps around (negative start) and therefore reads
 // columns far outside the diagonal band; otherwise the resident band is read.
+template <bool BIG>
 __device__ double null_block_mean(const stp_bandref& B, const double* __restrict__ dense, const stp_null_sample& s,
                                   int64_t r0, int64_t r1, int64_t c0, int64_t c1)
 {
+    stp_pw_frame stk_store[BIG ? 16 : 1];
+    stp_pw_frame* stk = stk_store;
     int64_t rl, rh, cl, ch;
     stp_pyslice(r0, r1, s.nrow, &rl, &rh);
     stp_pyslice(c0, c1, s.ncol, &cl, &ch);
@@ -128,15 +135,16 @@ __device__ double null_block_mean(const stp_bandref& B, const double* __restrict
         if (dense) {
             const double* base = dense + rl * (int64_t)s.ncol + cl;
             const int64_t nc = s.ncol;
-            acc = stp_pw([&](int64_t k) { double v = base[(k / w) * nc + (k % w)]; return (v != v) ? 0.0 : v; }, 0, cnt);
+            acc = stp_pw<BIG>([&](int64_t k) { double v = base[(k / w) * nc + (k % w)]; return (v != v) ? 0.0 : v; }, 0, cnt, stk);
         } else {
             const int64_t gr0 = s.row0 + rl, gc0 = s.col0 + cl;
-            acc = stp_pw([&](int64_t k) { return band_at0(B, gr0 + k / w, gc0 + k % w); }, 0, cnt);
+            acc = stp_pw<BIG>([&](int64_t k) { return band_at0(B, gr0 + k / w, gc0 + k % w); }, 0, cnt, stk);
         }
     }
     return acc / (double)cnt;
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(256) void k_null_windows(stp_bandref B, const double* __restrict__ dense,
                                                        const stp_null_sample* __restrict__ samp, int n, int bs,
                                                        double* __restrict__ lu, double* __restrict__ ru,
@@ -149,9 +157,9 @@ __global__ __launch_bounds__(256) void k_null_windows(stp_bandref B, const doubl
     for (int it = threadIdx.x; it < 2 * STP_NDIAG; it += blockDim.x) {
         const int j = it >> 1, dn = it & 1;
         const int64_t y = (dn ? x + j : x - j) + s.yoff;
-        double l = null_block_mean(B, dense, s, x - up - bs, x - up, y - up, y + down);
-        double c = null_block_mean(B, dense, s, x - up, x + down, y - up, y + down);
-        double r = null_block_mean(B, dense, s, x + down, x + down + bs, y - up, y + down);
+        double l = null_block_mean<BIG>(B, dense, s, x - up - bs, x - up, y - up, y + down);
+        double c = null_block_mean<BIG>(B, dense, s, x - up, x + down, y - up, y + down);
+        double r = null_block_mean<BIG>(B, dense, s, x + down, x + down + bs, y - up, y + down);
         double* L = dn ? ld : lu;
         double* R = dn ? rd : ru;
         L[(size_t)j * n + i] = c - l;
@@ -232,6 +240,7 @@ __device__ __forceinline__ int bg_count_ge(const double* __restrict__ srt, int n
     return nv - lo;
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(256) void k_pvalue(stp_bandref B, const double* __restrict__ srt /* sorted lu,ru,ld,rd */,
                                                  const int* __restrict__ nvalid, int ncolbg, int bs,
                                                  const stp_pv_stripe* __restrict__ st, double* __restrict__ out)
@@ -251,7 +260,8 @@ __global__ __launch_bounds__(256) void k_pvalue(stp_bandref B, const double* __r
         const int p = it / h, j = it - p * h;
         const int64_t gr = s.row0 + j;
         const int64_t n = hi[p] - lo[p];
-        part[p][j] = stp_pw([&](int64_t k) { return band_at0(B, gr, s.col0 + k); }, lo[p], n) / (double)n;
+        stp_pw_frame stk[BIG ? 16 : 1];
+        part[p][j] = stp_pw<BIG>([&](int64_t k) { return band_at0(B, gr, s.col0 + k); }, lo[p], n, stk) / (double)n;
     }
     __syncthreads();
     for (int j = threadIdx.x; j < h; j += blockDim.x) {
@@ -278,6 +288,7 @@ __global__ __launch_bounds__(256) void k_pvalue(stp_bandref B, const double* __r
 // ---------------------------------------------------------------------------------------------
 // getStripe.scoringstripes.iterate_idx (getStripe.py:661-759) for one stripe per workgroup
 
+template <bool BIG>
 __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double* __restrict__ exval,
                                                      const stp_score_stripe* __restrict__ st, double* __restrict__ out_g,
                                                      double* __restrict__ out_mean, double* __restrict__ out_total)
@@ -291,9 +302,13 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
     __shared__ int nkc[3], nkr;
     __shared__ double s_res[2];
     __shared__ double s_tot;
-    const stp_score_stripe s = st[blockIdx.x];
-    const int h = s.row1 - s.row0;
+    __shared__ stp_score_stripe s_stripe;            // indexed with run-time block numbers: keep it out of scratch
+    __shared__ stp_pw_frame s_stk[16];
     const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid == 0) s_stripe = st[blockIdx.x];
+    __syncthreads();
+    const stp_score_stripe& s = s_stripe;
+    const int h = s.row1 - s.row0;
     for (int i = tid; i < STP_NDIAG; i += nt) ex[i] = exval[i];
     for (int i = tid; i < h; i += nt) rowdel[i] = 0;
     __syncthreads();
@@ -359,7 +374,8 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
     for (int it = tid; it < 3 * hk; it += nt) {
         const int b = it / hk, q = it - b * hk, r = keepr[q];
         const int n = nkc[b];
-        double sum = stp_pw([&](int64_t k) { double v = oe(b, r, keepc[b][k]); return (v != v) ? 0.0 : v; }, 0, n);
+        stp_pw_frame stk[BIG ? 16 : 1];
+        double sum = stp_pw<BIG>([&](int64_t k) { double v = oe(b, r, keepc[b][k]); return (v != v) ? 0.0 : v; }, 0, n, stk);
         rowm[b][q] = sum / (double)n;
     }
     __syncthreads();
@@ -411,7 +427,7 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
         // diff = [x for x in diff if x >= 0 or x < 0]; np.mean(diff)
         int n = 0;
         for (int q = 0; q < nd; q++) { double v = diff[q]; if (v == v) diff[n++] = v; }
-        double avg = stp_pw([&](int64_t k) { return diff[k]; }, 0, n) / (double)n;
+        double avg = stp_pw<true>([&](int64_t k) { return diff[k]; }, 0, n, s_stk) / (double)n;
         out_g[blockIdx.x] = med * avg;
         const int nc = nkc[0];
         out_total[blockIdx.x] = s_tot * (double)nc;

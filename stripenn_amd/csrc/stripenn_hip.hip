@@ -1069,8 +1069,14 @@ int stp_null_windows(stp_ctx* ctx, const stp_band* band, const double* unit_matr
     double* o = (double*)bO.p;
     {
         prof_scope ps(ctx, "null_windows", 8.0 * (3.0 * bs) * (800.0 + bs) * n);
-        hipLaunchKernelGGL(k_null_windows, dim3(n), dim3(256), 0, ctx->stream, bref(band), (const double*)(unit_matrix ? bD.p : nullptr),
-                           (const stp_null_sample*)bS.p, n, bs, o, o + tn, o + 2 * tn, o + 3 * tn);
+        if (bs * bs <= 128)
+            hipLaunchKernelGGL(k_null_windows<false>, dim3(n), dim3(256), 0, ctx->stream, bref(band),
+                               (const double*)(unit_matrix ? bD.p : nullptr), (const stp_null_sample*)bS.p, n, bs, o, o + tn,
+                               o + 2 * tn, o + 3 * tn);
+        else
+            hipLaunchKernelGGL(k_null_windows<true>, dim3(n), dim3(256), 0, ctx->stream, bref(band),
+                               (const double*)(unit_matrix ? bD.p : nullptr), (const stp_null_sample*)bS.p, n, bs, o, o + tn,
+                               o + 2 * tn, o + 3 * tn);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(lu, o, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1155,8 +1161,14 @@ int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int
         double bytes = 0;
         for (int64_t i = 0; i < n; i++) bytes += (8.0 * (st[i].col1 - st[i].col0) + 16000.0) * (st[i].row1 - st[i].row0);
         prof_scope ps(ctx, "pvalue", bytes);
-        hipLaunchKernelGGL(k_pvalue, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bg->sorted, (const int*)bg->nvalid,
-                           bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p);
+        bool big = bs > 128;
+        for (int64_t i = 0; i < n && !big; i++) big = (st[i].col1 - st[i].col0) > 128;
+        if (!big)
+            hipLaunchKernelGGL(k_pvalue<false>, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bg->sorted,
+                               (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p);
+        else
+            hipLaunchKernelGGL(k_pvalue<true>, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bg->sorted,
+                               (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_p, bO.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1188,8 +1200,15 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
         for (int64_t i = 0; i < n; i++)
             for (int b = 0; b < 3; b++) bytes += 8.0 * (st[i].col1[b] - st[i].col0[b]) * (st[i].row1 - st[i].row0);
         prof_scope ps(ctx, "stripiness", bytes);
-        hipLaunchKernelGGL(k_stripiness, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bE.p,
-                           (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n);
+        bool big = false;
+        for (int64_t i = 0; i < n && !big; i++)
+            for (int b = 0; b < 3; b++) big = big || (st[i].col1[b] - st[i].col0[b]) > 128;
+        if (!big)
+            hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bE.p,
+                               (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n);
+        else
+            hipLaunchKernelGGL(k_stripiness<true>, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bE.p,
+                               (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_g, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
