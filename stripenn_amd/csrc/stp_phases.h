@@ -289,33 +289,10 @@ STP_HD void canny_p2(int tid, int nt, stp_tile T, int R, const double* w, const 
 // LDS with consecutive lanes on consecutive words.
 #define CT_VRUN 12   /* vertical outputs per thread: (CT_Y + 4) = 3 * 12 */
 #define CT_HRUN 5    /* horizontal outputs per thread: ceil(68 / 5) = 14 runs x 36 rows = 504 items */
-template <int R>
-STP_HD void canny_p1_blk(int tid, int nt, stp_tile T, const double* w, const float* sG, float* sVT)
-{
-    const int GW = CT_X + 2 * R + 4;
-    const int NG = (CT_Y + 4) / CT_VRUN;
-    for (int i = tid; i < GW * NG; i += nt) {
-        const int xx = i % GW, yg = i / GW;
-        const int yy0 = yg * CT_VRUN;
-        const int x = T.tx0 - R - 2 + xx;
-        double win[CT_VRUN + 2 * R];
-#pragma unroll
-        for (int k = 0; k < CT_VRUN + 2 * R; k++) win[k] = (double)sG[(yy0 + k) * GW + xx];
-#pragma unroll
-        for (int q = 0; q < CT_VRUN; q++) {
-            const int y = T.ty0 - 2 + yy0 + q;
-            double o = win[q + R] * w[R];
-#pragma unroll
-            for (int k = R; k >= 1; k--) o += (win[q + R - k] + win[q + R + k]) * w[R - k];
-            float out = (y >= 0 && y < T.S && x >= 0 && x < T.S) ? (float)o : 0.0f;
-            sVT[xx * CT_VP + yy0 + q] = out;
-        }
-    }
-}
-
 // vertical pass reading the grey image directly (no LDS copy of the tile): consecutive lanes read
 // consecutive columns of one image row (coalesced); rows shared by neighbouring groups come from L1/L2.
-template <int R>
+// YIN: every row this tile touches (ty0-R-2 .. ty0+CT_Y+R+1) lies inside the image -> no clamping.
+template <int R, bool YIN>
 STP_HD void canny_p1_blk_g(int tid, int nt, stp_tile T, const double* w, const float* __restrict__ gimg, float* sVT)
 {
     const int GW = CT_X + 2 * R + 4;
@@ -327,30 +304,58 @@ STP_HD void canny_p1_blk_g(int tid, int nt, stp_tile T, const double* w, const f
         const int xc = x < 0 ? 0 : (x > T.S - 1 ? T.S - 1 : x);
         const bool xin = (x == xc);
         float raw[CT_VRUN + 2 * R];
+        if (YIN) {
+            const float* col = gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + xc;
 #pragma unroll
-        for (int k = 0; k < CT_VRUN + 2 * R; k++) {        // all loads issued before any use
-            const int y = T.ty0 - R - 2 + yy0 + k;
-            const int yc = y < 0 ? 0 : (y > T.S - 1 ? T.S - 1 : y);
-            const float g = gimg[yc * STP_PITCH + xc];
-            raw[k] = (xin && y == yc) ? g : 0.0f;
+            for (int k = 0; k < CT_VRUN + 2 * R; k++) raw[k] = col[k * STP_PITCH];
+        } else {
+#pragma unroll
+            for (int k = 0; k < CT_VRUN + 2 * R; k++) {        // all loads issued before any use
+                const int y = T.ty0 - R - 2 + yy0 + k;
+                const int yc = y < 0 ? 0 : (y > T.S - 1 ? T.S - 1 : y);
+                const float g = gimg[yc * STP_PITCH + xc];
+                raw[k] = (y == yc) ? g : 0.0f;
+            }
         }
         double win[CT_VRUN + 2 * R];
 #pragma unroll
-        for (int k = 0; k < CT_VRUN + 2 * R; k++) win[k] = (double)raw[k];
+        for (int k = 0; k < CT_VRUN + 2 * R; k++) win[k] = xin ? (double)raw[k] : 0.0;
 #pragma unroll
         for (int q = 0; q < CT_VRUN; q++) {
-            const int y = T.ty0 - 2 + yy0 + q;
             double o = win[q + R] * w[R];
 #pragma unroll
             for (int k = R; k >= 1; k--) o += (win[q + R - k] + win[q + R + k]) * w[R - k];
-            float out = (y >= 0 && y < T.S && xin) ? (float)o : 0.0f;
-            sVT[xx * CT_VP + yy0 + q] = out;
+            float out = (float)o;
+            if (!YIN) {
+                const int y = T.ty0 - 2 + yy0 + q;
+                if (!(y >= 0 && y < T.S)) out = 0.0f;
+            }
+            sVT[xx * CT_VP + yy0 + q] = out;          // columns outside the image give exactly 0 (all-zero window)
         }
     }
 }
 
+// Bleed-over of the border columns of the image (x < R or x >= S-R), tabulated once per workgroup for
+// the VH rows of the tile: sBB[yy * 2R + q], q = x (left border) or R + x - (S-R) (right border).
+// The interior value of each row is sB[VH + yy] (canny_p1b).  Geometry only: shared by all images.
 template <int R>
-STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const float* sVT, const double* sB, double* sS)
+STP_HD void canny_p1c(int tid, int nt, stp_tile T, const double* w, const double* sB, double* sBB)
+{
+    const int VH = CT_Y + 4;
+    for (int i = tid; i < VH * 2 * R; i += nt) {
+        const int yy = i / (2 * R), q = i - yy * (2 * R);
+        const int x = q < R ? q : T.S - R + (q - R);
+        double v = 0.0;
+        if (x >= 0 && x < T.S) v = stp_bleed_h(sB[yy], x, T.S, R, w);
+        sBB[i] = v;
+    }
+}
+
+// XIN: every column of the smoothed tile (tx0-2 .. tx0+CT_X+1) is an interior column (x-R >= 0 and
+// x+R < S) -> no in-image test and no border bleed-over in the inner loop.
+template <int R, bool XIN>
+STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const float* sVT, const double* sB,
+                         const double* sBB, double* sS)
 {
     const int VH = CT_Y + 4, SW = CT_X + 4;
     const int NG = (SW + CT_HRUN - 1) / CT_HRUN;
@@ -358,25 +363,34 @@ STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const flo
         const int yy = i % VH, xg = i / VH;
         const int xx0 = xg * CT_HRUN;
         const int y = T.ty0 - 2 + yy;
+        const bool yin = (y >= 0 && y < T.S);
         double win[CT_HRUN + 2 * R];
 #pragma unroll
         for (int k = 0; k < CT_HRUN + 2 * R; k++) {
             const int col = xx0 + k;                      // sVT column index = image x - (tx0 - R - 2)
             win[k] = (col < CT_X + 2 * R + 4) ? (double)sVT[col * CT_VP + yy] : 0.0;
         }
+        const double bint = sB[VH + yy] + DBL_EPSILON;
 #pragma unroll
         for (int q = 0; q < CT_HRUN; q++) {
             const int xx = xx0 + q;
             if (xx >= SW) break;
-            const int x = T.tx0 - 2 + xx;
-            double s = 0.0;
-            if (y >= 0 && y < T.S && x >= 0 && x < T.S) {
-                double o = win[q + R] * w[R];
+            double o = win[q + R] * w[R];
 #pragma unroll
-                for (int k = R; k >= 1; k--) o += (win[q + R - k] + win[q + R + k]) * w[R - k];
-                float f = (float)o;
-                double bl = (x >= R && x + R < T.S) ? sB[VH + yy] : stp_bleed_h(sB[yy], x, T.S, R, w);
-                s = (double)f / (bl + DBL_EPSILON);
+            for (int k = R; k >= 1; k--) o += (win[q + R - k] + win[q + R + k]) * w[R - k];
+            const float f = (float)o;
+            double s;
+            if (XIN) {
+                s = yin ? (double)f / bint : 0.0;
+            } else {
+                const int x = T.tx0 - 2 + xx;
+                s = 0.0;
+                if (yin && x >= 0 && x < T.S) {
+                    double bl = bint;
+                    if (x < R) bl = sBB[yy * 2 * R + x] + DBL_EPSILON;
+                    else if (x + R >= T.S) bl = sBB[yy * 2 * R + R + (x - (T.S - R))] + DBL_EPSILON;
+                    s = (double)f / bl;
+                }
             }
             sS[yy * CT_SP + xx] = s;
         }
@@ -447,6 +461,31 @@ STP_HD void ct_sobel(const double* sS, stp_tile T, int y, int x, double* is, dou
     *is = i; *js = j;
 }
 
+// interior form: every magnitude pixel and its 3x3 neighbourhood lie strictly inside the image, so the
+// 'reflect' index map is the identity and there is nothing to test
+STP_HD void ct_sobel_in(const double* c, double* is, double* js)
+{
+    const int P = CT_SP;
+    double s00 = c[-P - 1], s01 = c[-P], s02 = c[-P + 1], s10 = c[-1], s12 = c[1], s20 = c[P - 1], s21 = c[P], s22 = c[P + 1];
+    double dm = (s00 - s02) * -1.0, d0 = (s10 - s12) * -1.0, dp = (s20 - s22) * -1.0;
+    double j = d0 * 2.0;
+    j += (dm + dp) * 1.0;
+    double em = (s00 - s20) * -1.0, e0 = (s01 - s21) * -1.0, ep = (s02 - s22) * -1.0;
+    double i = e0 * 2.0;
+    i += (em + ep) * 1.0;
+    *is = i; *js = j;
+}
+STP_HD void canny_p3_in(int tid, int nt, const double* sS, double* sM)
+{
+    const int MH = CT_Y + 2, MW = CT_X + 2;
+    for (int i = tid; i < MH * MW; i += nt) {
+        const int yy = i / MW, xx = i - yy * MW;
+        double is, js;
+        ct_sobel_in(sS + (yy + 1) * CT_SP + (xx + 1), &is, &js);
+        sM[i] = stp_hypot(is, js);
+    }
+}
+
 STP_HD void canny_p3(int tid, int nt, stp_tile T, const double* sS, double* sM)
 {
     const int MH = CT_Y + 2, MW = CT_X + 2;
@@ -457,7 +496,11 @@ STP_HD void canny_p3(int tid, int nt, stp_tile T, const double* sS, double* sM)
         if (y >= 0 && y < T.S && x >= 0 && x < T.S) {
             double is, js;
             ct_sobel(sS, T, y, x, &is, &js);
+#if defined(STP_ABLATE_HYPOT)    /* timing-only build: NOT bit-exact */
+            m = sqrt(is * is + js * js);
+#else
             m = stp_hypot(is, js);
+#endif
         }
         sM[i] = m;
     }

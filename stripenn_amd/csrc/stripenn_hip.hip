@@ -126,43 +126,6 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
     }
 }
 
-// Tile load with every global load in flight at once: fixed trip count, clamped address and a
-// select instead of a branch (a branchy loop serialises the ~17 loads of a thread, ~8 us per tile).
-template <int R>
-struct canny_tile_regs {
-    static constexpr int GW = CT_X + 2 * R + 4, GH = CT_Y + 2 * R + 4, N = GH * GW, IT = (N + 255) / 256;
-    float v[IT];
-    // issue every global load of this thread's share of the tile (no wait)
-    __device__ __forceinline__ void issue(int tid, const float* __restrict__ gimg, stp_tile T)
-    {
-#pragma unroll
-        for (int k = 0; k < IT; k++) {
-            const int i = tid + k * 256;
-            const int yy = i / GW, xx = i - yy * GW;
-            const int y = T.ty0 - R - 2 + yy, x = T.tx0 - R - 2 + xx;
-            const int yc = min(max(y, 0), T.S - 1), xc = min(max(x, 0), T.S - 1);
-            const float g = gimg[yc * STP_PITCH + xc];
-            v[k] = (y == yc && x == xc) ? g : 0.0f;
-        }
-    }
-    __device__ __forceinline__ void commit(int tid, float* sG) const
-    {
-#pragma unroll
-        for (int k = 0; k < IT; k++) {
-            const int i = tid + k * 256;
-            if (i < N) sG[i] = v[k];
-        }
-    }
-};
-
-template <int R>
-__device__ __forceinline__ void canny_load_tile(int tid, const float* __restrict__ gimg, stp_tile T, float* sG)
-{
-    canny_tile_regs<R> r;
-    r.issue(tid, gimg, T);
-    r.commit(tid, sG);
-}
-
 // NMS class of the tile's pixels and bit-plane packing by wave ballot (lane = x, CT_X == 64)
 __device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double* sS, const double* sM,
                                                stp_u64* __restrict__ low_img, stp_u64* __restrict__ high_img)
@@ -180,15 +143,13 @@ __device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double
     }
 }
 
-// K-B: Canny up to the classified local maxima, one tile of one image per workgroup.
-// RT > 0: compile-time Gaussian radius with register-blocked passes; RT == 0: generic radius.
-template <int RT>
+// K-B, generic form (any Gaussian radius <= 12, run-time loops): one tile of one image per workgroup.
+// The default radii 8 (sigma 2.0) and 10 (sigma 2.5) use k_canny_pipe below.
 __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
-                                                int imgs_per_frame, int Rrun, const double* __restrict__ gw,
-                                                stp_u64* __restrict__ low, stp_u64* __restrict__ high, int dbg_stop)
+                                                int imgs_per_frame, int R, const double* __restrict__ gw,
+                                                stp_u64* __restrict__ low, stp_u64* __restrict__ high)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int R = RT > 0 ? RT : Rrun;
     const int img = blockIdx.y;
     const int f = f0 + img / imgs_per_frame;
     const int S = fS[f];
@@ -197,41 +158,25 @@ __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, c
     stp_tile T;
     T.S = S; T.ty0 = (blockIdx.x / tpr) * CT_Y; T.tx0 = (blockIdx.x % tpr) * CT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
-    if (dbg_stop == -1) return;                                   // timing-only: pure dispatch cost
     const int GW = ct_gw(R), GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
-    // layout: [sW | sB | sS | sG | sV]; sM and sC alias sG/sV once those are dead
+    // layout: [sW | sB | sS | sG | sV]; sM aliases sG/sV once those are dead
     double* sW = (double*)smem;                                   // 2*CT_RMAX+1 -> 32 slots
     double* sB = sW + 32;                                         // 2*VH
     double* sS = sB + 2 * VH;                                     // VH*CT_SP
     float* sG = (float*)(sS + VH * CT_SP);                        // GH*GW
-    float* sV = sG + GH * GW;                                     // max(VH*GW, GW*CT_VP)
+    float* sV = sG + GH * GW;                                     // VH*GW
     double* sM = (double*)sG;                                     // (CT_Y+2)*(CT_X+2) f64, aliases sG/sV
-    uint8_t* sC = (uint8_t*)(sM + (CT_Y + 2) * (CT_X + 2));
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid < 2 * R + 1) sW[tid] = gw[tid];
-    const float* gimg = gray + (size_t)img * (STP_PITCH * STP_PITCH);
-    if constexpr (RT > 0) canny_load_tile<RT>(tid, gimg, T, sG);
-    else canny_p0(tid, nt, gimg, T, R, sG);
-    if (dbg_stop == -2) return;                                   // timing-only: tile load without p1b
+    canny_p0(tid, nt, gray + (size_t)img * (STP_PITCH * STP_PITCH), T, R, sG);
     canny_p1b(tid, nt, T, R, gw, sB);
     __syncthreads();
-    if (dbg_stop == 1) { if (tid == 0) low[(size_t)img * 2800] = (stp_u64)sG[5]; return; }   // timing-only ablation
-    if constexpr (RT > 0) {
-        canny_p1_blk<RT>(tid, nt, T, sW, sG, sV);
-        __syncthreads();
-        if (dbg_stop == 2) { if (tid == 0) low[(size_t)img * 2800] = (stp_u64)sV[5]; return; }
-        canny_p2_blk<RT>(tid, nt, T, sW, sV, sB, sS);
-    } else {
-        canny_p1(tid, nt, T, R, sW, sG, sV);
-        __syncthreads();
-        canny_p2(tid, nt, T, R, sW, sV, sB, sS);
-    }
+    canny_p1(tid, nt, T, R, sW, sG, sV);
     __syncthreads();
-    if (dbg_stop == 3) { if (tid == 0) low[(size_t)img * 2800] = (stp_u64)sS[5]; return; }
+    canny_p2(tid, nt, T, R, sW, sV, sB, sS);
+    __syncthreads();
     canny_p3(tid, nt, T, sS, sM);
     __syncthreads();
-    if (dbg_stop == 4) { if (tid == 0) low[(size_t)img * 2800] = (stp_u64)sM[5]; return; }
-    (void)sC;
     canny_nms_pack(tid, T, sS, sM, low + (size_t)img * (STP_FRAME_MAX * STP_NW), high + (size_t)img * (STP_FRAME_MAX * STP_NW));
 }
 
@@ -255,7 +200,7 @@ static __host__ __device__ size_t canny_smem_bytes(int R)
 static __host__ __device__ size_t canny_pipe_smem_bytes(int R)
 {
     const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
-    size_t fixed = (32 + 2 * VH + VH * CT_SP) * sizeof(double);
+    size_t fixed = (32 + 2 * VH + VH * 2 * R + VH * CT_SP) * sizeof(double);
     size_t v = (size_t)GW * CT_VP * sizeof(float);
     size_t m = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(double);
     return fixed + (v > m ? v : m);
@@ -282,21 +227,31 @@ __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gr
     constexpr int VH = CT_Y + 4;
     double* sW = (double*)smem;
     double* sB = sW + 32;
-    double* sS = sB + 2 * VH;
+    double* sBB = sB + 2 * VH;                   // border-column bleed-over table, VH x 2R
+    double* sS = sBB + VH * 2 * R;
     float* sV = (float*)(sS + VH * CT_SP);
     double* sM = (double*)sV;                    // magnitude tile aliases the vertical-pass tile
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid < 2 * R + 1) sW[tid] = gw[tid];
     canny_p1b(tid, nt, T, R, gw, sB);            // bleed-over factors depend on the tile geometry only
     __syncthreads();
+    // tile-uniform fast paths: rows / columns this tile touches all inside the image
+    const bool yin = (T.ty0 - R - 2 >= 0) && (T.ty0 + CT_Y + R + 1 < S);
+    const bool xin = (T.tx0 - 2 - R >= 0) && (T.tx0 + CT_X + 1 + R < S);
+    if (!xin) canny_p1c<R>(tid, nt, T, sW, sB, sBB);
+    __syncthreads();
     const size_t img0 = ((size_t)fl * nlev + lev) * nb;
     for (int bi = 0; bi < nb; bi++) {
         const size_t img = img0 + bi;
-        canny_p1_blk_g<R>(tid, nt, T, sW, gray + img * (STP_PITCH * STP_PITCH), sV);
+        const float* gimg = gray + img * (STP_PITCH * STP_PITCH);
+        if (yin) canny_p1_blk_g<R, true>(tid, nt, T, sW, gimg, sV);
+        else canny_p1_blk_g<R, false>(tid, nt, T, sW, gimg, sV);
         __syncthreads();
-        canny_p2_blk<R>(tid, nt, T, sW, sV, sB, sS);
+        if (xin) canny_p2_blk<R, true>(tid, nt, T, sW, sV, sB, sBB, sS);
+        else canny_p2_blk<R, false>(tid, nt, T, sW, sV, sB, sBB, sS);
         __syncthreads();
-        canny_p3(tid, nt, T, sS, sM);
+        if (xin && yin) canny_p3_in(tid, nt, sS, sM);
+        else canny_p3(tid, nt, T, sS, sM);
         __syncthreads();
         canny_nms_pack(tid, T, sS, sM, low + img * (STP_FRAME_MAX * STP_NW), high + img * (STP_FRAME_MAX * STP_NW));
         __syncthreads();
@@ -838,23 +793,16 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         prof_scope ps(ctx, "canny", ipx * 5.0);          // stage B: 4 B read + 1 B written
         const int tiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
         const dim3 cg(tiles, (unsigned)nimg);
-        static const int dbg_stop = getenv("STP_CANNY_STOP") ? atoi(getenv("STP_CANNY_STOP")) : 0;  // profiling ablation only
         const unsigned pgrid = (unsigned)(((nf * nlev + 7) / 8) * 8 * tiles);
-        if (R == 8 && dbg_stop == 0)
-            hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R), ctx->stream, d_gray,
-                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high);
-        else if (R == 10 && dbg_stop == 0)
-            hipLaunchKernelGGL(k_canny_pipe<10>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R), ctx->stream, d_gray,
-                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high);
-        else if (R == 8)
-            hipLaunchKernelGGL(k_canny<8>, cg, dim3(256), canny_smem_bytes(R), ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
-                               d_low, d_high, dbg_stop);
+        if (R == 8)
+            hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R), ctx->stream, d_gray, fr->d_S,
+                               f0, nf, nlev, nb, d_w, d_low, d_high);
         else if (R == 10)
-            hipLaunchKernelGGL(k_canny<10>, cg, dim3(256), canny_smem_bytes(R), ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
-                               d_low, d_high, dbg_stop);
+            hipLaunchKernelGGL(k_canny_pipe<10>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R), ctx->stream, d_gray, fr->d_S,
+                               f0, nf, nlev, nb, d_w, d_low, d_high);
         else
-            hipLaunchKernelGGL(k_canny<0>, cg, dim3(256), canny_smem_bytes(R), ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
-                               d_low, d_high, dbg_stop);
+            hipLaunchKernelGGL(k_canny, cg, dim3(256), canny_smem_bytes(R), ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
+                               d_low, d_high);
     }
     HIPCHK(hipGetLastError());
     {

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libstripenn_hip.so')
+LIB_PATH = os.environ.get('STP_LIB') or os.path.join(_HERE, 'libstripenn_hip.so')   # STP_LIB: profiling builds only
 
 STP_FRAME_MAX = 400
 STP_OK, STP_E_ARG, STP_E_CAPACITY, STP_E_HIP, STP_E_NOMEM, STP_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
