@@ -398,44 +398,29 @@ STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const flo
 }
 
 // glibc 2.35 sysdeps/ieee754/dbl-64/e_hypot.c (non-FMA kernel), what numpy's np.hypot calls.
+// Straight-line form: glibc's three paths (huge: scale by 2^-600, tiny: by 2^600, normal: none) differ
+// only by an exact power-of-two scaling around the same kernel, so one path with a selected scale factor
+// (1.0 in the normal range) returns identical bits; the "ax >= ay / EPS -> ax + ay" shortcut and the
+// kernel's "h <= 2 ay" alternative are selects.  No branches: independent calls interleave.
 STP_HD double stp_hypot(double x, double y)
 {
     x = fabs(x); y = fabs(y);
-    double ax = x < y ? y : x, ay = x < y ? x : y;
-    if (ax > 0x1p+511) {
-        if (ay <= ax * 0x1p-54) return ax + ay;
-        ax *= 0x1p-600; ay *= 0x1p-600;
-        double h = sqrt(ax * ax + ay * ay);
-        double t1, t2;
-        if (h <= 2.0 * ay) { double d = h - ay; t1 = ax * (2.0 * d - ax); t2 = (d - 2.0 * (ax - ay)) * d; }
-        else { double d = h - ax; t1 = 2.0 * d * (ax - 2.0 * ay); t2 = (4.0 * d - ay) * ay + d * d; }
-        h -= (t1 + t2) / (2.0 * h);
-        return h * 0x1p+600;
-    }
-    if (ay < 0x1p-459) {
-        if (ax >= ay / 0x1p-54) return ax + ay;
-        ax *= 0x1p+600; ay *= 0x1p+600;
-        double h = sqrt(ax * ax + ay * ay);
-        double t1, t2;
-        if (h <= 2.0 * ay) { double d = h - ay; t1 = ax * (2.0 * d - ax); t2 = (d - 2.0 * (ax - ay)) * d; }
-        else { double d = h - ax; t1 = 2.0 * d * (ax - 2.0 * ay); t2 = (4.0 * d - ay) * ay + d * d; }
-        h -= (t1 + t2) / (2.0 * h);
-        return h * 0x1p-600;
-    }
-    if (ax >= ay / 0x1p-54) return ax + ay;
-    double h = sqrt(ax * ax + ay * ay);
-    double t1, t2;
-    if (h <= 2.0 * ay) {
-        double d = h - ay;
-        t1 = ax * (2.0 * d - ax);
-        t2 = (d - 2.0 * (ax - ay)) * d;
-    } else {
-        double d = h - ax;
-        t1 = 2.0 * d * (ax - 2.0 * ay);
-        t2 = (4.0 * d - ay) * ay + d * d;
-    }
+    const double ax = x < y ? y : x, ay = x < y ? x : y;
+    const bool huge = ax > 0x1p+511, tiny = ay < 0x1p-459;
+    const double sc = huge ? 0x1p-600 : (tiny ? 0x1p+600 : 1.0);
+    const double us = huge ? 0x1p+600 : (tiny ? 0x1p-600 : 1.0);
+    // huge: ay <= ax * EPS ; otherwise: ax >= ay / EPS  (same predicate up to exact scaling)
+    const bool far_apart = huge ? (ay <= ax * 0x1p-54) : (ax >= ay * 0x1p+54);
+    const double a = ax * sc, b = ay * sc;
+    double h = sqrt(a * a + b * b);
+    const double dA = h - b, dB = h - a;
+    const double t1A = a * (2.0 * dA - a), t2A = (dA - 2.0 * (a - b)) * dA;
+    const double t1B = 2.0 * dB * (a - 2.0 * b), t2B = (4.0 * dB - b) * b + dB * dB;
+    const bool selA = h <= 2.0 * b;
+    const double t1 = selA ? t1A : t1B, t2 = selA ? t2A : t2B;
     h -= (t1 + t2) / (2.0 * h);
-    return h;
+    h = h * us;
+    return far_apart ? (ax + ay) : h;
 }
 
 // smoothed value at image (y, x) with scipy 'reflect' (only +-1 overshoot is ever requested)
@@ -446,35 +431,29 @@ STP_HD double ct_s(const double* sS, stp_tile T, int y, int x)
 }
 
 // ndi.sobel: antisymmetric pass o = x[0]*0 + (x[-1]-x[1])*(-1) (== x[1]-x[-1]); symmetric pass
-// o = x[0]*2 + (x[-1]+x[1])*1.   jsobel = sobel(axis=1), isobel = sobel(axis=0) (_canny.py:183-184)
+// o = x[0]*2 + (x[-1]+x[1])*1.   jsobel = sobel(axis=1), isobel = sobel(axis=0) (_canny.py:183-184).
+// `c` points at the pixel inside the smoothed tile; up/dn/lf/rt are the offsets of its neighbours.
+STP_HD void ct_sobel_off(const double* c, int up, int dn, int lf, int rt, double* is, double* js)
+{
+    double s00 = c[up + lf], s01 = c[up], s02 = c[up + rt], s10 = c[lf], s12 = c[rt], s20 = c[dn + lf], s21 = c[dn],
+           s22 = c[dn + rt];
+    double dm = (s00 - s02) * -1.0, d0 = (s10 - s12) * -1.0, dp = (s20 - s22) * -1.0;
+    double j = d0 * 2.0;
+    j += (dm + dp) * 1.0;
+    double em = (s00 - s20) * -1.0, e0 = (s01 - s21) * -1.0, ep = (s02 - s22) * -1.0;
+    double i = e0 * 2.0;
+    i += (em + ep) * 1.0;
+    *is = i; *js = j;
+}
+// interior pixel: plain offsets
+STP_HD void ct_sobel_in(const double* c, double* is, double* js) { ct_sobel_off(c, -CT_SP, CT_SP, -1, 1, is, js); }
+// any in-image pixel: scipy's 'reflect' with an overshoot of one is a clamp to the edge pixel
 STP_HD void ct_sobel(const double* sS, stp_tile T, int y, int x, double* is, double* js)
 {
-    double s00 = ct_s(sS, T, y - 1, x - 1), s01 = ct_s(sS, T, y - 1, x), s02 = ct_s(sS, T, y - 1, x + 1);
-    double s10 = ct_s(sS, T, y, x - 1), s12 = ct_s(sS, T, y, x + 1);
-    double s20 = ct_s(sS, T, y + 1, x - 1), s21 = ct_s(sS, T, y + 1, x), s22 = ct_s(sS, T, y + 1, x + 1);
-    double dm = (s00 - s02) * -1.0, d0 = (s10 - s12) * -1.0, dp = (s20 - s22) * -1.0;
-    double j = d0 * 2.0;
-    j += (dm + dp) * 1.0;
-    double em = (s00 - s20) * -1.0, e0 = (s01 - s21) * -1.0, ep = (s02 - s22) * -1.0;
-    double i = e0 * 2.0;
-    i += (em + ep) * 1.0;
-    *is = i; *js = j;
+    const double* c = sS + (y - (T.ty0 - 2)) * CT_SP + (x - (T.tx0 - 2));
+    ct_sobel_off(c, y > 0 ? -CT_SP : 0, y < T.S - 1 ? CT_SP : 0, x > 0 ? -1 : 0, x < T.S - 1 ? 1 : 0, is, js);
 }
 
-// interior form: every magnitude pixel and its 3x3 neighbourhood lie strictly inside the image, so the
-// 'reflect' index map is the identity and there is nothing to test
-STP_HD void ct_sobel_in(const double* c, double* is, double* js)
-{
-    const int P = CT_SP;
-    double s00 = c[-P - 1], s01 = c[-P], s02 = c[-P + 1], s10 = c[-1], s12 = c[1], s20 = c[P - 1], s21 = c[P], s22 = c[P + 1];
-    double dm = (s00 - s02) * -1.0, d0 = (s10 - s12) * -1.0, dp = (s20 - s22) * -1.0;
-    double j = d0 * 2.0;
-    j += (dm + dp) * 1.0;
-    double em = (s00 - s20) * -1.0, e0 = (s01 - s21) * -1.0, ep = (s02 - s22) * -1.0;
-    double i = e0 * 2.0;
-    i += (em + ep) * 1.0;
-    *is = i; *js = j;
-}
 STP_HD void canny_p3_in(int tid, int nt, const double* sS, double* sM)
 {
     const int MH = CT_Y + 2, MW = CT_X + 2;
@@ -515,8 +494,8 @@ STP_HD int ct_nms(const double* sS, const double* sM, stp_tile T, int y, int x)
     const double* mp = sM + (y - (T.ty0 - 1)) * MW + (x - (T.tx0 - 1));
     double m = mp[0];
     if (!(m >= 0.1)) return 0;      // below the low threshold the class is 0 whatever the local-max test says
-    double gi, gj;
-    ct_sobel(sS, T, y, x, &gi, &gj);
+    double gi, gj;        // (y, x) is an interior pixel here: direct indexing, no reflect
+    ct_sobel_in(sS + (y - (T.ty0 - 2)) * CT_SP + (x - (T.tx0 - 2)), &gi, &gj);
     double ai = fabs(gi), aj = fabs(gj);
     bool same = (gi >= 0 && gj >= 0) || (gi <= 0 && gj <= 0);
     bool opp = (gi <= 0 && gj >= 0) || (gi >= 0 && gj <= 0);

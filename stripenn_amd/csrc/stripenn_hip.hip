@@ -193,8 +193,7 @@ static __host__ __device__ size_t canny_smem_bytes(int R)
 // K-B, per-tile brightness loop (compile-time radius): one workgroup per (tile, frame, level) walks the
 // brightness images of that tile (the bleed-over factors and all index arithmetic are shared).  The
 // vertical pass reads the grey image straight from global memory into registers, so LDS holds only the
-// transposed vertical-pass tile (aliased later by the magnitude tile) and the smoothed tile: 38.7 KB,
-// four workgroups per CU.  Blocks are mapped XCD-aware: blocks b, b+8, b+16, ... share an XCD
+// transposed vertical-pass tile (aliased later by the magnitude tile) and the smoothed tile: ~43 KB.  Blocks are mapped XCD-aware: blocks b, b+8, b+16, ... share an XCD
 // (round-robin dispatch), so they get consecutive tiles of the same (frame, level) and the overlapping
 // halos of neighbouring tiles are served by that XCD's L2.
 static __host__ __device__ size_t canny_pipe_smem_bytes(int R)
@@ -247,14 +246,24 @@ __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gr
         if (yin) canny_p1_blk_g<R, true>(tid, nt, T, sW, gimg, sV);
         else canny_p1_blk_g<R, false>(tid, nt, T, sW, gimg, sV);
         __syncthreads();
+#if defined(STP_ABLATE_CANNY_P1)      /* timing-only build: vertical pass only */
+        if (tid == 0) low[img * (STP_FRAME_MAX * STP_NW)] = (stp_u64)sV[70];
+        __syncthreads();
+        continue;
+#endif
         if (xin) canny_p2_blk<R, true>(tid, nt, T, sW, sV, sB, sBB, sS);
         else canny_p2_blk<R, false>(tid, nt, T, sW, sV, sB, sBB, sS);
         __syncthreads();
+#if defined(STP_ABLATE_CANNY_P12)     /* timing-only build: Gaussian passes only */
+        if (tid == 0) low[img * (STP_FRAME_MAX * STP_NW)] = (stp_u64)sS[70];
+        __syncthreads();
+        continue;
+#endif
         if (xin && yin) canny_p3_in(tid, nt, sS, sM);
         else canny_p3(tid, nt, T, sS, sM);
         __syncthreads();
         canny_nms_pack(tid, T, sS, sM, low + img * (STP_FRAME_MAX * STP_NW), high + img * (STP_FRAME_MAX * STP_NW));
-        __syncthreads();
+        __syncthreads();        // sM aliases the vertical-pass tile of the next image
     }
 }
 

@@ -69,20 +69,18 @@ void emu_canny2(const float* gray /* pitch 400 */, int S, int R, const double* w
                 if (yin) canny_p1_blk_g<8, true>(0, 1, T, w, gray, sV.data()); else canny_p1_blk_g<8, false>(0, 1, T, w, gray, sV.data());
                 if (xin) canny_p2_blk<8, true>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data());
                 else canny_p2_blk<8, false>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data());
-                if (xin && yin) { canny_p3_in(0, 1, sS.data(), sM.data()); did_p3 = true; }
             } else if (R == 10 && blocked) {
                 std::vector<double> sBB(VH * 20);
                 if (!xin) canny_p1c<10>(0, 1, T, w, sB.data(), sBB.data());
                 if (yin) canny_p1_blk_g<10, true>(0, 1, T, w, gray, sV.data()); else canny_p1_blk_g<10, false>(0, 1, T, w, gray, sV.data());
                 if (xin) canny_p2_blk<10, true>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data());
                 else canny_p2_blk<10, false>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data());
-                if (xin && yin) { canny_p3_in(0, 1, sS.data(), sM.data()); did_p3 = true; }
             } else {
                 canny_p1(0, 1, T, R, w, sG.data(), sV.data());
                 canny_p2(0, 1, T, R, w, sV.data(), sB.data(), sS.data());
             }
-            if (!did_p3)
-            canny_p3(0, 1, T, sS.data(), sM.data());
+            if (blocked && (R == 8 || R == 10) && xin && yin) { canny_p3_in(0, 1, sS.data(), sM.data()); did_p3 = true; }
+            if (!did_p3) canny_p3(0, 1, T, sS.data(), sM.data());
             canny_p4(0, 1, T, sS.data(), sM.data(), sC.data());
             canny_p5(0, 1, T, sC.data(), low, high);
         }
