@@ -461,7 +461,7 @@ STP_HD void canny_p3_in(int tid, int nt, const double* sS, double* sM)
         const int yy = i / MW, xx = i - yy * MW;
         double is, js;
         ct_sobel_in(sS + (yy + 1) * CT_SP + (xx + 1), &is, &js);
-        sM[i] = stp_hypot(is, js);
+        sM[i] = sqrt(is * is + js * js);              // approximate magnitude, see ct_nms
     }
 }
 
@@ -475,11 +475,7 @@ STP_HD void canny_p3(int tid, int nt, stp_tile T, const double* sS, double* sM)
         if (y >= 0 && y < T.S && x >= 0 && x < T.S) {
             double is, js;
             ct_sobel(sS, T, y, x, &is, &js);
-#if defined(STP_ABLATE_HYPOT)    /* timing-only build: NOT bit-exact */
-            m = sqrt(is * is + js * js);
-#else
-            m = stp_hypot(is, js);
-#endif
+            m = sqrt(is * is + js * js);              // approximate magnitude, see ct_nms
         }
         sM[i] = m;
     }
@@ -487,39 +483,55 @@ STP_HD void canny_p3(int tid, int nt, stp_tile T, const double* sS, double* sM)
 
 // _canny.py:193-280: interior & magnitude>0, four overlapping sectors (later ones override),
 // bilinear interpolation with `<=`, thresholds 0.1 / 0.2 with `>=`.  Returns 0 / 1 (low) / 2 (high).
+//
+// The magnitude tile sM holds h0 = sqrt(is^2 + js^2), NOT numpy's hypot.  h0 is within 2 ulp of the true
+// value and glibc's hypot within 1 ulp, so |h0 - m| <= 3 ulp(m) < 7e-16 m for every pixel.  A decision
+// taken from h0 values equals the reference's whenever the compared quantities differ by more than the
+// propagated error (< 2e-15 of the largest magnitude involved: four magnitudes through two products, one
+// sum, one comparison).  We accept it only when the gap exceeds 1e-12 of that magnitude (500x the bound)
+// and the thresholds 0.1 / 0.2 are missed by more than 1e-13; otherwise (ties, plateaus, near-ties) the
+// five magnitudes are recomputed with the exact glibc kernel (stp_hypot) and the reference's test is
+// evaluated literally.  The fallback is taken by a vanishing fraction of pixels.
 STP_HD int ct_nms(const double* sS, const double* sM, stp_tile T, int y, int x)
 {
     if (y < 1 || x < 1 || y >= T.S - 1 || x >= T.S - 1) return 0;
     const int MW = CT_X + 2;
     const double* mp = sM + (y - (T.ty0 - 1)) * MW + (x - (T.tx0 - 1));
-    double m = mp[0];
-    if (!(m >= 0.1)) return 0;      // below the low threshold the class is 0 whatever the local-max test says
-    double gi, gj;        // (y, x) is an interior pixel here: direct indexing, no reflect
+    const double m0 = mp[0];
+    if (m0 < 0.1 - 1e-13) return 0;       // exact m < 0.1: class 0 whatever the local-max test says
+    double gi, gj;                          // (y, x) is interior: direct indexing
     ct_sobel_in(sS + (y - (T.ty0 - 2)) * CT_SP + (x - (T.tx0 - 2)), &gi, &gj);
-    double ai = fabs(gi), aj = fabs(gj);
-    bool same = (gi >= 0 && gj >= 0) || (gi <= 0 && gj <= 0);
-    bool opp = (gi <= 0 && gj >= 0) || (gi >= 0 && gj <= 0);
-    // the LAST matching sector decides (assignment order in _canny.py)
-    double c1p, c2p, c1m, c2m, wq;
-    if (opp && ai >= aj) {                 // 135-180
-        wq = aj / ai;
-        c1p = mp[-MW]; c2p = mp[-MW + 1]; c1m = mp[MW]; c2m = mp[MW - 1];
-    } else if (opp && ai <= aj) {          // 90-135
-        wq = ai / aj;
-        c1p = mp[1]; c2p = mp[-MW + 1]; c1m = mp[-1]; c2m = mp[MW - 1];
-    } else if (same && ai <= aj) {         // 45-90
-        wq = ai / aj;
-        c1p = mp[1]; c2p = mp[MW + 1]; c1m = mp[-1]; c2m = mp[-MW - 1];
-    } else if (same && ai >= aj) {         // 0-45
-        wq = aj / ai;
-        c1p = mp[MW]; c2p = mp[MW + 1]; c1m = mp[-MW]; c2m = mp[-MW - 1];
-    } else {
-        return 0;
+    const double ai = fabs(gi), aj = fabs(gj);
+    const bool same = (gi >= 0 && gj >= 0) || (gi <= 0 && gj <= 0);
+    const bool opp = (gi <= 0 && gj >= 0) || (gi >= 0 && gj <= 0);
+    // the LAST matching sector decides (assignment order in _canny.py); the "minus" side neighbours are
+    // the mirror images of the "plus" side ones
+    int dy1, dx1, dy2, dx2;
+    double wq;
+    if (opp && ai >= aj) { wq = aj / ai; dy1 = -1; dx1 = 0; dy2 = -1; dx2 = 1; }        // 135-180
+    else if (opp && ai <= aj) { wq = ai / aj; dy1 = 0; dx1 = 1; dy2 = -1; dx2 = 1; }    // 90-135
+    else if (same && ai <= aj) { wq = ai / aj; dy1 = 0; dx1 = 1; dy2 = 1; dx2 = 1; }    // 45-90
+    else if (same && ai >= aj) { wq = aj / ai; dy1 = 1; dx1 = 0; dy2 = 1; dx2 = 1; }    // 0-45
+    else return 0;
+    const int o1 = dy1 * MW + dx1, o2 = dy2 * MW + dx2;
+    const double omw = 1.0 - wq;
+    double m = m0, c1p = mp[o1], c2p = mp[o2], c1m = mp[-o1], c2m = mp[-o2];
+    double lp = c2p * wq + c1p * omw, lm = c2m * wq + c1m * omw;
+    double big = m0;
+    big = c1p > big ? c1p : big; big = c2p > big ? c2p : big; big = c1m > big ? c1m : big; big = c2m > big ? c2m : big;
+    const double tol = big * 1e-12;
+    const bool certain = fabs(lp - m0) > tol && fabs(lm - m0) > tol && fabs(m0 - 0.1) > 1e-13 && fabs(m0 - 0.2) > 1e-13;
+    if (!certain) {                         // exact re-evaluation (glibc hypot of the five pixels)
+        double is, js;
+        m = stp_hypot(gi, gj);
+        ct_sobel(sS, T, y + dy1, x + dx1, &is, &js); c1p = stp_hypot(is, js);
+        ct_sobel(sS, T, y + dy2, x + dx2, &is, &js); c2p = stp_hypot(is, js);
+        ct_sobel(sS, T, y - dy1, x - dx1, &is, &js); c1m = stp_hypot(is, js);
+        ct_sobel(sS, T, y - dy2, x - dx2, &is, &js); c2m = stp_hypot(is, js);
+        lp = c2p * wq + c1p * omw; lm = c2m * wq + c1m * omw;
+        if (!(m > 0.0)) return 0;
     }
-    double omw = 1.0 - wq;
-    bool cp = (c2p * wq + c1p * omw) <= m;
-    bool cm = (c2m * wq + c1m * omw) <= m;
-    if (!(cp && cm)) return 0;
+    if (!(lp <= m && lm <= m)) return 0;
     return (m >= 0.2) ? 2 : ((m >= 0.1) ? 1 : 0);
 }
 

@@ -126,21 +126,61 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
     }
 }
 
-// NMS class of the tile's pixels and bit-plane packing by wave ballot (lane = x, CT_X == 64)
-__device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double* sS, const double* sM,
-                                               stp_u64* __restrict__ low_img, stp_u64* __restrict__ high_img)
+// NMS class of the tile's pixels and bit-plane packing.  Each wave owns 8 rows (lane = x, CT_X == 64):
+// it first collects the pixels whose magnitude reaches the low threshold (the only ones that can get a
+// class) into a wave-private LDS queue by ballot + popcount, then runs the interpolation test densely
+// over the queue, 64 candidates at a time -- candidates are 7-25 % of the pixels but occur in every row,
+// so a per-row test would keep all lanes of every wave busy with the expensive path.
+__device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double* sS, const double* sM, uint16_t* sQ,
+                                               stp_u64* sBits, stp_u64* __restrict__ low_img, stp_u64* __restrict__ high_img)
 {
     const int lane = tid & 63, wv = tid >> 6;
-    for (int yy = wv; yy < CT_Y; yy += 4) {
+    uint16_t* q = sQ + wv * 512;
+    stp_u64* lowB = sBits;
+    stp_u64* highB = sBits + CT_Y;
+    if (lane < 8) { lowB[wv * 8 + lane] = 0; highB[wv * 8 + lane] = 0; }
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int yy = wv * 8 + r;
         const int y = T.ty0 + yy, x = T.tx0 + lane;
-        int c = 0;
-        if (y < T.S && x < T.S) c = ct_nms(sS, sM, T, y, x);
-        const stp_u64 lo = __ballot(c >= 1), hi = __ballot(c == 2);
-        if (lane == 0 && y < T.S) {
-            low_img[y * STP_NW + (T.tx0 >> 6)] = lo;
-            high_img[y * STP_NW + (T.tx0 >> 6)] = hi;
+        bool c = false;
+        if (y >= 1 && x >= 1 && y < T.S - 1 && x < T.S - 1) c = sM[(yy + 1) * (CT_X + 2) + lane + 1] >= 0.1 - 1e-13;
+        const stp_u64 m = __ballot(c);
+        if (c) q[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((yy << 6) | lane);
+        n += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        if (k < n) {
+            const int e = q[k], yy = e >> 6, xx = e & 63;
+            const int cls = ct_nms(sS, sM, T, T.ty0 + yy, T.tx0 + xx);
+            if (cls >= 1) atomicOr(&lowB[yy], 1ull << xx);
+            if (cls == 2) atomicOr(&highB[yy], 1ull << xx);
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 8) {
+        const int yy = wv * 8 + lane, y = T.ty0 + yy;
+        if (y < T.S) {
+            low_img[y * STP_NW + (T.tx0 >> 6)] = lowB[yy];
+            high_img[y * STP_NW + (T.tx0 >> 6)] = highB[yy];
+        }
+    }
+}
+
+#define CANNY_NMS_BYTES (2 * CT_Y * 8 + 4 * 512 * 2)   /* bit-rows + 4 wave queues of 512 u16 */
+static __host__ __device__ size_t canny_smem_bytes(int R)
+{
+    const int GW = CT_X + 2 * R + 4, GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
+    size_t fixed = (32 + 2 * VH + VH * CT_SP) * sizeof(double);
+    size_t vsz = (size_t)VH * GW > (size_t)GW * CT_VP ? (size_t)VH * GW : (size_t)GW * CT_VP;
+    size_t gv = ((size_t)GH * GW + vsz) * sizeof(float);
+    size_t mc = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(double) + CT_Y * CT_X;
+    return fixed + (gv > mc ? gv : mc);
 }
 
 // K-B, generic form (any Gaussian radius <= 12, run-time loops): one tile of one image per workgroup.
@@ -166,6 +206,8 @@ __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, c
     float* sG = (float*)(sS + VH * CT_SP);                        // GH*GW
     float* sV = sG + GH * GW;                                     // VH*GW
     double* sM = (double*)sG;                                     // (CT_Y+2)*(CT_X+2) f64, aliases sG/sV
+    stp_u64* sBits = (stp_u64*)(smem + canny_smem_bytes(R));      // class bit-rows + candidate queues
+    uint16_t* sQ = (uint16_t*)(sBits + 2 * CT_Y);
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid < 2 * R + 1) sW[tid] = gw[tid];
     canny_p0(tid, nt, gray + (size_t)img * (STP_PITCH * STP_PITCH), T, R, sG);
@@ -177,17 +219,8 @@ __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, c
     __syncthreads();
     canny_p3(tid, nt, T, sS, sM);
     __syncthreads();
-    canny_nms_pack(tid, T, sS, sM, low + (size_t)img * (STP_FRAME_MAX * STP_NW), high + (size_t)img * (STP_FRAME_MAX * STP_NW));
-}
-
-static __host__ __device__ size_t canny_smem_bytes(int R)
-{
-    const int GW = CT_X + 2 * R + 4, GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
-    size_t fixed = (32 + 2 * VH + VH * CT_SP) * sizeof(double);
-    size_t vsz = (size_t)VH * GW > (size_t)GW * CT_VP ? (size_t)VH * GW : (size_t)GW * CT_VP;
-    size_t gv = ((size_t)GH * GW + vsz) * sizeof(float);
-    size_t mc = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(double) + CT_Y * CT_X;
-    return fixed + (gv > mc ? gv : mc);
+    canny_nms_pack(tid, T, sS, sM, sQ, sBits, low + (size_t)img * (STP_FRAME_MAX * STP_NW),
+                   high + (size_t)img * (STP_FRAME_MAX * STP_NW));
 }
 
 // K-B, per-tile brightness loop (compile-time radius): one workgroup per (tile, frame, level) walks the
@@ -230,6 +263,8 @@ __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gr
     double* sS = sBB + VH * 2 * R;
     float* sV = (float*)(sS + VH * CT_SP);
     double* sM = (double*)sV;                    // magnitude tile aliases the vertical-pass tile
+    stp_u64* sBits = (stp_u64*)(smem + canny_pipe_smem_bytes(R));   // class bit-rows + candidate queues
+    uint16_t* sQ = (uint16_t*)(sBits + 2 * CT_Y);
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid < 2 * R + 1) sW[tid] = gw[tid];
     canny_p1b(tid, nt, T, R, gw, sB);            // bleed-over factors depend on the tile geometry only
@@ -262,7 +297,7 @@ __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gr
         if (xin && yin) canny_p3_in(tid, nt, sS, sM);
         else canny_p3(tid, nt, T, sS, sM);
         __syncthreads();
-        canny_nms_pack(tid, T, sS, sM, low + img * (STP_FRAME_MAX * STP_NW), high + img * (STP_FRAME_MAX * STP_NW));
+        canny_nms_pack(tid, T, sS, sM, sQ, sBits, low + img * (STP_FRAME_MAX * STP_NW), high + img * (STP_FRAME_MAX * STP_NW));
         __syncthreads();        // sM aliases the vertical-pass tile of the next image
     }
 }
@@ -804,13 +839,13 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         const dim3 cg(tiles, (unsigned)nimg);
         const unsigned pgrid = (unsigned)(((nf * nlev + 7) / 8) * 8 * tiles);
         if (R == 8)
-            hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R), ctx->stream, d_gray, fr->d_S,
-                               f0, nf, nlev, nb, d_w, d_low, d_high);
+            hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_NMS_BYTES, ctx->stream, d_gray,
+                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high);
         else if (R == 10)
-            hipLaunchKernelGGL(k_canny_pipe<10>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R), ctx->stream, d_gray, fr->d_S,
-                               f0, nf, nlev, nb, d_w, d_low, d_high);
+            hipLaunchKernelGGL(k_canny_pipe<10>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_NMS_BYTES, ctx->stream, d_gray,
+                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high);
         else
-            hipLaunchKernelGGL(k_canny, cg, dim3(256), canny_smem_bytes(R), ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
+            hipLaunchKernelGGL(k_canny, cg, dim3(256), canny_smem_bytes(R) + CANNY_NMS_BYTES, ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
                                d_low, d_high);
     }
     HIPCHK(hipGetLastError());

@@ -99,3 +99,50 @@ def test_vertical_line_bitsliced_random(emu):
         edges = good[lab]
         assert np.array_equal(_unpack(dbgw[:2800], S).astype(bool), edges)
         assert np.array_equal(_unpack(dbgw[2800:5600], S), O.vertical_line(edges.astype(np.uint8)))
+
+
+def _plateau_images(S):
+    """Grey images full of exact ties: straight step edges (equal magnitudes along the edge), a symmetric
+    blob, a staircase -- the certified-approximation NMS must fall back to the exact hypot there."""
+    yy, xx = np.mgrid[0:S, 0:S]
+    imgs = []
+    imgs.append(np.where(xx < S // 2, 0.25, 0.9))                                   # vertical step
+    imgs.append(np.where(yy < S // 3, 0.8, 0.3))                                    # horizontal step
+    imgs.append(np.where(xx + yy < S, 0.2, 0.95))                                   # anti-diagonal step
+    imgs.append(np.where(xx - yy > 7, 0.35, 0.85))                                  # diagonal step
+    imgs.append(0.5 + 0.4 * ((np.abs(xx - S // 2) < 20) & (np.abs(yy - S // 2) < 20)))   # symmetric square
+    imgs.append(0.3 + 0.1 * ((xx // 16) % 5))                                       # staircase
+    return [np.ascontiguousarray(i, dtype=np.float32) for i in imgs]
+
+
+@pytest.mark.parametrize('S', [400, 143])
+def test_canny_ties_and_plateaus(emu, S, golden_stages):
+    gw = np.ascontiguousarray(golden_stages['gw_2p0'])
+    for k, img in enumerate(_plateau_images(S)):
+        full = np.zeros((400, 400), np.float32)
+        full[:S, :S] = img
+        low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64)
+        emu.emu_canny(_p(full), S, 8, _p(gw), _p(low), _p(high))
+        oe, dbg = O.canny(img, gw, 8, debug=True)
+        got = _unpack(low, S).astype(np.uint8) + _unpack(high, S)
+        assert np.array_equal(got, dbg['cls']), 'plateau image %d (S=%d)' % (k, S)
+        assert dbg['cls'].any()
+
+
+def test_generic_radius_path(emu, golden_stages):
+    """k_canny (generic radius, run-time loops) replayed with blocked = 0 on one golden image."""
+    g = golden_stages
+    gw = np.ascontiguousarray(g['gw_2p0'])
+    img = _plateau_images(200)[2] * 0.5 + 0.25 * np.random.default_rng(3).random((200, 200)).astype(np.float32)
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    full = np.zeros((400, 400), np.float32); full[:200, :200] = img
+    low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64)
+    emu.emu_canny2(_p(full), 200, 8, _p(gw), _p(low), _p(high), 0)
+    oe, dbg = O.canny(img, gw, 8, debug=True)
+    assert np.array_equal(_unpack(low, 200).astype(np.uint8) + _unpack(high, 200), dbg['cls'])
+    # sigma 3.0 -> radius 12 exists only in the generic form
+    from oracle.oracle import gauss_weights
+    w3, r3 = gauss_weights(3.0)
+    emu.emu_canny2(_p(full), 200, r3, _p(w3), _p(low), _p(high), 0)
+    oe, dbg = O.canny(img, w3, r3, debug=True)
+    assert np.array_equal(_unpack(low, 200).astype(np.uint8) + _unpack(high, 200), dbg['cls'])

@@ -96,3 +96,39 @@ def test_multi_level_batch_matches_oracle(gpu_chr7, golden_stages, chr7):
             int(r['h']), float(r['total'])) for r in recs]
     assert len(got) == len(exp) and len(got) > 50
     assert got == exp
+
+
+def test_plateaus_and_other_parameters(hip_ctx):
+    """Block-structured contact matrices (exact ties in the gradient magnitude -> the certified NMS must
+    take its exact fallback), plus canny sigma 2.5 / 3.0 (generic-radius kernel) and bfilter 1 / 5."""
+    from stripenn_amd import hip
+    n = 900
+    rr, cc = np.mgrid[0:n, 0:n]
+    dense = np.where((cc // 37 + rr // 53) % 2 == 0, 12.0, 3.0) + np.where(np.abs(cc - rr) < 25, 20.0, 0.0)
+    dense = np.where(np.abs(cc - rr) <= 520, dense, 0.0)
+    hw = 512
+    band_h = np.zeros((n, 2 * hw))
+    for i in range(n):
+        lo, hi = max(0, i - hw), min(n, i + hw)
+        band_h[i, lo - i + hw:hi - i + hw] = dense[i, lo:hi]
+    band = hip_ctx.band_upload(band_h)
+    fr = band.frames([0, 100, 500], [299, 499, 899])
+    for sigma, bf in ((2.0, 3), (2.5, 3), (3.0, 3), (2.0, 1), (2.0, 5)):
+        gw, gr = hip.gauss_weights(sigma)
+        for f, (s, e) in enumerate(((0, 299), (100, 499), (500, 899))):
+            D = np.ascontiguousarray(dense[s:e + 1, s:e + 1])
+            for M in (10.0, 30.0):
+                gp = O.gplane(D, M)
+                for bi in (0, 5):
+                    got = fr.dbg_stages(f, M, bi, sigma=sigma, bfilter=bf)
+                    og = O.gray(gp, O.brightness_levels()[bi], bf)
+                    assert np.array_equal(got['gray'], og)
+                    oe, dbg = O.canny(og, gw, gr, debug=True)
+                    assert np.array_equal(got['cls'], dbg['cls']), (sigma, bf, f, M, bi)
+                    assert np.array_equal(got['edges'], oe)
+                recs = fr.stripe_search([M], sigma=sigma, bfilter=bf)
+                mine = recs[recs['frame'] == f]
+                r, tot = O.stripe_search(D, M, sigma=sigma, bf=bf)
+                assert [tuple(int(v) for v in q) for q in r] == [(int(a['b_index']), int(a['ud']), int(a['x']), int(a['y']), int(a['w']), int(a['h'])) for a in mine]
+                assert np.array_equal(mine['total'], tot)
+    fr.close(); band.close()
