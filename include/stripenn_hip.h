@@ -186,6 +186,19 @@ typedef struct {
 int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rects, int64_t n, double* out_mean,
                     double* out_sum);
 
+/* ---- order statistics of the positive pixels: getStripe.getQuantile_original ------------------
+ * (getStripe.py:160-176: `np.quantile(mat[mat > 0], quantile)` over the whole chromosome.)
+ * The host streams the chromosome in row strips (`stp_select_append`; non-positive and NaN entries
+ * are ignored, exactly like `mat[mat > 0]`), so the dense chromosome (12 GB for chr1 at 5 kb) never
+ * exists; `stp_select_ranks` returns the exact order statistics a[rank] (0-based, ascending) by
+ * radix select; numpy's interpolation between them is applied by the caller (stripenn_amd/getStripe.py). */
+typedef struct stp_select stp_select;
+int stp_select_create(stp_ctx* ctx, stp_select** out);
+int stp_select_append(stp_ctx* ctx, stp_select* sel, const double* values_host, int64_t n);
+int stp_select_count(stp_ctx* ctx, stp_select* sel, int64_t* n_positive);
+int stp_select_ranks(stp_ctx* ctx, stp_select* sel, const int64_t* ranks, int32_t nranks, double* out);
+void stp_select_free(stp_ctx* ctx, stp_select* sel);
+
 /* ---- statistics / profiling ---------------------------------------------------------------
  * When profiling is on, every kernel launch is bracketed by HIP events on the ctx stream. */
 typedef struct {

@@ -40,6 +40,12 @@ class HipBackend:
         L.stp_pvalue.argtypes = [vp, vp, vp, C.c_int32, vp, C.c_int64, vp]
         L.stp_stripiness.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]
         L.stp_stripe_mean.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
+        L.stp_select_create.argtypes = [vp, C.POINTER(vp)]
+        L.stp_select_append.argtypes = [vp, vp, vp, C.c_int64]
+        L.stp_select_count.argtypes = [vp, vp, C.POINTER(C.c_int64)]
+        L.stp_select_ranks.argtypes = [vp, vp, vp, C.c_int32, vp]
+        L.stp_select_free.argtypes = [vp, vp]
+        L.stp_select_free.restype = None
         self._bg = None
         self._bg_key = None
 
@@ -116,6 +122,32 @@ class HipBackend:
         if n:
             self.ctx._chk(self.ctx.L.stp_stripe_mean(self.ctx.h, band.h, _p(rects), n, _p(m), _p(s)))
         return m, s
+
+    # ---- order statistics of positive pixels (getQuantile_original)
+    def select_open(self):
+        h = C.c_void_p()
+        self.ctx._chk(self.ctx.L.stp_select_create(self.ctx.h, C.byref(h)))
+        return h
+
+    def select_append(self, sel, values):
+        values = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        if values.size:
+            self.ctx._chk(self.ctx.L.stp_select_append(self.ctx.h, sel, _p(values), values.size))
+
+    def select_count(self, sel):
+        n = C.c_int64()
+        self.ctx._chk(self.ctx.L.stp_select_count(self.ctx.h, sel, C.byref(n)))
+        return int(n.value)
+
+    def select_ranks(self, sel, ranks):
+        ranks = np.ascontiguousarray(ranks, dtype=np.int64)
+        out = np.zeros(len(ranks), np.float64)
+        if len(ranks):
+            self.ctx._chk(self.ctx.L.stp_select_ranks(self.ctx.h, sel, _p(ranks), len(ranks), _p(out)))
+        return out
+
+    def select_close(self, sel):
+        self.ctx.L.stp_select_free(self.ctx.h, sel)
 
     def close(self):
         self.clear_background()

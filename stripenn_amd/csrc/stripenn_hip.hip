@@ -10,6 +10,7 @@
 #include "../../include/stripenn_hip.h"
 #include "stp_phases.h"
 #include "stp_score.h"
+#include "stp_select.h"
 
 // ============================================================================================
 // device kernels
@@ -1234,6 +1235,109 @@ int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rc, int6
     HIPCHK(hipMemcpyAsync(out_mean, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(out_sum, o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return STP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// order statistics of the positive pixels (getQuantile_original)
+struct stp_select {
+    std::vector<std::pair<double*, long long>> chunks;   // device buffers
+    long long npos = -1;                                 // cached count of positive values
+    stp_sel_state* state = nullptr;
+};
+
+int stp_select_create(stp_ctx* ctx, stp_select** out)
+{
+    if (!ctx || !out) return STP_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    stp_select* s = new (std::nothrow) stp_select();
+    if (!s) return STP_E_NOMEM;
+    if (hipMalloc((void**)&s->state, sizeof(stp_sel_state)) != hipSuccess) { delete s; return set_err(ctx, STP_E_NOMEM, "hipMalloc(select state)"); }
+    *out = s;
+    return STP_OK;
+}
+
+void stp_select_free(stp_ctx* ctx, stp_select* s)
+{
+    if (!s) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    for (auto& c : s->chunks) (void)hipFree(c.first);
+    if (s->state) (void)hipFree(s->state);
+    delete s;
+}
+
+int stp_select_append(stp_ctx* ctx, stp_select* s, const double* values_host, int64_t n)
+{
+    if (!ctx || !s || n < 0 || (n > 0 && !values_host)) return STP_E_ARG;
+    if (n == 0) return STP_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    double* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)n * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d, values_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(d); return set_err(ctx, STP_E_HIP, "select append: upload failed"); }
+    s->chunks.push_back(std::make_pair(d, (long long)n));
+    s->npos = -1;
+    return STP_OK;
+}
+
+static unsigned sel_grid(long long n)
+{
+    long long g = (n + 256 * 8 - 1) / (256 * 8);
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (unsigned)g;
+}
+
+int stp_select_count(stp_ctx* ctx, stp_select* s, int64_t* n_positive)
+{
+    if (!ctx || !s || !n_positive) return STP_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (s->npos < 0) {
+        HIPCHK(hipMemsetAsync(s->state, 0, sizeof(stp_sel_state), ctx->stream));
+        for (auto& c : s->chunks) {
+            prof_scope ps(ctx, "select_count", 8.0 * c.second);
+            hipLaunchKernelGGL(k_sel_count, dim3(sel_grid(c.second)), dim3(256), 0, ctx->stream, (const double*)c.first, c.second,
+                               &s->state->k);
+        }
+        HIPCHK(hipGetLastError());
+        unsigned long long k = 0;
+        HIPCHK(hipMemcpyAsync(&k, &s->state->k, sizeof(k), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        s->npos = (long long)k;
+    }
+    *n_positive = s->npos;
+    return STP_OK;
+}
+
+int stp_select_ranks(stp_ctx* ctx, stp_select* s, const int64_t* ranks, int32_t nranks, double* out)
+{
+    if (!ctx || !s || !ranks || !out || nranks < 0) return STP_E_ARG;
+    int64_t np = 0;
+    int rc = stp_select_count(ctx, s, &np);
+    if (rc) return rc;
+    static const int shifts[5] = {51, 38, 25, 12, 0};
+    static const int widths[5] = {13, 13, 13, 13, 12};
+    for (int r = 0; r < nranks; r++) {
+        if (ranks[r] < 0 || ranks[r] >= np) return set_err(ctx, STP_E_ARG, "rank outside [0, n_positive)");
+        unsigned long long init[2] = {0ull, (unsigned long long)ranks[r]};
+        HIPCHK(hipMemsetAsync(s->state, 0, sizeof(stp_sel_state), ctx->stream));
+        HIPCHK(hipMemcpyAsync(s->state, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        for (int pass = 0; pass < 5; pass++) {
+            for (auto& c : s->chunks) {
+                prof_scope ps(ctx, "select_hist", 8.0 * c.second);
+                hipLaunchKernelGGL(k_sel_hist, dim3(sel_grid(c.second)), dim3(256), 0, ctx->stream, (const double*)c.first,
+                                   c.second, shifts[pass], widths[pass], pass, s->state);
+            }
+            hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(1024), 0, ctx->stream, s->state, shifts[pass]);
+        }
+        HIPCHK(hipGetLastError());
+        unsigned long long key = 0;
+        HIPCHK(hipMemcpyAsync(&key, &s->state->prefix, sizeof(key), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        memcpy(&out[r], &key, sizeof(double));
+    }
     return STP_OK;
 }
 

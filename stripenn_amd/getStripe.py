@@ -37,6 +37,36 @@ def _extent(start, end, resol):
     return start // resol, -(-end // resol)
 
 
+def quantile_linear(order_stats, n, q):
+    """numpy.quantile(a, q) (method 'linear', numpy/lib/function_base.py `_quantile`) given a callable
+    that returns exact order statistics a_sorted[ranks]: virtual index (n-1)*q, neighbours floor / +1
+    (both the last element once the index reaches n-1, the first below 0), gamma = index - floor, and
+    numpy's `_lerp` (a + (b-a)*t, replaced by b - (b-a)*(1-t) where t >= 0.5)."""
+    q = np.asanyarray(q, dtype=np.float64)
+    scalar = (q.ndim == 0)
+    qa = np.atleast_1d(q)
+    if n <= 0:
+        raise IndexError('index -1 is out of bounds for axis 0 with size 0')      # np.quantile of an empty array
+    virtual = (n - 1) * qa
+    prev = np.floor(virtual).astype(np.intp)
+    nxt = prev + 1
+    above = virtual >= n - 1
+    prev[above] = -1
+    nxt[above] = -1
+    below = virtual < 0
+    prev[below] = 0
+    nxt[below] = 0
+    gamma = np.asanyarray(virtual - prev)
+    ranks = np.unique(np.concatenate((prev % n, nxt % n)))
+    vals = dict(zip(ranks.tolist(), np.asarray(order_stats(ranks), dtype=np.float64).tolist()))
+    a = np.array([vals[int(i % n)] for i in prev], dtype=np.float64)
+    b = np.array([vals[int(i % n)] for i in nxt], dtype=np.float64)
+    diff = np.subtract(b, a)
+    lerp = np.asanyarray(np.add(a, diff * gamma))
+    np.subtract(b, diff * (1 - gamma), out=lerp, where=gamma >= 0.5)
+    return lerp[0] if scalar else lerp
+
+
 class getStripe:
     def __init__(self, unbalLib, resol, minH, maxW, canny, all_chromnames, chromnames, all_chromsizes, chromsizes, core,
                  bfilter, seed, backend=None, device=0, halfwidth=HALFWIDTH):
@@ -107,15 +137,29 @@ class getStripe:
 
     # ------------------------------------------------------------------ quantiles (host)
     def getQuantile_original(self, coolinfo, ChrList, quantile):
-        """getStripe.py:160-176 -- stays on the host in this milestone."""
+        """getStripe.py:160-176: `np.quantile(mat[mat > 0], quantile)` over the whole chromosome.
+        The chromosome is streamed to the device in row strips (the reference materialises it densely:
+        12 GB for chr1 at 5 kb); the exact order statistics come from a radix select on the GPU
+        (stp_select_*), numpy's 'linear' interpolation between them is applied here."""
         res = {}
         chrom_names = list(coolinfo.chromsizes.keys())
         chridx = sorted(c for c in range(len(chrom_names)) if chrom_names[c] in ChrList)
         for ci in chridx:
             CHROM = chrom_names[ci]
-            mat = self.unbalLib.fetch(CHROM)
-            res[CHROM] = np.quantile(mat[mat > 0], quantile)
-            del mat
+            nb = self._nbins(CHROM)
+            size = int(self.chromnames2sizes[str(CHROM)])
+            sel = self.backend.select_open()
+            try:
+                strip = max(1, int(16e6 // max(nb, 1)))                 # <= 128 MB of float64 per fetch
+                for r0 in range(0, nb, strip):
+                    r1 = min(r0 + strip, nb)
+                    rows = '%s:%d-%d' % (CHROM, r0 * self.resol + 1, min(r1 * self.resol, size))
+                    blk = np.asarray(self.unbalLib.fetch(rows, str(CHROM)), dtype=np.float64)
+                    self.backend.select_append(sel, blk[blk > 0])
+                n = self.backend.select_count(sel)
+                res[CHROM] = quantile_linear(lambda ranks: self.backend.select_ranks(sel, ranks), n, quantile)
+            finally:
+                self.backend.select_close(sel)
         return res
 
     def getQuantile_slow(self, coolinfo, ChrList, quantile):

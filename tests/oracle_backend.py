@@ -112,3 +112,20 @@ class OracleBackend:
 
     def close(self):
         pass
+
+    # order statistics of positive pixels: numpy partition as the checker
+    def select_open(self):
+        return []
+
+    def select_append(self, sel, values):
+        sel.append(np.asarray(values, dtype=np.float64).ravel())
+
+    def select_count(self, sel):
+        return int(sum(len(v) for v in sel))
+
+    def select_ranks(self, sel, ranks):
+        a = np.sort(np.concatenate(sel)) if sel else np.zeros(0)
+        return a[np.asarray(ranks, dtype=np.int64)]
+
+    def select_close(self, sel):
+        sel.clear()

@@ -42,3 +42,15 @@ def test_remove_redundant_semantics():
     import pytest
     with pytest.raises(ValueError):
         obj.RemoveRedundant(df, 'other')
+
+
+def test_quantile_linear_equals_numpy():
+    """Host interpolation around exact order statistics == np.quantile, bit for bit."""
+    from stripenn_amd.getStripe import quantile_linear
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 3, 10, 999, 100003):
+        a = rng.random(n) * rng.integers(1, 1000, n)
+        srt = np.sort(a)
+        for q in ([0.95, 0.96, 0.97, 0.98, 0.99], [0.0, 1.0, 0.5], 0.25, [1e-9, 1 - 1e-12, 0.3333333333333333]):
+            got = quantile_linear(lambda r: srt[np.asarray(r)], n, q)
+            assert np.array_equal(np.asarray(got), np.asarray(np.quantile(a, q))), (n, q)

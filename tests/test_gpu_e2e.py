@@ -43,3 +43,27 @@ def test_score_pipeline_on_gpu():
 
 def test_background_with_numcores_gt1_on_gpu():
     E.run_par_background(_HipWithWeights)
+
+
+def test_gpu_quantile_matches_numpy():
+    """stp_select_*: exact order statistics of the positive entries over several appended chunks."""
+    from stripenn_amd.backend import HipBackend
+    from stripenn_amd.getStripe import quantile_linear
+    hb = HipBackend(0)
+    rng = np.random.default_rng(5)
+    chunks = [rng.random(n) * rng.integers(0, 50, n) * (rng.random(n) > 0.3) for n in (1000003, 17, 250000)]
+    chunks[1][:3] = [np.nan, -1.0, 0.0]
+    allv = np.concatenate(chunks)
+    pos = allv[allv > 0]
+    sel = hb.select_open()
+    for c in chunks:
+        hb.select_append(sel, c)
+    assert hb.select_count(sel) == len(pos)
+    q = [0.95, 0.96, 0.97, 0.98, 0.99, 0.0, 1.0, 0.5]
+    got = quantile_linear(lambda r: hb.select_ranks(sel, r), len(pos), q)
+    assert np.array_equal(got, np.quantile(pos, q))
+    srt = np.sort(pos)
+    ranks = np.array([0, 1, len(pos) // 2, len(pos) - 1])
+    assert np.array_equal(hb.select_ranks(sel, ranks), srt[ranks])
+    hb.select_close(sel)
+    hb.close()
