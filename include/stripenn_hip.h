@@ -199,6 +199,22 @@ int stp_select_count(stp_ctx* ctx, stp_select* sel, int64_t* n_positive);
 int stp_select_ranks(stp_ctx* ctx, stp_select* sel, const int64_t* ranks, int32_t nranks, double* out);
 void stp_select_free(stp_ctx* ctx, stp_select* sel);
 
+/* ---- redundancy filter: getStripe.RemoveRedundant (getStripe.py:1116-1196) ---------------------
+ * For every pair of rows of one chromosome whose frame numbers differ by at most one (the reference
+ * groups rows with num in {n, n+1}, :1119-1121), with A the row that comes first in the table:
+ *   s_x = |[max(x0), min(x1)]| / min(A.x1 - A.x0, B.x1 - B.x0),  s_y likewise;  if both > 0.2:
+ *   by 0 'size'  : drop A if A.h/A.w <= B.h/B.w else B          (:1147-1150)
+ *   by 1 'score' : drop A if A.key   <= B.key   else B          (:1152-1155)
+ *   by 2 'pvalue': drop A if A.key   >  B.key   else B          (:1157-1160)
+ * Deletions are only collected (a dropped row still knocks out others), so the pair tests are
+ * independent.  order[] = row indices sorted by (chromosome, num) (stable); b0/b1/b2[i] = start of
+ * row i's (chr, num) bucket, its end = start of the (chr, num+1) bucket, and that bucket's end, as
+ * positions in order[] (b1 == b2 when the next frame number is absent).  keep[i] = 0/1. */
+int stp_remove_redundant(stp_ctx* ctx, int64_t n, const int64_t* pos1, const int64_t* pos2, const int64_t* pos3,
+                         const int64_t* pos4, const int32_t* h, const int32_t* w, const double* key, int32_t by,
+                         const int32_t* order, const int32_t* b0, const int32_t* b1, const int32_t* b2,
+                         uint8_t* keep);
+
 /* ---- statistics / profiling ---------------------------------------------------------------
  * When profiling is on, every kernel launch is bracketed by HIP events on the ctx stream. */
 typedef struct {

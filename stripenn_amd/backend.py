@@ -40,6 +40,7 @@ class HipBackend:
         L.stp_pvalue.argtypes = [vp, vp, vp, C.c_int32, vp, C.c_int64, vp]
         L.stp_stripiness.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]
         L.stp_stripe_mean.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
+        L.stp_remove_redundant.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
         L.stp_select_create.argtypes = [vp, C.POINTER(vp)]
         L.stp_select_append.argtypes = [vp, vp, vp, C.c_int64]
         L.stp_select_count.argtypes = [vp, vp, C.POINTER(C.c_int64)]
@@ -122,6 +123,20 @@ class HipBackend:
         if n:
             self.ctx._chk(self.ctx.L.stp_stripe_mean(self.ctx.h, band.h, _p(rects), n, _p(m), _p(s)))
         return m, s
+
+    # ---- redundancy filter
+    def remove_redundant(self, p1, p2, p3, p4, h, w, key, by, order, b0, b1, b2):
+        c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+        p1, p2, p3, p4 = (c(a, np.int64) for a in (p1, p2, p3, p4))
+        h, w, order, b0, b1, b2 = (c(a, np.int32) for a in (h, w, order, b0, b1, b2))
+        n = len(p1)
+        keep = np.ones(n, np.uint8)
+        if n:
+            k = None if key is None else c(key, np.float64)
+            self.ctx._chk(self.ctx.L.stp_remove_redundant(self.ctx.h, n, _p(p1), _p(p2), _p(p3), _p(p4), _p(h), _p(w),
+                                                           None if k is None else _p(k), int(by), _p(order), _p(b0), _p(b1),
+                                                           _p(b2), _p(keep)))
+        return keep.astype(bool)
 
     # ---- order statistics of positive pixels (getQuantile_original)
     def select_open(self):

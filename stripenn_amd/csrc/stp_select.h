@@ -69,3 +69,39 @@ __global__ __launch_bounds__(1024) void k_sel_pick(stp_sel_state* __restrict__ s
     __syncthreads();
     for (int b = 0; b < 8; b++) st->hist[tid * 8 + b] = 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// getStripe.RemoveRedundant (getStripe.py:1116-1196): one lane per row, pairs = rows of its own frame
+// bucket that come later in the table plus every row of the next frame's bucket.
+__global__ __launch_bounds__(256) void k_remove_redundant(long long n, const long long* __restrict__ p1,
+                                                          const long long* __restrict__ p2, const long long* __restrict__ p3,
+                                                          const long long* __restrict__ p4, const int* __restrict__ h,
+                                                          const int* __restrict__ w, const double* __restrict__ key, int by,
+                                                          const int* __restrict__ order, const int* __restrict__ b0,
+                                                          const int* __restrict__ b1, const int* __restrict__ b2,
+                                                          unsigned int* __restrict__ drop)
+{
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= n) return;
+    const long long ax0 = p1[i], ax1 = p2[i], ay0 = p3[i], ay1 = p4[i];
+    for (int q = b0[i]; q < b2[i]; q++) {
+        const int j = order[q];
+        if (q < b1[i] && j <= i) continue;            // own bucket: each unordered pair once
+        const long long bx0 = p1[j], bx1 = p2[j], by0 = p3[j], by1 = p4[j];
+        long long ox = (ax1 < bx1 ? ax1 : bx1) - (ax0 > bx0 ? ax0 : bx0) + 1;
+        long long oy = (ay1 < by1 ? ay1 : by1) - (ay0 > by0 ? ay0 : by0) + 1;
+        if (ox < 0) ox = 0;
+        if (oy < 0) oy = 0;
+        const long long dx = (ax1 - ax0 < bx1 - bx0) ? ax1 - ax0 : bx1 - bx0;
+        const long long dy = (ay1 - ay0 < by1 - by0) ? ay1 - ay0 : by1 - by0;
+        const double sx = (double)ox / (double)dx, sy = (double)oy / (double)dy;   // python int / int
+        if (sx > 0.2 && sy > 0.2) {
+            const long long a = (i < j) ? i : j, b = (i < j) ? j : i;              // A comes first in the table
+            bool dropA;
+            if (by == 0) dropA = ((double)h[a] / (double)w[a]) <= ((double)h[b] / (double)w[b]);
+            else if (by == 1) dropA = key[a] <= key[b];
+            else dropA = key[a] > key[b];
+            drop[dropA ? a : b] = 1u;
+        }
+    }
+}

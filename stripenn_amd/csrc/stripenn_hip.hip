@@ -1341,6 +1341,47 @@ int stp_select_ranks(stp_ctx* ctx, stp_select* s, const int64_t* ranks, int32_t 
     return STP_OK;
 }
 
+
+int stp_remove_redundant(stp_ctx* ctx, int64_t n, const int64_t* pos1, const int64_t* pos2, const int64_t* pos3,
+                         const int64_t* pos4, const int32_t* h, const int32_t* w, const double* key, int32_t by,
+                         const int32_t* order, const int32_t* b0, const int32_t* b1, const int32_t* b2, uint8_t* keep)
+{
+    if (!ctx || n < 0 || by < 0 || by > 2) return STP_E_ARG;
+    if (n == 0) return STP_OK;
+    if (!pos1 || !pos2 || !pos3 || !pos4 || !h || !w || !order || !b0 || !b1 || !b2 || !keep || (by != 0 && !key)) return STP_E_ARG;
+    for (int64_t i = 0; i < n; i++) {
+        if (b0[i] < 0 || b0[i] > b1[i] || b1[i] > b2[i] || b2[i] > n || order[i] < 0 || order[i] >= n)
+            return set_err(ctx, STP_E_ARG, "remove_redundant: bad bucket table");
+        if (pos2[i] == pos1[i] || pos4[i] == pos3[i]) return set_err(ctx, STP_E_ARG, "remove_redundant: zero-length stripe (the reference divides by zero)");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    dev_buf bP, bI, bK, bD;
+    HIPCHK(bP.alloc((size_t)n * 4 * sizeof(long long)));
+    HIPCHK(bI.alloc((size_t)n * 6 * sizeof(int)));
+    HIPCHK(bK.alloc((size_t)n * sizeof(double)));
+    HIPCHK(bD.alloc((size_t)n * sizeof(unsigned int)));
+    long long* dp = (long long*)bP.p;
+    int* di = (int*)bI.p;
+    const int64_t* ps[4] = {pos1, pos2, pos3, pos4};
+    for (int k = 0; k < 4; k++) HIPCHK(hipMemcpyAsync(dp + k * n, ps[k], (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    const int32_t* is[6] = {h, w, order, b0, b1, b2};
+    for (int k = 0; k < 6; k++) HIPCHK(hipMemcpyAsync(di + k * n, is[k], (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (key) HIPCHK(hipMemcpyAsync(bK.p, key, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(bD.p, 0, (size_t)n * sizeof(unsigned int), ctx->stream));
+    {
+        prof_scope ps2(ctx, "remove_redundant", 48.0 * n);
+        hipLaunchKernelGGL(k_remove_redundant, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, dp, dp + n,
+                           dp + 2 * n, dp + 3 * n, di, di + n, (const double*)bK.p, by, di + 2 * n, di + 3 * n, di + 4 * n,
+                           di + 5 * n, (unsigned int*)bD.p);
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<unsigned int> hd((size_t)n);
+    HIPCHK(hipMemcpyAsync(hd.data(), bD.p, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < n; i++) keep[i] = hd[i] ? 0 : 1;
+    return STP_OK;
+}
+
 int stp_set_profiling(stp_ctx* ctx, int on)
 {
     if (!ctx) return STP_E_ARG;

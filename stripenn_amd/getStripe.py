@@ -569,87 +569,83 @@ class getStripe:
             recs = self._search(chrom, chridx, MP[chrom])
             recs = recs[recs['level'] == index]
             fr, starts, ends = self._chrom_frames(chrom, chridx)
-            chromsize = int(self.chromsizes[chridx])
-            for f in np.unique(recs['frame']):
-                fr_recs = recs[recs['frame'] == f]
-                tables.append(self._frame_table(chrom, chromsize, int(f), starts[f], ends[f], fr, fr_recs, perc))
+            tables.append(self._chrom_table(chrom, int(self.chromsizes[chridx]), starts, ends, fr, recs, perc))
         result = pd.concat(tables)
-        res = self.RemoveRedundant(result, 'size')
+        # StripeSearch ends with RemoveRedundant over the rows of ONE frame (getStripe.py:1112): same filter,
+        # all frames in one device call, pairs restricted to equal frame numbers
+        result = self._filter_redundant(result, 'size', same_frame_only=True)
+        res = self.RemoveRedundant(result, 'size')                       # :852
         res = res.reset_index(drop=True)
         p = self.pvalue(bgleft_up, bgright_up, bgleft_down, bgright_down, res)
         res = res.assign(pvalue=pd.Series(p))
         return res
 
-    def _frame_table(self, chrom, chromsize, f, start, end, fr, recs, perc):
-        """Rows of one frame as StripeSearch builds them (getStripe.py:1081-1112)."""
-        S = int(fr.S[f])
-        nz = fr.nz[f, :S].astype(np.int64)
-        framesize = end - start + 1
-        start_full = (start + np.arange(framesize, dtype=np.int64)) * self.resol + 1
-        end_full = start_full + self.resol - 1
-        if end_full[-1] >= chromsize:
-            end_full[-1] = chromsize
-        start_array = start_full[nz]
-        end_array = end_full[nz]
+    def _chrom_table(self, chrom, chromsize, starts, ends, fr, recs, perc):
+        """Rows of all frames of one chromosome as StripeSearch builds them (getStripe.py:1081-1110),
+        vectorised: bp coordinates through the compaction map, frame order then record order."""
+        n = len(recs)
+        f = recs['frame'].astype(np.int64)
+        st = np.asarray(starts, dtype=np.int64)[f]
+        en = np.asarray(ends, dtype=np.int64)[f]
         x = recs['x'].astype(np.int64)
         y = recs['y'].astype(np.int64)
         w = recs['w'].astype(np.int64)
         h = recs['h'].astype(np.int64)
+        nz = fr.nz.astype(np.int64)
+
+        def start_bp(idx):
+            return (st + nz[f, idx]) * self.resol + 1
+
+        def end_bp(idx):
+            b = st + nz[f, idx]
+            e = b * self.resol + self.resol
+            return np.where((b == en) & (e >= chromsize), chromsize, e)     # only a frame's last bin is clipped (:804-806)
+        pos1, pos2 = start_bp(x), end_bp(x + w - 1)
+        pos3, pos4 = start_bp(y), end_bp(y + h - 1)
         total = recs['total']
-        pos1 = start_array[x]
-        pos2 = end_array[x + w - 1]
-        pos3 = start_array[y]
-        pos4 = end_array[y + h - 1]
-        n = len(recs)
-        df = pd.DataFrame({'chr': [chrom] * n, 'pos1': pos1, 'pos2': pos2, 'chr2': [chrom] * n, 'pos3': pos3, 'pos4': pos4,
-                           'length': pos4 - pos3 + 1, 'width': pos2 - pos1 + 1, 'total': total, 'Mean': total / h / w,
-                           'maxpixel': [str(perc * 100) + '%'] * n, 'num': [f] * n, 'start': [start] * n,
-                           'end': [end] * n, 'x': x, 'y': y, 'h': h, 'w': w,
-                           'medpixel': [float(fr.medpixel[f])] * n})
-        return self.RemoveRedundant(df, 'size')
+        return pd.DataFrame({'chr': [chrom] * n, 'pos1': pos1, 'pos2': pos2, 'chr2': [chrom] * n, 'pos3': pos3, 'pos4': pos4,
+                             'length': pos4 - pos3 + 1, 'width': pos2 - pos1 + 1, 'total': total, 'Mean': total / h / w,
+                             'maxpixel': [str(perc * 100) + '%'] * n, 'num': f, 'start': st, 'end': en, 'x': x, 'y': y,
+                             'h': h, 'w': w, 'medpixel': fr.medpixel[f].astype(np.float64)})
 
     def StripeSearch(self, submat, num, start, end, M, perc, chr, framesize, start_array, end_array):
         """Not supported as a dense-matrix call: frames are gathered from the resident band on the
         device (use extract).  Kept so that callers get a clear error rather than a silent CPU path."""
         raise NotImplementedError('stripenn_amd runs StripeSearch on the device from the resident band; use extract()')
 
-    # ------------------------------------------------------------------ redundancy filter (host)
+    # ------------------------------------------------------------------ redundancy filter
     def RemoveRedundant(self, df, by):
-        """getStripe.py:1116-1196.  Host-side integer logic (SURVEY 8a-16 keeps it on the CPU)."""
+        """getStripe.py:1116-1196 (K: k_remove_redundant): pairs of rows of one chromosome whose frame
+        numbers differ by at most one; the bucket table is built here, the pair tests run on the device."""
+        return self._filter_redundant(df, by, same_frame_only=False)
+
+    def _filter_redundant(self, df, by, same_frame_only):
         if by != 'size' and by != 'score' and by != 'pvalue':
             raise ValueError('"by" should be one of "size", "pvalue" and "score"')
-        row_size = df.shape[0]
-        if row_size == 0:
+        n = df.shape[0]
+        if n == 0:
             return df
-        keep = np.ones(row_size, dtype=bool)
         chrs = np.asarray(df['chr'])
-        p1 = df['pos1'].tolist(); p2 = df['pos2'].tolist(); p3 = df['pos3'].tolist(); p4 = df['pos4'].tolist()
-        hh = df['h'].tolist(); ww = df['w'].tolist()
-        nums = np.asarray(df['num'])
+        codes = {}
+        code = np.array([codes.setdefault(c, len(codes)) for c in chrs.tolist()], dtype=np.int64)
+        num = np.asarray(df['num'], dtype=np.int64)
+        span = int(num.max() - num.min()) + 3
+        key = code * span + (num - num.min())
+        order = np.argsort(key, kind='stable').astype(np.int32)
+        skey = key[order]
+        b0 = np.searchsorted(skey, key, 'left').astype(np.int32)
+        b1 = np.searchsorted(skey, key, 'right').astype(np.int32)
+        b2 = b1 if same_frame_only else np.searchsorted(skey, key + 1, 'right').astype(np.int32)
+        p = [np.asarray(df[c], dtype=np.int64) for c in ('pos1', 'pos2', 'pos3', 'pos4')]
+        if np.any(p[1] == p[0]) or np.any(p[3] == p[2]):
+            raise ZeroDivisionError('division by zero')                  # as the reference (:1142-1143)
+        hh = np.asarray(df['h'], dtype=np.int32)
+        ww = np.asarray(df['w'], dtype=np.int32)
+        mode = {'size': 0, 'score': 1, 'pvalue': 2}[by]
+        k = None
         if by == 'score':
-            key = df['Stripiness'].tolist()
+            k = np.asarray(df['Stripiness'], dtype=np.float64)
         if by == 'pvalue':
-            key = df['pvalue'].tolist()
-        for c in list(set(chrs.tolist())):
-            c_idx = np.where(chrs == c)[0]
-            sub_num = nums[c_idx]
-            for n in sorted(set(sub_num.tolist())):
-                members = c_idx[np.where((sub_num == n) | (sub_num == n + 1))[0]]
-                L = len(members)
-                for a in range(L - 1):
-                    ii = int(members[a])
-                    for b in range(a + 1, L):
-                        jj = int(members[b])
-                        ox = max(0, min(p2[ii], p2[jj]) - max(p1[ii], p1[jj]) + 1)
-                        oy = max(0, min(p4[ii], p4[jj]) - max(p3[ii], p3[jj]) + 1)
-                        s_x = ox / min(p2[ii] - p1[ii], p2[jj] - p1[jj])
-                        s_y = oy / min(p4[ii] - p3[ii], p4[jj] - p3[jj])
-                        if s_x > 0.2 and s_y > 0.2:
-                            if by == 'size':
-                                drop = ii if hh[ii] / ww[ii] <= hh[jj] / ww[jj] else jj
-                            elif by == 'score':
-                                drop = ii if key[ii] <= key[jj] else jj
-                            else:
-                                drop = ii if key[ii] > key[jj] else jj
-                            keep[drop] = False
+            k = np.asarray(df['pvalue'], dtype=np.float64)
+        keep = self.backend.remove_redundant(p[0], p[1], p[2], p[3], hh, ww, k, mode, order, b0, b1, b2)
         return df.iloc[np.where(keep)[0]]

@@ -129,3 +129,34 @@ class OracleBackend:
 
     def select_close(self, sel):
         sel.clear()
+
+    # redundancy filter: the reference's pair loops (getStripe.py:1116-1161) over the bucket table
+    def remove_redundant(self, p1, p2, p3, p4, h, w, key, by, order, b0, b1, b2):
+        n = len(p1)
+        keep = np.ones(n, dtype=bool)
+        p1, p2, p3, p4 = (np.asarray(a).tolist() for a in (p1, p2, p3, p4))
+        h = np.asarray(h).tolist(); w = np.asarray(w).tolist()
+        key = None if key is None else np.asarray(key).tolist()
+        seen = set()
+        for i in range(n):
+            for q in range(int(b0[i]), int(b2[i])):
+                j = int(order[q])
+                if j == i:
+                    continue
+                a, b = (i, j) if i < j else (j, i)
+                if (a, b) in seen:
+                    continue
+                seen.add((a, b))
+                ox = max(0, min(p2[a], p2[b]) - max(p1[a], p1[b]) + 1)
+                oy = max(0, min(p4[a], p4[b]) - max(p3[a], p3[b]) + 1)
+                s_x = ox / min(p2[a] - p1[a], p2[b] - p1[b])
+                s_y = oy / min(p4[a] - p3[a], p4[b] - p3[b])
+                if s_x > 0.2 and s_y > 0.2:
+                    if by == 0:
+                        drop = a if h[a] / w[a] <= h[b] / w[b] else b
+                    elif by == 1:
+                        drop = a if key[a] <= key[b] else b
+                    else:
+                        drop = a if key[a] > key[b] else b
+                    keep[drop] = False
+        return keep

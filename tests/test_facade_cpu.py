@@ -31,6 +31,7 @@ def test_remove_redundant_semantics():
     import pandas as pd
     from stripenn_amd import getStripe as GS
     obj = GS.getStripe.__new__(GS.getStripe)
+    obj.backend = OracleBackend()
     df = pd.DataFrame({'chr': ['a'] * 4, 'pos1': [1, 1, 500001, 1], 'pos2': [20000, 25000, 520000, 20000],
                        'pos3': [1, 1, 500001, 1], 'pos4': [400000, 300000, 900000, 400000], 'h': [80, 60, 80, 80],
                        'w': [4, 5, 4, 4], 'num': [0, 0, 2, 1], 'pvalue': [0.05, 0.01, 0.2, 0.05]})

@@ -67,3 +67,27 @@ def test_gpu_quantile_matches_numpy():
     assert np.array_equal(hb.select_ranks(sel, ranks), srt[ranks])
     hb.select_close(sel)
     hb.close()
+
+
+def test_gpu_remove_redundant_matches_reference_loops():
+    """k_remove_redundant vs the reference's pair loops on random overlapping stripe tables."""
+    import pandas as pd
+    from stripenn_amd import getStripe as GS
+    from stripenn_amd.backend import HipBackend
+    from oracle_backend import OracleBackend
+    rng = np.random.default_rng(9)
+    n = 3000
+    num = np.sort(rng.integers(0, 60, n))
+    x0 = num * 200 * 5000 + rng.integers(0, 300, n) * 5000 + 1
+    wbin = rng.integers(2, 9, n); hbin = rng.integers(11, 200, n)
+    df = pd.DataFrame({'chr': np.where(rng.random(n) < 0.5, 'chrA', 'chrB'), 'pos1': x0, 'pos2': x0 + wbin * 5000 - 1,
+                       'pos3': x0, 'pos4': x0 + hbin * 5000 - 1, 'h': hbin, 'w': wbin, 'num': num,
+                       'pvalue': np.round(rng.random(n), 2), 'Stripiness': np.round(rng.random(n), 1)})
+    g = GS.getStripe.__new__(GS.getStripe); g.backend = HipBackend(0)
+    o = GS.getStripe.__new__(GS.getStripe); o.backend = OracleBackend()
+    for by in ('size', 'pvalue', 'score'):
+        a = g.RemoveRedundant(df, by); b = o.RemoveRedundant(df, by)
+        assert a.index.tolist() == b.index.tolist() and 0 < len(a) < n, by
+        a = g._filter_redundant(df, by, True); b = o._filter_redundant(df, by, True)
+        assert a.index.tolist() == b.index.tolist()
+    g.backend.close()

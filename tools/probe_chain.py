@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 from stripenn_amd import synth, hip
 nb = 19642
 ch = synth.SynthChrom(nb, 16); band_h = ch.band(512)

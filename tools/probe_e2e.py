@@ -1,5 +1,5 @@
 import sys, time, os, io, contextlib
-sys.path.insert(0, '.')
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
 import numpy as np
 from stripenn_amd import stripenn, getStripe
 spec = 'synth:' + ','.join('chr%d=%d' % (i + 1, (6000 - 400 * i) * 5000 - 1234) for i in range(6)) + ';resol=5000;seed=7'
