@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STP_ABI_VERSION 1
+#define STP_ABI_VERSION 2
 #define STP_FRAME_MAX 400   /* frames are at most 400 x 400 (getStripe.py:794-799) */
 #define STP_NDIAG 400       /* diagonals kept for expected values / background (getStripe.py:219,305) */
 
@@ -176,8 +176,10 @@ typedef struct {
     int32_t mcol0[3], mcol1[3];   /* masked relative column range [lo, hi] per block; lo > hi: none */
     int32_t mrow0, mrow1;         /* masked relative row range                               */
 } stp_score_stripe;
+/* out_status (may be NULL): 1 when an all-NaN column maps to a row index outside the stripe -- the
+ * reference's np.delete raises IndexError there (getStripe.py:735); the facade re-raises it. */
 int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, const stp_score_stripe* stripes,
-                   int64_t n, double* out_g, double* out_oe_mean, double* out_oe_total);
+                   int64_t n, double* out_g, double* out_oe_mean, double* out_oe_total, int32_t* out_status);
 
 /* ---- observed mean / sum: getStripe.getMean (getStripe.py:501-534) -------------------------- */
 typedef struct {

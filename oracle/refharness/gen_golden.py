@@ -223,3 +223,6 @@ if __name__ == '__main__':
     if 'e2e' in which:
         from gen_golden_e2e import e2e_goldens
         e2e_goldens()
+    if 'e2e1kb' in which:
+        from gen_golden_e2e import e2e_goldens
+        e2e_goldens(which=('1kb',))

@@ -54,14 +54,16 @@ def df_to_store(store, prefix, df, cols_int, cols_float, cols_str):
         store[prefix + c] = np.array([str(v) for v in df[c]], dtype='U16')
 
 
-def run(core, tag):
-    resol = 5000
-    names, sizes, sel = synth.make_genome(E2E_SIZES, resol, seed0=E2E_SEED0, names=E2E_NAMES)
+def run(core, tag, resol=5000, sizes_bp=None, maxpixel=None, seed0=E2E_SEED0, nan_frac=0.005):
+    E2E_MAXPIXEL = maxpixel or globals()['E2E_MAXPIXEL']
+    names, sizes, sel = synth.make_genome(sizes_bp or E2E_SIZES, resol, seed0=seed0, names=E2E_NAMES, nan_frac=nan_frac)
     obj = gs_mod.getStripe(sel, resol, 10, 8, 2.0, list(names), list(names), np.array(sizes), np.array(sizes), core,
                            3, E2E_PRNG_SEED)
     info = Info(); info.chromsizes = pd.Series(sizes, index=names)
     store = {'resol': resol, 'sizes': np.array(sizes), 'names': np.array(names), 'seed0': E2E_SEED0,
              'maxpixel': np.array(E2E_MAXPIXEL), 'prng_seed': E2E_PRNG_SEED, 'core': core}
+    store['seed0'] = seed0
+    store['nan_frac'] = nan_frac
     with quiet():
         MP = obj.getQuantile_original(info, names, E2E_MAXPIXEL)       # stripenn.py:126
         EV = obj.mpmean()                                              # stripenn.py:128
@@ -139,6 +141,13 @@ def run(core, tag):
     print('e2e', tag, 'final rows', len(rt), 'filtered', len(filt))
 
 
-def e2e_goldens():
-    run(1, 'seq')      # numcores=1: the PRNG stream runs on across chromosomes
-    run(2, 'par')      # numcores>1: loky pickles self, every chromosome restarts from the seed
+def e2e_goldens(which=('seq', 'par', '1kb')):
+    if 'seq' in which:
+        run(1, 'seq')      # numcores=1: the PRNG stream runs on across chromosomes
+    if 'par' in which:
+        run(2, 'par')      # numcores>1: loky pickles self, every chromosome restarts from the seed
+    if '1kb' in which:
+        # 1 kb bins: background size 50 (wrapped Python slices in nulldist, 2500-element window means).
+        # No NaN bins: with 50-bin flanks the reference itself raises IndexError in np.delete
+        # (getStripe.py:735) as soon as an all-NaN flank column has an index >= the stripe height.
+        run(1, '1kb', resol=1000, sizes_bp=[2600 * 1000 - 321, 1800 * 1000 - 77], maxpixel=[0.97], seed0=77, nan_frac=0.0)

@@ -38,7 +38,7 @@ class HipBackend:
         L.stp_background_free.argtypes = [vp, vp]
         L.stp_background_free.restype = None
         L.stp_pvalue.argtypes = [vp, vp, vp, C.c_int32, vp, C.c_int64, vp]
-        L.stp_stripiness.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp]
+        L.stp_stripiness.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
         L.stp_stripe_mean.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
         L.stp_remove_redundant.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
         L.stp_select_create.argtypes = [vp, C.POINTER(vp)]
@@ -112,8 +112,14 @@ class HipBackend:
         exval = np.ascontiguousarray(exval, dtype=np.float64)
         n = len(stripes)
         g, m, t = np.zeros(n), np.zeros(n), np.zeros(n)
+        status = np.zeros(n, np.int32)
         if n:
-            self.ctx._chk(self.ctx.L.stp_stripiness(self.ctx.h, band.h, _p(exval), _p(stripes), n, _p(g), _p(m), _p(t)))
+            self.ctx._chk(self.ctx.L.stp_stripiness(self.ctx.h, band.h, _p(exval), _p(stripes), n, _p(g), _p(m), _p(t),
+                                                     _p(status)))
+        if status.any():
+            # the reference's np.delete(center, rowdel, axis=0) raises here (getStripe.py:735)
+            raise IndexError('index out of bounds for axis 0: an all-NaN flank column maps to a row outside stripe %d'
+                             % int(np.nonzero(status)[0][0]))
         return g, m, t
 
     def stripe_mean(self, band, rects):

@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256) void k_pvalue(stp_bandref B, const double* __r
 template <bool BIG>
 __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double* __restrict__ exval,
                                                      const stp_score_stripe* __restrict__ st, double* __restrict__ out_g,
-                                                     double* __restrict__ out_mean, double* __restrict__ out_total)
+                                                     double* __restrict__ out_mean, double* __restrict__ out_total,
+                                                     int* __restrict__ out_status)
 {
     __shared__ double ex[STP_NDIAG];
     __shared__ double rowm[3][STP_SCORE_MAXROWS];
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
     __syncthreads();
     // the rows dead columns delete (:713-733), compaction of kept columns / rows
     if (tid == 0) {
-        int anydel = 0;
+        int anydel = 0, status = 0;
         for (int b = 0; b < 3; b++) {
             const int w = s.col1[b] - s.col0[b];
             int n = 0;
@@ -348,6 +349,7 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
                 if (keepc[b][c]) keepc[b][n++] = (int16_t)c;
                 else {
                     int rd = s.mirror ? (h - 1 - c) : c;
+                    if (rd < -h || rd >= h) status = 1;          // np.delete: index out of bounds (IndexError)
                     if (rd < 0) rd += h;
                     if (rd >= 0 && rd < h) { rowdel[rd] = 1; anydel = 1; }
                 }
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
         }
         nkr = anydel ? n : -h;       // negative: identity map, filled in parallel below
         s_tot = 0.0;
+        out_status[blockIdx.x] = status;
     }
     __syncthreads();
     if (nkr < 0) {

@@ -1170,7 +1170,7 @@ int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int
 }
 
 int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, const stp_score_stripe* st, int64_t n,
-                   double* out_g, double* out_mean, double* out_total)
+                   double* out_g, double* out_mean, double* out_total, int32_t* out_status)
 {
     if (!ctx || !band || !exval400 || !st || !out_g || !out_mean || !out_total || n < 0) return STP_E_ARG;
     if (n == 0) return STP_OK;
@@ -1184,7 +1184,7 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
     dev_buf bS, bE, bO;
     HIPCHK(bS.alloc((size_t)n * sizeof(stp_score_stripe)));
     HIPCHK(bE.alloc(STP_NDIAG * sizeof(double)));
-    HIPCHK(bO.alloc((size_t)n * 3 * sizeof(double)));
+    HIPCHK(bO.alloc((size_t)n * 3 * sizeof(double) + (size_t)n * sizeof(int)));
     HIPCHK(hipMemcpyAsync(bS.p, st, (size_t)n * sizeof(stp_score_stripe), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(bE.p, exval400, STP_NDIAG * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     double* o = (double*)bO.p;
@@ -1198,15 +1198,16 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
             for (int b = 0; b < 3; b++) big = big || (st[i].col1[b] - st[i].col0[b]) > 128;
         if (!big)
             hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bE.p,
-                               (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n);
+                               (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n));
         else
             hipLaunchKernelGGL(k_stripiness<true>, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bE.p,
-                               (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n);
+                               (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n));
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_g, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(out_mean, o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(out_total, o + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (out_status) HIPCHK(hipMemcpyAsync(out_status, o + 3 * n, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return STP_OK;
 }

@@ -29,7 +29,8 @@ def load(tag='seq'):
     st = np.load(os.path.join(ROOT, 'tests', 'golden', 'stages_chr7.npz'))
     names = [str(x) for x in g['names']]
     sizes = g['sizes']
-    _, _, sel = synth.make_genome(list(sizes), int(g['resol']), seed0=int(g['seed0']), names=names)
+    nan_frac = float(g['nan_frac']) if 'nan_frac' in g.files else 0.005
+    _, _, sel = synth.make_genome(list(sizes), int(g['resol']), seed0=int(g['seed0']), names=names, nan_frac=nan_frac)
     return g, st, names, sizes, sel
 
 
@@ -54,9 +55,9 @@ class Info:
     pass
 
 
-def run_compute(make_backend, float_exact, core=1):
+def run_compute(make_backend, float_exact, core=1, tag='seq'):
     """Returns nothing; asserts every intermediate and the final TSVs against the reference."""
-    g, st, names, sizes, sel = load('seq')
+    g, st, names, sizes, sel = load(tag)
     resol = int(g['resol'])
     obj = GS.getStripe(sel, resol, 10, 8, 2.0, names, names, sizes, sizes, core, 3, int(g['prng_seed']),
                        backend=make_backend(np.ascontiguousarray(st['gw_2p0'])))
@@ -106,8 +107,8 @@ def run_compute(make_backend, float_exact, core=1):
     return obj, out
 
 
-def run_score(make_backend, float_exact):
-    g, st, names, sizes, sel = load('seq')
+def run_score(make_backend, float_exact, tag='seq'):
+    g, st, names, sizes, sel = load(tag)
     resol = int(g['resol'])
     ref = pd.read_csv(io.StringIO(str(g['tsv_unfiltered'])), sep='\t')
     table = ref[['chr', 'pos1', 'pos2', 'chr2', 'pos3', 'pos4']].reset_index(drop=True)
@@ -132,3 +133,22 @@ def run_par_background(make_backend):
     bg = obj.nulldist()
     for t, k in zip(bg, ('lu', 'ru', 'ld', 'rd')):
         assert sha(t) == str(g['bg_%s_sha' % k]), 'background table %s differs (numcores>1 PRNG rule)' % k
+
+
+def run_nan_flank_indexerror(make_backend):
+    """1 kb bins, a NaN bin inside the 50-bin left flank of a 21-row stripe: the reference's
+    np.delete(center, rowdel, axis=0) raises IndexError (getStripe.py:735); so must we."""
+    import pytest
+    resol = 1000
+    names, sizes, sel = synth.make_genome([1500 * resol - 5], resol, seed0=3, names=['chr1'], nan_frac=0.02)
+    nanb = [int(b) for b in sel.chroms['chr1'].nan_bins if 100 < b < 1300]
+    assert nanb
+    b = nanb[0]
+    x0 = b + 40                                # NaN bin sits at flank column 10 .. inside [x0-50, x0)
+    table = pd.DataFrame({'chr': ['chr1'], 'pos1': [x0 * resol + 1], 'pos2': [(x0 + 3) * resol], 'chr2': ['chr1'],
+                          'pos3': [x0 * resol + 1], 'pos4': [(x0 + 5) * resol]})     # 5 rows < flank index 10
+    obj = GS.getStripe(sel, resol, 10, 8, 2.0, names, names, sizes, sizes, 1, 3, 1, backend=make_backend(None))
+    EV = {'chr1': [1.0] * 400}
+    with pytest.raises(IndexError):
+        obj.scoringstripes(table, EV, '0')
+    return obj

@@ -16,7 +16,7 @@ def test_exports_match_header():
     assert len(declared) >= 20
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, 'declared in the header but not exported: %s' % missing
-    assert L.stp_version() == 1
+    assert L.stp_version() == 2
 
 
 def test_no_cpu_fallback_without_gpu():

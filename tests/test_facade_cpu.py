@@ -23,6 +23,17 @@ def test_score_pipeline_matches_reference_exactly():
     E.run_score(_mk, float_exact=True)
 
 
+def test_compute_and_score_at_1kb_match_reference_exactly():
+    """resolution 1 kb: background size 50 -> wrapped Python slices in nulldist (the unit-matrix path),
+    2500-element window means (numpy's recursive pairwise sum), 50-bin flanks."""
+    E.run_compute(_mk, float_exact=True, tag='1kb')
+    E.run_score(_mk, float_exact=True, tag='1kb')
+
+
+def test_nan_flank_raises_indexerror_like_reference():
+    E.run_nan_flank_indexerror(_mk)
+
+
 def test_background_with_numcores_gt1():
     E.run_par_background(_mk)
 

@@ -41,6 +41,18 @@ def test_score_pipeline_on_gpu():
     E.run_score(_HipWithWeights, float_exact=False)
 
 
+def test_compute_and_score_at_1kb_on_gpu():
+    """1 kb bins (background size 50): k_null_windows<true>, unit-matrix path for wrapped slices."""
+    obj, out = E.run_compute(_HipWithWeights, float_exact=True, tag='1kb')
+    obj.backend.close()
+    E.run_score(_HipWithWeights, float_exact=True, tag='1kb')
+
+
+def test_nan_flank_raises_indexerror_on_gpu():
+    obj = E.run_nan_flank_indexerror(_HipWithWeights)
+    obj.backend.close()
+
+
 def test_background_with_numcores_gt1_on_gpu():
     E.run_par_background(_HipWithWeights)
 
