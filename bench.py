@@ -103,6 +103,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--bins', type=int, default=CHR16_BINS, help='chromosome length in 5 kb bins')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-score', action='store_true', help='StripeSearch chain only (skips the p-value / Stripiness set-up; for very long chromosomes)')
     args = ap.parse_args()
 
     import torch
@@ -138,10 +139,11 @@ def main():
     obj = GS.getStripe(sel, 5000, 10, 8, 2.0, [name], [name], np.array([size]), np.array([size]), 2, 3, 123456789,
                        backend=hb)
     obj._bands[name] = hb.ctx.band_upload(band_h)
-    EV = np.asarray(obj.mpmean()[name])
-    bg = obj.nulldist()
-    hb.set_background(*bg)
     sband = obj._bands[name]
+    if not args.no_score:
+        EV = np.asarray(obj.mpmean()[name])
+        bg = obj.nulldist()
+        hb.set_background(*bg)
     bs = 10
 
     def score_inputs(recs, fr):
@@ -172,9 +174,10 @@ def main():
     def step():
         fr = sband.frames(st, en)
         recs = fr.stripe_search(Ms)
-        pv, sc = score_inputs(recs, fr)
-        p = hb.pvalue(sband, bs, pv)
-        g = hb.stripiness(sband, EV, sc)[0]
+        if not args.no_score:
+            pv, sc = score_inputs(recs, fr)
+            p = hb.pvalue(sband, bs, pv)
+            g = hb.stripiness(sband, EV, sc)[0]
         S = fr.S.copy()
         fr.close()
         return recs, S

@@ -353,9 +353,24 @@ STP_HD void canny_p1c(int tid, int nt, stp_tile T, const double* w, const double
 
 // XIN: every column of the smoothed tile (tx0-2 .. tx0+CT_X+1) is an interior column (x-R >= 0 and
 // x+R < S) -> no in-image test and no border bleed-over in the inner loop.
+// Division by the bleed-over of an interior pixel (one constant c for every interior pixel of every
+// image): q = f * rc, r = fma(-q, c, f), q' = fma(r, rc, q) with rc = RN(1 / c) is the correctly rounded
+// quotient (Markstein).  It is used only when the host has verified it against the true division for all
+// 2^23 float mantissas (the numerator is always a float; the quotient scales exactly with its exponent).
+struct stp_fastdiv {
+    double c, rc;
+    int ok;
+};
+STP_HD double stp_div_const(double f, double c, double rc)
+{
+    const double q = f * rc;
+    const double r = fma(-q, c, f);
+    return fma(r, rc, q);
+}
+
 template <int R, bool XIN>
 STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const float* sVT, const double* sB,
-                         const double* sBB, double* sS)
+                         const double* sBB, double* sS, stp_fastdiv fd)
 {
     const int VH = CT_Y + 4, SW = CT_X + 4;
     const int NG = (SW + CT_HRUN - 1) / CT_HRUN;
@@ -371,6 +386,7 @@ STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const flo
             win[k] = (col < CT_X + 2 * R + 4) ? (double)sVT[col * CT_VP + yy] : 0.0;
         }
         const double bint = sB[VH + yy] + DBL_EPSILON;
+        const bool fast = XIN && fd.ok && yin && (bint == fd.c);      // interior row: the verified constant
 #pragma unroll
         for (int q = 0; q < CT_HRUN; q++) {
             const int xx = xx0 + q;
@@ -381,7 +397,7 @@ STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const flo
             const float f = (float)o;
             double s;
             if (XIN) {
-                s = yin ? (double)f / bint : 0.0;
+                s = fast ? stp_div_const((double)f, fd.c, fd.rc) : (yin ? (double)f / bint : 0.0);
             } else {
                 const int x = T.tx0 - 2 + xx;
                 s = 0.0;
@@ -454,28 +470,38 @@ STP_HD void ct_sobel(const double* sS, stp_tile T, int y, int x, double* is, dou
     ct_sobel_off(c, y > 0 ? -CT_SP : 0, y < T.S - 1 ? CT_SP : 0, x > 0 ? -1 : 0, x < T.S - 1 ? 1 : 0, is, js);
 }
 
-STP_HD void canny_p3_in(int tid, int nt, const double* sS, double* sM)
+// approximate magnitude (float, one hardware sqrt): relative error < 3e-7, see ct_nms
+STP_HD float stp_mag32(double is, double js)
+{
+    const float q = (float)(is * is + js * js);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(q);
+#else
+    return sqrtf(q);
+#endif
+}
+STP_HD void canny_p3_in(int tid, int nt, const double* sS, float* sM)
 {
     const int MH = CT_Y + 2, MW = CT_X + 2;
     for (int i = tid; i < MH * MW; i += nt) {
         const int yy = i / MW, xx = i - yy * MW;
         double is, js;
         ct_sobel_in(sS + (yy + 1) * CT_SP + (xx + 1), &is, &js);
-        sM[i] = sqrt(is * is + js * js);              // approximate magnitude, see ct_nms
+        sM[i] = stp_mag32(is, js);
     }
 }
 
-STP_HD void canny_p3(int tid, int nt, stp_tile T, const double* sS, double* sM)
+STP_HD void canny_p3(int tid, int nt, stp_tile T, const double* sS, float* sM)
 {
     const int MH = CT_Y + 2, MW = CT_X + 2;
     for (int i = tid; i < MH * MW; i += nt) {
         int yy = i / MW, xx = i - yy * MW;
         int y = T.ty0 - 1 + yy, x = T.tx0 - 1 + xx;
-        double m = 0.0;
+        float m = 0.0f;
         if (y >= 0 && y < T.S && x >= 0 && x < T.S) {
             double is, js;
             ct_sobel(sS, T, y, x, &is, &js);
-            m = sqrt(is * is + js * js);              // approximate magnitude, see ct_nms
+            m = stp_mag32(is, js);
         }
         sM[i] = m;
     }
@@ -484,21 +510,21 @@ STP_HD void canny_p3(int tid, int nt, stp_tile T, const double* sS, double* sM)
 // _canny.py:193-280: interior & magnitude>0, four overlapping sectors (later ones override),
 // bilinear interpolation with `<=`, thresholds 0.1 / 0.2 with `>=`.  Returns 0 / 1 (low) / 2 (high).
 //
-// The magnitude tile sM holds h0 = sqrt(is^2 + js^2), NOT numpy's hypot.  h0 is within 2 ulp of the true
-// value and glibc's hypot within 1 ulp, so |h0 - m| <= 3 ulp(m) < 7e-16 m for every pixel.  A decision
-// taken from h0 values equals the reference's whenever the compared quantities differ by more than the
-// propagated error (< 2e-15 of the largest magnitude involved: four magnitudes through two products, one
-// sum, one comparison).  We accept it only when the gap exceeds 1e-12 of that magnitude (500x the bound)
-// and the thresholds 0.1 / 0.2 are missed by more than 1e-13; otherwise (ties, plateaus, near-ties) the
-// five magnitudes are recomputed with the exact glibc kernel (stp_hypot) and the reference's test is
-// evaluated literally.  The fallback is taken by a vanishing fraction of pixels.
-STP_HD int ct_nms(const double* sS, const double* sM, stp_tile T, int y, int x)
+// The magnitude tile sM holds a FLOAT approximation h0 of numpy's hypot(is, js): the f64 sum of squares
+// rounded to float and one hardware square root, relative error < 3e-7 (2^-24 for the rounding, at most
+// 1 ulp(float) for v_sqrt_f32).  A decision taken from h0 values equals the reference's whenever the
+// compared quantities differ by more than the propagated error (< 1e-6 of the largest magnitude
+// involved).  We accept it only when the gap exceeds 1e-5 of that magnitude and the thresholds 0.1 /
+// 0.2 are missed by more than 1e-6; otherwise (ties, plateaus, near-ties) the five magnitudes are
+// recomputed with the exact glibc kernel (stp_hypot) and the reference's test is evaluated literally.
+// The fallback is taken by ~1e-5 of the candidates on noisy data, by thousands on synthetic plateaus.
+STP_HD int ct_nms(const double* sS, const float* sM, stp_tile T, int y, int x)
 {
     if (y < 1 || x < 1 || y >= T.S - 1 || x >= T.S - 1) return 0;
     const int MW = CT_X + 2;
-    const double* mp = sM + (y - (T.ty0 - 1)) * MW + (x - (T.tx0 - 1));
-    const double m0 = mp[0];
-    if (m0 < 0.1 - 1e-13) return 0;       // exact m < 0.1: class 0 whatever the local-max test says
+    const float* mp = sM + (y - (T.ty0 - 1)) * MW + (x - (T.tx0 - 1));
+    const double m0 = (double)mp[0];
+    if (m0 < 0.1 - 1e-6) return 0;        // exact m < 0.1: class 0 whatever the local-max test says
     double gi, gj;                          // (y, x) is interior: direct indexing
     ct_sobel_in(sS + (y - (T.ty0 - 2)) * CT_SP + (x - (T.tx0 - 2)), &gi, &gj);
     const double ai = fabs(gi), aj = fabs(gj);
@@ -515,12 +541,12 @@ STP_HD int ct_nms(const double* sS, const double* sM, stp_tile T, int y, int x)
     else return 0;
     const int o1 = dy1 * MW + dx1, o2 = dy2 * MW + dx2;
     const double omw = 1.0 - wq;
-    double m = m0, c1p = mp[o1], c2p = mp[o2], c1m = mp[-o1], c2m = mp[-o2];
+    double m = m0, c1p = (double)mp[o1], c2p = (double)mp[o2], c1m = (double)mp[-o1], c2m = (double)mp[-o2];
     double lp = c2p * wq + c1p * omw, lm = c2m * wq + c1m * omw;
     double big = m0;
     big = c1p > big ? c1p : big; big = c2p > big ? c2p : big; big = c1m > big ? c1m : big; big = c2m > big ? c2m : big;
-    const double tol = big * 1e-12;
-    const bool certain = fabs(lp - m0) > tol && fabs(lm - m0) > tol && fabs(m0 - 0.1) > 1e-13 && fabs(m0 - 0.2) > 1e-13;
+    const double tol = big * 1e-5;
+    const bool certain = fabs(lp - m0) > tol && fabs(lm - m0) > tol && fabs(m0 - 0.1) > 1e-6 && fabs(m0 - 0.2) > 1e-6;
     if (!certain) {                         // exact re-evaluation (glibc hypot of the five pixels)
         double is, js;
         m = stp_hypot(gi, gj);
@@ -536,7 +562,7 @@ STP_HD int ct_nms(const double* sS, const double* sM, stp_tile T, int y, int x)
 }
 
 // class of every tile pixel into an LDS byte tile (CT_Y x CT_X)
-STP_HD void canny_p4(int tid, int nt, stp_tile T, const double* sS, const double* sM, uint8_t* sC)
+STP_HD void canny_p4(int tid, int nt, stp_tile T, const double* sS, const float* sM, uint8_t* sC)
 {
     for (int i = tid; i < CT_Y * CT_X; i += nt) {
         int yy = i / CT_X, xx = i - yy * CT_X;

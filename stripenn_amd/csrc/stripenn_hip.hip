@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
 // class) into a wave-private LDS queue by ballot + popcount, then runs the interpolation test densely
 // over the queue, 64 candidates at a time -- candidates are 7-25 % of the pixels but occur in every row,
 // so a per-row test would keep all lanes of every wave busy with the expensive path.
-__device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double* sS, const double* sM, uint16_t* sQ,
+__device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double* sS, const float* sM, uint16_t* sQ,
                                                stp_u64* sBits, stp_u64* __restrict__ low_img, stp_u64* __restrict__ high_img)
 {
     const int lane = tid & 63, wv = tid >> 6;
@@ -146,7 +146,7 @@ __device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double
         const int yy = wv * 8 + r;
         const int y = T.ty0 + yy, x = T.tx0 + lane;
         bool c = false;
-        if (y >= 1 && x >= 1 && y < T.S - 1 && x < T.S - 1) c = sM[(yy + 1) * (CT_X + 2) + lane + 1] >= 0.1 - 1e-13;
+        if (y >= 1 && x >= 1 && y < T.S - 1 && x < T.S - 1) c = sM[(yy + 1) * (CT_X + 2) + lane + 1] >= (float)(0.1 - 1e-6);
         const stp_u64 m = __ballot(c);
         if (c) q[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((yy << 6) | lane);
         n += __popcll(m);
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, c
     double* sS = sB + 2 * VH;                                     // VH*CT_SP
     float* sG = (float*)(sS + VH * CT_SP);                        // GH*GW
     float* sV = sG + GH * GW;                                     // VH*GW
-    double* sM = (double*)sG;                                     // (CT_Y+2)*(CT_X+2) f64, aliases sG/sV
+    float* sM = sG;                                               // (CT_Y+2)*(CT_X+2) f32, aliases sG
     stp_u64* sBits = (stp_u64*)(smem + canny_smem_bytes(R));      // class bit-rows + candidate queues
     uint16_t* sQ = (uint16_t*)(sBits + 2 * CT_Y);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -242,7 +242,7 @@ static __host__ __device__ size_t canny_pipe_smem_bytes(int R)
 template <int RT>
 __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
                                                      int nf, int nlev, int nb, const double* __restrict__ gw,
-                                                     stp_u64* __restrict__ low, stp_u64* __restrict__ high)
+                                                     stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_fastdiv fd)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int R = RT;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gr
     double* sBB = sB + 2 * VH;                   // border-column bleed-over table, VH x 2R
     double* sS = sBB + VH * 2 * R;
     float* sV = (float*)(sS + VH * CT_SP);
-    double* sM = (double*)sV;                    // magnitude tile aliases the vertical-pass tile
+    float* sM = sV;                              // magnitude tile (f32) aliases the vertical-pass tile
     stp_u64* sBits = (stp_u64*)(smem + canny_pipe_smem_bytes(R));   // class bit-rows + candidate queues
     uint16_t* sQ = (uint16_t*)(sBits + 2 * CT_Y);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gr
         __syncthreads();
         continue;
 #endif
-        if (xin) canny_p2_blk<R, true>(tid, nt, T, sW, sV, sB, sBB, sS);
-        else canny_p2_blk<R, false>(tid, nt, T, sW, sV, sB, sBB, sS);
+        if (xin) canny_p2_blk<R, true>(tid, nt, T, sW, sV, sB, sBB, sS, fd);
+        else canny_p2_blk<R, false>(tid, nt, T, sW, sV, sB, sBB, sS, fd);
         __syncthreads();
 #if defined(STP_ABLATE_CANNY_P12)     /* timing-only build: Gaussian passes only */
         if (tid == 0) low[img * (STP_FRAME_MAX * STP_NW)] = (stp_u64)sS[70];
@@ -812,6 +812,31 @@ struct dev_buf {
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
 };
 
+// Interior bleed-over constant of the given Gaussian weights and exhaustive verification of the
+// multiply + 2 FMA division by it for every float mantissa (cached per weight vector).
+static stp_fastdiv make_fastdiv(const double* w, int R)
+{
+    static std::vector<double> cache_w;
+    static stp_fastdiv cache_fd = {0.0, 0.0, 0};
+    if ((int)cache_w.size() == 2 * R + 1 && memcmp(cache_w.data(), w, (2 * R + 1) * sizeof(double)) == 0) return cache_fd;
+    stp_fastdiv fd;
+    const int S = 4 * R + 8;                                       // any size with an interior pixel
+    const double V = stp_bleed_v(2 * R + 2, S, R, w);
+    fd.c = stp_bleed_h(V, 2 * R + 2, S, R, w) + DBL_EPSILON;
+    fd.rc = 1.0 / fd.c;
+    fd.ok = 1;
+    for (uint32_t m = 0; m < (1u << 23) && fd.ok; m++) {
+        uint32_t bits = 0x3F800000u | m;                           // floats in [1, 2)
+        float f;
+        memcpy(&f, &bits, 4);
+        const double q = stp_div_const((double)f, fd.c, fd.rc), t = (double)f / fd.c;
+        if (memcmp(&q, &t, 8) != 0) fd.ok = 0;
+    }
+    cache_w.assign(w, w + 2 * R + 1);
+    cache_fd = fd;
+    return fd;
+}
+
 // shared by stp_stripe_search and stp_dbg_stages: run the three image kernels on frames
 // [f0, f0+nf) for n_levels levels; buffers sized by the caller.
 static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, int f0, int nf,
@@ -838,13 +863,14 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         prof_scope ps(ctx, "canny", ipx * 5.0);          // stage B: 4 B read + 1 B written
         const int tiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
         const dim3 cg(tiles, (unsigned)nimg);
+        const stp_fastdiv fd = make_fastdiv(prm->gauss_w, R);
         const unsigned pgrid = (unsigned)(((nf * nlev + 7) / 8) * 8 * tiles);
         if (R == 8)
             hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_NMS_BYTES, ctx->stream, d_gray,
-                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high);
+                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high, fd);
         else if (R == 10)
             hipLaunchKernelGGL(k_canny_pipe<10>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_NMS_BYTES, ctx->stream, d_gray,
-                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high);
+                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high, fd);
         else
             hipLaunchKernelGGL(k_canny, cg, dim3(256), canny_smem_bytes(R) + CANNY_NMS_BYTES, ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
                                d_low, d_high);

@@ -51,10 +51,22 @@ void emu_canny2(const float* gray /* pitch 400 */, int S, int R, const double* w
 {
     const int GW = ct_gw(R), GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
     std::vector<float> sG(GH * GW), sV(VH * GW > GW * CT_VP ? VH * GW : GW * CT_VP);
-    std::vector<double> sB(2 * VH), sS(VH * CT_SP), sM((CT_Y + 2) * (CT_X + 2));
+    std::vector<double> sB(2 * VH), sS(VH * CT_SP);
+    std::vector<float> sM((CT_Y + 2) * (CT_X + 2));
     std::vector<uint8_t> sC(CT_Y * CT_X);
     memset(low, 0, sizeof(stp_u64) * STP_FRAME_MAX * STP_NW);
     memset(high, 0, sizeof(stp_u64) * STP_FRAME_MAX * STP_NW);
+    stp_fastdiv fd;                     // as the library does: interior constant, verified on 2^23 mantissas
+    {
+        const int Sx = 4 * R + 8;
+        const double V = stp_bleed_v(2 * R + 2, Sx, R, w);
+        fd.c = stp_bleed_h(V, 2 * R + 2, Sx, R, w) + DBL_EPSILON; fd.rc = 1.0 / fd.c; fd.ok = 1;
+        for (uint32_t m = 0; m < (1u << 23) && fd.ok; m++) {
+            uint32_t bits = 0x3F800000u | m; float f; memcpy(&f, &bits, 4);
+            const double q = stp_div_const((double)f, fd.c, fd.rc), t = (double)f / fd.c;
+            if (memcmp(&q, &t, 8) != 0) fd.ok = 0;
+        }
+    }
     for (int ty0 = 0; ty0 < S; ty0 += CT_Y)
         for (int tx0 = 0; tx0 < S; tx0 += CT_X) {
             stp_tile T; T.S = S; T.ty0 = ty0; T.tx0 = tx0;
@@ -67,14 +79,14 @@ void emu_canny2(const float* gray /* pitch 400 */, int S, int R, const double* w
                 std::vector<double> sBB(VH * 16);
                 if (!xin) canny_p1c<8>(0, 1, T, w, sB.data(), sBB.data());
                 if (yin) canny_p1_blk_g<8, true>(0, 1, T, w, gray, sV.data()); else canny_p1_blk_g<8, false>(0, 1, T, w, gray, sV.data());
-                if (xin) canny_p2_blk<8, true>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data());
-                else canny_p2_blk<8, false>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data());
+                if (xin) canny_p2_blk<8, true>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data(), fd);
+                else canny_p2_blk<8, false>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data(), fd);
             } else if (R == 10 && blocked) {
                 std::vector<double> sBB(VH * 20);
                 if (!xin) canny_p1c<10>(0, 1, T, w, sB.data(), sBB.data());
                 if (yin) canny_p1_blk_g<10, true>(0, 1, T, w, gray, sV.data()); else canny_p1_blk_g<10, false>(0, 1, T, w, gray, sV.data());
-                if (xin) canny_p2_blk<10, true>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data());
-                else canny_p2_blk<10, false>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data());
+                if (xin) canny_p2_blk<10, true>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data(), fd);
+                else canny_p2_blk<10, false>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data(), fd);
             } else {
                 canny_p1(0, 1, T, R, w, sG.data(), sV.data());
                 canny_p2(0, 1, T, R, w, sV.data(), sB.data(), sS.data());
@@ -138,3 +150,18 @@ int emu_lines(const stp_u64* low, const stp_u64* high, const double* band, int W
 }
 
 }  // extern "C"
+
+// whether the multiply + 2 FMA division by the interior bleed-over constant is exact for every float
+extern "C" int emu_fastdiv_ok(const double* w, int R, double* c_out)
+{
+    const int Sx = 4 * R + 8;
+    const double V = stp_bleed_v(2 * R + 2, Sx, R, w);
+    const double c = stp_bleed_h(V, 2 * R + 2, Sx, R, w) + DBL_EPSILON, rc = 1.0 / c;
+    if (c_out) *c_out = c;
+    for (uint32_t m = 0; m < (1u << 23); m++) {
+        uint32_t bits = 0x3F800000u | m; float f; memcpy(&f, &bits, 4);
+        const double q = stp_div_const((double)f, c, rc), t = (double)f / c;
+        if (memcmp(&q, &t, 8) != 0) return 0;
+    }
+    return 1;
+}
