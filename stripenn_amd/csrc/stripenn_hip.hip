@@ -235,8 +235,8 @@ static __host__ __device__ size_t canny_pipe_smem_bytes(int R)
     const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
     size_t fixed = (32 + 2 * VH + VH * 2 * R + VH * CT_SP) * sizeof(double);
     size_t v = (size_t)GW * CT_VP * sizeof(float);
-    size_t m = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(double);
-    return fixed + (v > m ? v : m);
+    size_t m = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(float);
+    return fixed + v + m;
 }
 
 template <int RT>
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gr
     double* sBB = sB + 2 * VH;                   // border-column bleed-over table, VH x 2R
     double* sS = sBB + VH * 2 * R;
     float* sV = (float*)(sS + VH * CT_SP);
-    float* sM = sV;                              // magnitude tile (f32) aliases the vertical-pass tile
+    float* sM = sV + (CT_X + 2 * R + 4) * CT_VP;   // magnitude tile (f32), own slot: see the loop below
     stp_u64* sBits = (stp_u64*)(smem + canny_pipe_smem_bytes(R));   // class bit-rows + candidate queues
     uint16_t* sQ = (uint16_t*)(sBits + 2 * CT_Y);
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -299,7 +299,9 @@ __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gr
         else canny_p3(tid, nt, T, sS, sM);
         __syncthreads();
         canny_nms_pack(tid, T, sS, sM, sQ, sBits, low + img * (STP_FRAME_MAX * STP_NW), high + img * (STP_FRAME_MAX * STP_NW));
-        __syncthreads();        // sM aliases the vertical-pass tile of the next image
+        // no barrier here: the next image's vertical pass touches only global memory and sV, so a wave that
+        // has finished its share of the NMS moves on; the barrier after that pass orders this NMS (reads of
+        // sS / sM, the wave-private queues) before the next horizontal pass rewrites sS
     }
 }
 
