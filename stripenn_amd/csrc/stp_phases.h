@@ -767,33 +767,34 @@ STP_HD void lines_vline(int tid, int nt, int S, const stp_u64* sE, stp_u64* sV)
     }
 }
 
-// V3[r][c] = V[r][c-1] | V[r][c] | V[r][c+1]  (ImageProcessing.py:122-123)
-STP_HD void lines_v3(int tid, int nt, int S, const stp_u64* sV, stp_u64* sV3)
-{
-    for (int i = tid; i < S * STP_NW; i += nt) {
-        int r = i / STP_NW, w = i - r * STP_NW;
-        const stp_u64* row = sV + r * STP_NW;
-        sV3[i] = row[w] | bm_shl1(row, w) | bm_shr1(row, w);
-    }
-}
-
-// ImageProcessing.block (ImageProcessing.py:124-195) + the caller's keep test (getStripe.py:929-940)
-STP_HD void lines_block(int tid, int nt, int S, int minH, const stp_u64* sV, const stp_u64* sV3, int16_t* colT,
-                        int16_t* colEnd, int16_t* colUd)
+// ImageProcessing.block (ImageProcessing.py:124-195) + the caller's keep test (getStripe.py:929-940).
+// value[i] = V[i][c-1] | V[i][c] | V[i][c+1] (ImageProcessing.py:122-123) is formed on the fly from the
+// row word of V (plus the neighbouring word for the two lanes at a word edge).
+STP_HD void lines_block(int tid, int nt, int S, int minH, const stp_u64* sV, int16_t* colT, int16_t* colEnd, int16_t* colUd)
 {
     for (int c = tid; c < S; c += nt) {
         int count = 0, MAX = 0, END = 0, J = 0, buffer = 0;
-        const int wi = c >> 6;
-        const stp_u64 bit = 1ull << (c & 63);
+        const int wi = c >> 6, b = c & 63;
+        const stp_u64 bit = 1ull << b;
+        const stp_u64 m3 = (b == 0) ? 3ull : ((b == 63) ? (3ull << 62) : (7ull << (b - 1)));   // own-word part of c-1..c+1
+        const int nbw = (b == 0 && wi > 0) ? wi - 1 : ((b == 63 && wi + 1 < STP_NW) ? wi + 1 : -1);
+        const stp_u64 nbm = (b == 0) ? (1ull << 63) : 1ull;                                       // bit of the neighbour word
         for (int i0 = 0; i0 < S; i0 += 8) {          // 8 independent LDS reads in flight per step
             stp_u64 wd[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) wd[k] = (i0 + k < S) ? sV3[(i0 + k) * STP_NW + wi] : 0ull;
+            for (int k = 0; k < 8; k++) {
+                stp_u64 v = 0;
+                if (i0 + k < S) {
+                    v = sV[(i0 + k) * STP_NW + wi] & m3;
+                    if (nbw >= 0) v |= sV[(i0 + k) * STP_NW + nbw] & nbm;
+                }
+                wd[k] = v;
+            }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int i = i0 + k;
                 if (i >= S) break;
-                if (wd[k] & bit) { count++; J = i; }
+                if (wd[k]) { count++; J = i; }
                 else if (buffer < 5) buffer++;
                 else {
                     if (count > MAX) { MAX = count; END = J; }

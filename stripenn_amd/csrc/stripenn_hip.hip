@@ -310,27 +310,30 @@ struct stp_drec {
     double total;
 };
 
-// K-C: hysteresis + verticalLine + block + line joining + totals, one workgroup per image,
-// every mask bit-packed in LDS (3 x 22.4 KB).
+// K-C: hysteresis + verticalLine + block + line joining + totals, one workgroup per image, every mask
+// bit-packed in LDS.  Only TWO 22.4 KB bit matrices are resident (bufA: low -> vert, bufB: edges ->
+// testmat): after verticalLine the edge map is parked in global memory (escr, L2-resident) and re-read
+// one row per lane during refinement; the 3-column OR of `block` is formed on the fly.  53 KB of LDS
+// -> three workgroups per CU (this kernel is latency bound: serial scans, one-lane grouping).
 __global__ __launch_bounds__(512) void k_lines(const stp_u64* __restrict__ low, const stp_u64* __restrict__ high,
                                                 const double* __restrict__ band, int W, int hw,
                                                 const int32_t* __restrict__ fstart, const int32_t* __restrict__ fS,
                                                 const int16_t* __restrict__ fnz, int f0, int imgs_per_frame,
                                                 int minH, int maxW, stp_drec* __restrict__ recs,
-                                                int32_t* __restrict__ rec_count, int want_dbg,
+                                                int32_t* __restrict__ rec_count, stp_u64* __restrict__ escr, int want_dbg,
                                                 stp_u64* __restrict__ dbg /* E,V,T1,T2 */, int16_t* __restrict__ dbg_cols,
                                                 int dbg_stop)
 {
-    __shared__ stp_u64 buf0[STP_FRAME_MAX * STP_NW];   // low -> V3 -> testmat
-    __shared__ stp_u64 buf1[STP_FRAME_MAX * STP_NW];   // E (edges)
-    __shared__ stp_u64 buf2[STP_FRAME_MAX * STP_NW];   // V (vert)
+    __shared__ stp_u64 bufA[STP_FRAME_MAX * STP_NW];   // low -> V (vert)
+    __shared__ stp_u64 bufB[STP_FRAME_MAX * STP_NW];   // E (edges) -> testmat -> row sums
     __shared__ int16_t s_nz[STP_FRAME_MAX];
-    __shared__ int16_t colT[STP_FRAME_MAX], colEnd[STP_FRAME_MAX], colUd[STP_FRAME_MAX];
+    __shared__ int16_t colEnd[STP_FRAME_MAX], colUd[STP_FRAME_MAX];
     __shared__ int16_t cnt[STP_FRAME_MAX], minr[STP_FRAME_MAX], maxr[STP_FRAME_MAX];
     __shared__ int16_t cidx[STP_FRAME_MAX], clen[STP_FRAME_MAX], xs[STP_FRAME_MAX + 8];
     __shared__ stp_lrec lrec[STP_RCAP];
-    __shared__ double rs[STP_FRAME_MAX];
     __shared__ int s_nrec, s_nrow, s_wcnt[8];
+    int16_t* colT = cidx;                              // block lengths: only copied out for the parity tests
+    double* rs = (double*)bufB;                        // row sums: testmat is dead by then
     const int img = blockIdx.x;
     const int f = f0 + img / imgs_per_frame;
     const int S = fS[f];
@@ -341,41 +344,43 @@ __global__ __launch_bounds__(512) void k_lines(const stp_u64* __restrict__ low, 
     }
     const stp_u64* limg = low + (size_t)img * (STP_FRAME_MAX * STP_NW);
     const stp_u64* himg = high + (size_t)img * (STP_FRAME_MAX * STP_NW);
+    stp_u64* eimg = escr + (size_t)img * (STP_FRAME_MAX * STP_NW);
     for (int i = tid; i < S; i += nt) s_nz[i] = fnz[(size_t)f * STP_FRAME_MAX + i];
-    lines_load(tid, nt, S, limg, himg, buf0, buf1);
+    lines_load(tid, nt, S, limg, himg, bufA, bufB);
     __syncthreads();
-    if (dbg_stop == 1) { if (tid == 0) rec_count[img] = (int)buf1[3]; return; }      // timing-only ablation
+    if (dbg_stop == 1) { if (tid == 0) rec_count[img] = (int)bufB[3]; return; }      // timing-only ablation
     for (int it = 0; it < 4 * STP_FRAME_MAX * STP_FRAME_MAX; it++) {
-        int ch = lines_hyst_sweep_strip(tid, nt, S, buf0, buf1);
+        int ch = lines_hyst_sweep_strip(tid, nt, S, bufA, bufB);
         if (!__syncthreads_or(ch)) break;
     }
-    if (dbg_stop == 2) { if (tid == 0) rec_count[img] = (int)buf1[3]; return; }
-    lines_vline(tid, nt, S, buf1, buf2);
+    if (dbg_stop == 2) { if (tid == 0) rec_count[img] = (int)bufB[3]; return; }
+    lines_vline(tid, nt, S, bufB, bufA);               // low is dead: vert goes to bufA
+    for (int i = tid; i < S * STP_NW; i += nt) eimg[i] = bufB[i];   // park the edge map
+    __threadfence_block();
     __syncthreads();
-    lines_v3(tid, nt, S, buf2, buf0);
-    __syncthreads();
-    if (dbg_stop == 3) { if (tid == 0) rec_count[img] = (int)buf0[3]; return; }
-    lines_block(tid, nt, S, minH, buf2, buf0, colT, colEnd, colUd);
+    if (dbg_stop == 3) { if (tid == 0) rec_count[img] = (int)bufA[3]; return; }
+    lines_block(tid, nt, S, minH, bufA, colT, colEnd, colUd);
     if (tid == 0) s_nrec = 0;
     __syncthreads();
     if (dbg_stop == 4) { if (tid == 0) rec_count[img] = colT[3]; return; }
     if (want_dbg) {
         stp_u64* d = dbg + (size_t)img * 4 * (STP_FRAME_MAX * STP_NW);
-        for (int i = tid; i < S * STP_NW; i += nt) { d[i] = buf1[i]; d[STP_FRAME_MAX * STP_NW + i] = buf2[i]; }
+        for (int i = tid; i < S * STP_NW; i += nt) { d[i] = eimg[i]; d[STP_FRAME_MAX * STP_NW + i] = bufA[i]; }
         int16_t* dc = dbg_cols + (size_t)img * 3 * STP_FRAME_MAX;
         for (int i = tid; i < S; i += nt) { dc[i] = colT[i]; dc[STP_FRAME_MAX + i] = colEnd[i]; dc[2 * STP_FRAME_MAX + i] = colUd[i]; }
+        __syncthreads();
     }
     for (int ud = 1; ud <= 2; ud++) {
-        lines_zero(tid, nt, S * STP_NW, buf0);
+        lines_zero(tid, nt, S * STP_NW, bufB);
         __syncthreads();
-        lines_paint(tid, nt, S, ud, colEnd, colUd, buf0);
+        lines_paint(tid, nt, S, ud, colEnd, colUd, bufB);
         __syncthreads();
-        lines_refine(tid, nt, S, buf1, buf2, buf0);
+        lines_refine(tid, nt, S, eimg, bufA, bufB);
         __syncthreads();
-        lines_colstat(tid, nt, S, buf0, cnt, minr, maxr);
+        lines_colstat(tid, nt, S, bufB, cnt, minr, maxr);
         if (want_dbg) {
             stp_u64* d = dbg + (size_t)img * 4 * (STP_FRAME_MAX * STP_NW) + (size_t)(1 + ud) * (STP_FRAME_MAX * STP_NW);
-            for (int i = tid; i < S * STP_NW; i += nt) d[i] = buf0[i];
+            for (int i = tid; i < S * STP_NW; i += nt) d[i] = bufB[i];
         }
         __syncthreads();
         lines_cols_count(tid, nt, S, cnt, s_wcnt);
@@ -469,7 +474,7 @@ struct stp_pending {
     double bytes;
 };
 
-enum { WS_GRAY = 0, WS_LOW, WS_HIGH, WS_RECS, WS_CNT, WS_OUT, WS_TOTAL, WS_PARAMS, WS_NSLOTS };
+enum { WS_GRAY = 0, WS_LOW, WS_HIGH, WS_RECS, WS_CNT, WS_OUT, WS_TOTAL, WS_PARAMS, WS_EDGES, WS_NSLOTS };
 
 struct stp_ctx {
     int device = 0;
@@ -845,6 +850,8 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
                      const double* d_M, int nlev, const double* d_b, const double* d_w, float* d_gray, stp_u64* d_low,
                      stp_u64* d_high, stp_drec* d_recs, int32_t* d_cnt, int want_dbg, stp_u64* d_dbg, int16_t* d_dbgc)
 {
+    void* p_edges = nullptr;     // parked edge maps of k_lines (one bit matrix per image)
+    HIPCHK(ws_get(ctx, WS_EDGES, (size_t)nf * nlev * prm->n_bright * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), &p_edges));
     const stp_band* band = fr->band;
     const int nb = prm->n_bright, a = prm->bfilter / 2, R = prm->gauss_radius;
     const int ipf = nlev * nb;
@@ -883,7 +890,7 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         prof_scope ps(ctx, "lines", ipx * 9.0);          // stages C-F: 2 + 2 + 1 + 4 B per image px
         hipLaunchKernelGGL(k_lines, dim3((unsigned)nimg), dim3(512), 0, ctx->stream, d_low, d_high, band->d, band->W,
                            band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, ipf, prm->minH, prm->maxW, d_recs, d_cnt,
-                           want_dbg, d_dbg, d_dbgc, lines_stop);
+                           (stp_u64*)p_edges, want_dbg, d_dbg, d_dbgc, lines_stop);
     }
     HIPCHK(hipGetLastError());
     return STP_OK;
