@@ -483,6 +483,10 @@ struct stp_ctx {
     size_t ws_bytes[WS_NSLOTS] = {0};
     void* pin = nullptr;                   // pinned host staging buffer (records)
     size_t pin_bytes = 0;
+    // size-bucketed free lists: short-lived per-call device buffers are recycled instead of going through
+    // hipMalloc / hipFree (both synchronise the device and cost ~0.1 ms each)
+    std::vector<std::pair<size_t, void*>> pool_free;
+    size_t pool_bytes = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
@@ -519,6 +523,34 @@ static hipError_t ws_get(stp_ctx* ctx, int slot, size_t bytes, void** out)
     }
     *out = ctx->ws[slot];
     return hipSuccess;
+}
+
+static size_t pool_round(size_t n)
+{
+    size_t r = 256;
+    while (r < n) r <<= 1;
+    return r;
+}
+static hipError_t pool_alloc(stp_ctx* ctx, size_t bytes, void** out)
+{
+    const size_t r = pool_round(bytes ? bytes : 1);
+    for (size_t i = 0; i < ctx->pool_free.size(); i++)
+        if (ctx->pool_free[i].first == r) {
+            *out = ctx->pool_free[i].second;
+            ctx->pool_free[i] = ctx->pool_free.back();
+            ctx->pool_free.pop_back();
+            ctx->pool_bytes -= r;
+            return hipSuccess;
+        }
+    return hipMalloc(out, r);
+}
+static void pool_release(stp_ctx* ctx, void* p, size_t bytes)
+{
+    if (!p) return;
+    const size_t r = pool_round(bytes ? bytes : 1);
+    if (ctx->pool_bytes + r > ((size_t)1 << 30)) { (void)hipFree(p); return; }   // keep at most 1 GiB idle
+    ctx->pool_free.push_back(std::make_pair(r, p));
+    ctx->pool_bytes += r;
 }
 
 static hipError_t pin_get(stp_ctx* ctx, size_t bytes, void** out)
@@ -636,6 +668,7 @@ void stp_ctx_destroy(stp_ctx* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     resolve_pending(ctx);
     for (int i = 0; i < WS_NSLOTS; i++) if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    for (auto& e : ctx->pool_free) (void)hipFree(e.second);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -717,10 +750,12 @@ void stp_frames_free(stp_ctx* ctx, stp_frames* fr)
 {
     if (!fr) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    if (fr->d_start) (void)hipFree(fr->d_start);
-    if (fr->d_n0) (void)hipFree(fr->d_n0);
-    if (fr->d_S) (void)hipFree(fr->d_S);
-    if (fr->d_nz) (void)hipFree(fr->d_nz);
+    if (ctx) {
+        pool_release(ctx, fr->d_start, fr->n * sizeof(int32_t));
+        pool_release(ctx, fr->d_n0, fr->n * sizeof(int32_t));
+        pool_release(ctx, fr->d_S, fr->n * sizeof(int32_t));
+        pool_release(ctx, fr->d_nz, (size_t)fr->n * STP_FRAME_MAX * sizeof(int16_t));
+    }
     delete fr;
 }
 
@@ -744,10 +779,10 @@ int stp_frames_create(stp_ctx* ctx, const stp_band* band, const int32_t* start, 
     fr->h_S.resize(n); fr->h_nz.assign((size_t)n * STP_FRAME_MAX, 0); fr->h_med.assign(n, 0.0);
 #define FRCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { stp_frames_free(ctx, fr); \
         return set_err(ctx, e_ == hipErrorOutOfMemory ? STP_E_NOMEM : STP_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
-    FRCHK(hipMalloc((void**)&fr->d_start, n * sizeof(int32_t)));
-    FRCHK(hipMalloc((void**)&fr->d_n0, n * sizeof(int32_t)));
-    FRCHK(hipMalloc((void**)&fr->d_S, n * sizeof(int32_t)));
-    FRCHK(hipMalloc((void**)&fr->d_nz, (size_t)n * STP_FRAME_MAX * sizeof(int16_t)));
+    FRCHK(pool_alloc(ctx, n * sizeof(int32_t), (void**)&fr->d_start));
+    FRCHK(pool_alloc(ctx, n * sizeof(int32_t), (void**)&fr->d_n0));
+    FRCHK(pool_alloc(ctx, n * sizeof(int32_t), (void**)&fr->d_S));
+    FRCHK(pool_alloc(ctx, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), (void**)&fr->d_nz));
     FRCHK(hipMemcpyAsync(fr->d_start, fr->h_start.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     FRCHK(hipMemcpyAsync(fr->d_n0, fr->h_n0.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     FRCHK(hipMemsetAsync(fr->d_nz, 0, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), ctx->stream));
@@ -762,7 +797,7 @@ int stp_frames_create(stp_ctx* ctx, const stp_band* band, const int32_t* start, 
     {
         // medpixel: two order statistics per frame by radix select, numpy's lerp on the host
         double* d_med = nullptr;
-        FRCHK(hipMalloc((void**)&d_med, (size_t)n * 3 * sizeof(double)));
+        FRCHK(pool_alloc(ctx, (size_t)n * 3 * sizeof(double), (void**)&d_med));
         {
             double bytes = 0;
             for (int i = 0; i < n; i++) bytes += 8.0 * fr->h_n0[i] * fr->h_n0[i];
@@ -773,7 +808,7 @@ int stp_frames_create(stp_ctx* ctx, const stp_band* band, const int32_t* start, 
         std::vector<double> hm((size_t)n * 3);
         hipError_t e1 = hipMemcpyAsync(hm.data(), d_med, hm.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
         if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_med);
+        pool_release(ctx, d_med, (size_t)n * 3 * sizeof(double));
         FRCHK(e1);
         for (int i = 0; i < n; i++) {
             const double a = hm[3 * i], b = hm[3 * i + 1], N = hm[3 * i + 2];
@@ -813,10 +848,12 @@ static int check_params(stp_ctx* ctx, const stp_search_params* p)
     return STP_OK;
 }
 
-struct dev_buf {
+struct dev_buf {                      // per-call device buffer, recycled through the ctx pool
     void* p = nullptr;
-    ~dev_buf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    size_t n = 0;
+    stp_ctx* c = nullptr;
+    ~dev_buf() { if (p) { if (c) pool_release(c, p, n); else (void)hipFree(p); } }
+    hipError_t alloc(stp_ctx* ctx, size_t bytes) { c = ctx; n = bytes; return pool_alloc(ctx, bytes, &p); }
 };
 
 // Interior bleed-over constant of the given Gaussian weights and exhaustive verification of the
@@ -984,16 +1021,16 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
     const int nb = prm->n_bright;
     dev_buf bM, bB, bW, bGray, bLow, bHigh, bRecs, bCnt, bDbg, bDbgc;
     const size_t nimg = nb;
-    HIPCHK(bM.alloc(sizeof(double)));
-    HIPCHK(bB.alloc(nb * sizeof(double)));
-    HIPCHK(bW.alloc((2 * prm->gauss_radius + 1) * sizeof(double)));
-    HIPCHK(bGray.alloc(nimg * STP_PITCH * STP_PITCH * sizeof(float)));
-    HIPCHK(bLow.alloc(nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
-    HIPCHK(bHigh.alloc(nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
-    HIPCHK(bRecs.alloc(nimg * STP_RCAP * sizeof(stp_drec)));
-    HIPCHK(bCnt.alloc(nimg * sizeof(int32_t)));
-    HIPCHK(bDbg.alloc(nimg * 4 * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
-    HIPCHK(bDbgc.alloc(nimg * 3 * STP_FRAME_MAX * sizeof(int16_t)));
+    HIPCHK(bM.alloc(ctx, sizeof(double)));
+    HIPCHK(bB.alloc(ctx, nb * sizeof(double)));
+    HIPCHK(bW.alloc(ctx, (2 * prm->gauss_radius + 1) * sizeof(double)));
+    HIPCHK(bGray.alloc(ctx, nimg * STP_PITCH * STP_PITCH * sizeof(float)));
+    HIPCHK(bLow.alloc(ctx, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
+    HIPCHK(bHigh.alloc(ctx, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
+    HIPCHK(bRecs.alloc(ctx, nimg * STP_RCAP * sizeof(stp_drec)));
+    HIPCHK(bCnt.alloc(ctx, nimg * sizeof(int32_t)));
+    HIPCHK(bDbg.alloc(ctx, nimg * 4 * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
+    HIPCHK(bDbgc.alloc(ctx, nimg * 3 * STP_FRAME_MAX * sizeof(int16_t)));
     HIPCHK(hipMemsetAsync(bDbg.p, 0, nimg * 4 * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), ctx->stream));
     HIPCHK(hipMemcpyAsync(bM.p, &M, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(bB.p, prm->bright, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -1054,8 +1091,8 @@ int stp_diag_sums(stp_ctx* ctx, const stp_band* band, double* part_sum, int64_t*
     HIPCHK(hipSetDevice(ctx->device));
     dev_buf bs, bc;
     const size_t n = (size_t)n400 * STP_NDIAG;
-    HIPCHK(bs.alloc(n * sizeof(double)));
-    HIPCHK(bc.alloc(n * sizeof(long long)));
+    HIPCHK(bs.alloc(ctx, n * sizeof(double)));
+    HIPCHK(bc.alloc(ctx, n * sizeof(long long)));
     {
         prof_scope ps(ctx, "diag_sums", 8.0 * 400.0 * (double)band->nrows);
         hipLaunchKernelGGL(k_diag_sums, dim3(n400), dim3(448), 0, ctx->stream, bref(band), (double*)bs.p, (long long*)bc.p);
@@ -1088,11 +1125,11 @@ int stp_null_windows(stp_ctx* ctx, const stp_band* band, const double* unit_matr
     const size_t tn = (size_t)STP_NDIAG * n;
     if (unit_matrix) {
         const size_t mb = (size_t)samples[0].nrow * samples[0].ncol * sizeof(double);
-        HIPCHK(bD.alloc(mb));
+        HIPCHK(bD.alloc(ctx, mb));
         HIPCHK(hipMemcpyAsync(bD.p, unit_matrix, mb, hipMemcpyHostToDevice, ctx->stream));
     }
-    HIPCHK(bS.alloc((size_t)n * sizeof(stp_null_sample)));
-    HIPCHK(bO.alloc(4 * tn * sizeof(double)));
+    HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_null_sample)));
+    HIPCHK(bO.alloc(ctx, 4 * tn * sizeof(double)));
     HIPCHK(hipMemcpyAsync(bS.p, samples, (size_t)n * sizeof(stp_null_sample), hipMemcpyHostToDevice, ctx->stream));
     double* o = (double*)bO.p;
     {
@@ -1182,8 +1219,8 @@ int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int
     }
     HIPCHK(hipSetDevice(ctx->device));
     dev_buf bS, bO;
-    HIPCHK(bS.alloc((size_t)n * sizeof(stp_pv_stripe)));
-    HIPCHK(bO.alloc((size_t)n * sizeof(double)));
+    HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_pv_stripe)));
+    HIPCHK(bO.alloc(ctx, (size_t)n * sizeof(double)));
     HIPCHK(hipMemcpyAsync(bS.p, st, (size_t)n * sizeof(stp_pv_stripe), hipMemcpyHostToDevice, ctx->stream));
     {
         double bytes = 0;
@@ -1217,9 +1254,9 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
         }
     HIPCHK(hipSetDevice(ctx->device));
     dev_buf bS, bE, bO;
-    HIPCHK(bS.alloc((size_t)n * sizeof(stp_score_stripe)));
-    HIPCHK(bE.alloc(STP_NDIAG * sizeof(double)));
-    HIPCHK(bO.alloc((size_t)n * 3 * sizeof(double) + (size_t)n * sizeof(int)));
+    HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_score_stripe)));
+    HIPCHK(bE.alloc(ctx, STP_NDIAG * sizeof(double)));
+    HIPCHK(bO.alloc(ctx, (size_t)n * 3 * sizeof(double) + (size_t)n * sizeof(int)));
     HIPCHK(hipMemcpyAsync(bS.p, st, (size_t)n * sizeof(stp_score_stripe), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(bE.p, exval400, STP_NDIAG * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     double* o = (double*)bO.p;
@@ -1257,8 +1294,8 @@ int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rc, int6
     }
     HIPCHK(hipSetDevice(ctx->device));
     dev_buf bS, bO;
-    HIPCHK(bS.alloc((size_t)n * sizeof(stp_rect)));
-    HIPCHK(bO.alloc((size_t)n * 2 * sizeof(double)));
+    HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_rect)));
+    HIPCHK(bO.alloc(ctx, (size_t)n * 2 * sizeof(double)));
     HIPCHK(hipMemcpyAsync(bS.p, rc, (size_t)n * sizeof(stp_rect), hipMemcpyHostToDevice, ctx->stream));
     double* o = (double*)bO.p;
     {
@@ -1392,10 +1429,10 @@ int stp_remove_redundant(stp_ctx* ctx, int64_t n, const int64_t* pos1, const int
     }
     HIPCHK(hipSetDevice(ctx->device));
     dev_buf bP, bI, bK, bD;
-    HIPCHK(bP.alloc((size_t)n * 4 * sizeof(long long)));
-    HIPCHK(bI.alloc((size_t)n * 6 * sizeof(int)));
-    HIPCHK(bK.alloc((size_t)n * sizeof(double)));
-    HIPCHK(bD.alloc((size_t)n * sizeof(unsigned int)));
+    HIPCHK(bP.alloc(ctx, (size_t)n * 4 * sizeof(long long)));
+    HIPCHK(bI.alloc(ctx, (size_t)n * 6 * sizeof(int)));
+    HIPCHK(bK.alloc(ctx, (size_t)n * sizeof(double)));
+    HIPCHK(bD.alloc(ctx, (size_t)n * sizeof(unsigned int)));
     long long* dp = (long long*)bP.p;
     int* di = (int*)bI.p;
     const int64_t* ps[4] = {pos1, pos2, pos3, pos4};
