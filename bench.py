@@ -212,7 +212,7 @@ def main():
 
     out = None
     if rank == 0:
-        chain_ms = sum(v['ms'] for k, v in stats.items() if k in BYTES_PER_IMAGE_PX)
+        chain_ms = stats['chain_wall']['ms'] if 'chain_wall' in stats else sum(v['ms'] for k, v in stats.items() if k in BYTES_PER_IMAGE_PX)
         dom = max((k for k in stats if k in BYTES_PER_IMAGE_PX or k in SCORE_KERNELS), key=lambda k: stats[k]['ms'])
         d = stats[dom]
         ach = d['alg_bytes'] / d['launches'] / (d['ms'] / d['launches'] * 1e-3) / 1e9

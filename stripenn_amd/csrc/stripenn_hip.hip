@@ -898,6 +898,9 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     const double ipx = px * ipf;   // image pixels in this launch
     HIPCHK(hipMemsetAsync(d_low, 0, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), ctx->stream));
     HIPCHK(hipMemsetAsync(d_high, 0, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), ctx->stream));
+    // (measured and dropped: running k_lines of one sub-chunk on a second stream beside gray / canny of the
+    //  next -- chain wall 5.99 ms alone vs 6.02 / 6.29 / 6.83 ms with 2 / 4 / 8 sub-chunks)
+    prof_scope chain_scope(ctx, "chain_wall", ipx * 26.0);     // gray + canny + lines as one interval
     {
         prof_scope ps(ctx, "gray", ipx * 12.0);          // stage A of SURVEY 8(d): 8 B read + 4 B written per image px
         const int tiles = ((STP_FRAME_MAX + GT_X - 1) / GT_X) * ((STP_FRAME_MAX + GT_Y - 1) / GT_Y);
