@@ -815,31 +815,6 @@ STP_HD void lines_block(int tid, int nt, int S, int minH, const stp_u64* sV, int
     }
 }
 
-STP_HD void lines_zero(int tid, int nt, int n, stp_u64* m)
-{
-    for (int i = tid; i < n; i += nt) m[i] = 0;
-}
-
-// getStripe.py:948-955: column c painted on rows [st, en) (thread-per-column; needs LDS atomics
-// on the device because columns of one word belong to different threads)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define STP_ATOMIC_OR(p, v) atomicOr((p), (v))
-#else
-#define STP_ATOMIC_OR(p, v) (*(p) |= (v))
-#endif
-STP_HD void lines_paint(int tid, int nt, int S, int ud, const int16_t* colEnd, const int16_t* colUd, stp_u64* sT)
-{
-    for (int c = tid; c < S; c += nt) {
-        if (colUd[c] != ud) continue;
-        int st = c, en = colEnd[c];
-        if (ud == 1) { int t = st; st = en; en = t; }
-        if (st < 0) st = 0;
-        if (en > S) en = S;
-        const stp_u64 bit = 1ull << (c & 63);
-        for (int y = st; y < en; y++) STP_ATOMIC_OR(&sT[y * STP_NW + (c >> 6)], bit);
-    }
-}
-
 // helpers on one bit-row
 STP_HD int row_next_set(const stp_u64* row, int from, int S)
 {
@@ -871,6 +846,124 @@ STP_HD stp_u64 word_range_mask(int w, int lo, int hi)   // bits of word w inside
     if (b > 63) b = 63;
     stp_u64 m = (b == 63) ? ~0ull : ((1ull << (b + 1)) - 1ull);
     return m & (~0ull << a);
+}
+
+// ---- column-word forms ------------------------------------------------------------------------
+// A column of a bit matrix as 7 words (bit i of the 448-bit vector = row i; rows >= S are 0).  With the
+// column in registers, `block`'s per-row state machine advances run by run instead of row by row:
+//   a run of k ones : count += k, J = its last row;
+//   a run of z zeros: the first 5-buffer of them only fill the gap buffer; one more closes the run
+//                     (count > MAX -> MAX = count, END = J; count = buffer = 0); after that every 6th
+//                     zero closes again, which is a no-op because count is 0, so buffer = rest % 6.
+STP_HD void col_block_scan(const stp_u64* v3, const stp_u64* v, int c, int S, int minH, int16_t* t_out, int16_t* end_out,
+                           int16_t* ud_out)
+{
+    int count = 0, MAX = 0, END = 0, J = 0, buffer = 0;
+    int i = 0;
+    while (i < S) {
+        if ((v3[i >> 6] >> (i & 63)) & 1ull) {
+            const int e = row_next_clear(v3, i, S);
+            count += e - i; J = e - 1; i = e;
+        } else {
+            const int e = row_next_set(v3, i, S);
+            int z = e - i;
+            if (z <= 5 - buffer) buffer += z;
+            else {
+                z -= (5 - buffer) + 1;
+                if (count > MAX) { MAX = count; END = J; }
+                count = 0;
+                buffer = z % 6;
+            }
+            i = e;
+        }
+    }
+    if (count > MAX) { MAX = count; END = J; }
+    const int t = MAX;
+    if (END < c) END = END - t + 1;
+    int above = c < END ? c : END, bottom = c > END ? c : END;
+    if (above < 0) above = 0;
+    if (bottom > S - 1) bottom = S - 1;
+    int any = 0;
+    for (int w = above >> 6; w <= (bottom >> 6); w++) any |= (v[w] & word_range_mask(w, above, bottom)) != 0;
+    *t_out = (int16_t)t; *end_out = (int16_t)END;
+    *ud_out = (int16_t)((t > minH && any) ? (END > c ? 2 : 1) : 0);
+}
+STP_HD void col_stat(const stp_u64* tc, int S, int16_t* cnt, int16_t* minr, int16_t* maxr)
+{
+    int n = 0, mn = S, mx = -1;
+    for (int w = 0; w < STP_NW; w++) {
+        const stp_u64 x = tc[w];
+        if (!x) continue;
+#if defined(__HIP_DEVICE_COMPILE__)
+        n += __popcll(x);
+        if (mn == S) mn = (w << 6) + (__ffsll((long long)x) - 1);
+        mx = (w << 6) + 63 - __clzll((long long)x);
+#else
+        n += __builtin_popcountll(x);
+        if (mn == S) mn = (w << 6) + __builtin_ctzll(x);
+        mx = (w << 6) + 63 - __builtin_clzll(x);
+#endif
+    }
+    *cnt = (int16_t)n; *minr = (int16_t)mn; *maxr = (int16_t)mx;
+}
+// CPU-replay forms: gather the column bit by bit (the device transposes 64x64 blocks with wave shuffles)
+STP_HD void col_gather(const stp_u64* m, int S, int c, stp_u64* out)
+{
+    for (int w = 0; w < STP_NW; w++) out[w] = 0;
+    for (int r = 0; r < S; r++)
+        if ((m[r * STP_NW + (c >> 6)] >> (c & 63)) & 1ull) out[r >> 6] |= 1ull << (r & 63);
+}
+STP_HD void lines_block_cols(int tid, int nt, int S, int minH, const stp_u64* sV, const stp_u64* sV3, int16_t* colT,
+                             int16_t* colEnd, int16_t* colUd)
+{
+    for (int c = tid; c < S; c += nt) {
+        stp_u64 v[STP_NW], v3[STP_NW];
+        col_gather(sV, S, c, v);
+        col_gather(sV3, S, c, v3);
+        col_block_scan(v3, v, c, S, minH, &colT[c], &colEnd[c], &colUd[c]);
+    }
+}
+STP_HD void lines_colstat_cols(int tid, int nt, int S, const stp_u64* sT, int16_t* cnt, int16_t* minr, int16_t* maxr)
+{
+    for (int c = tid; c < S; c += nt) {
+        stp_u64 tc[STP_NW];
+        col_gather(sT, S, c, tc);
+        col_stat(tc, S, &cnt[c], &minr[c], &maxr[c]);
+    }
+}
+// V3[r][c] = V[r][c-1] | V[r][c] | V[r][c+1]  (ImageProcessing.py:122-123)
+STP_HD void lines_v3(int tid, int nt, int S, const stp_u64* sV, stp_u64* sV3)
+{
+    for (int i = tid; i < S * STP_NW; i += nt) {
+        int r = i / STP_NW, w = i - r * STP_NW;
+        const stp_u64* row = sV + r * STP_NW;
+        sV3[i] = row[w] | bm_shl1(row, w) | bm_shr1(row, w);
+    }
+}
+
+STP_HD void lines_zero(int tid, int nt, int n, stp_u64* m)
+{
+    for (int i = tid; i < n; i += nt) m[i] = 0;
+}
+
+// getStripe.py:948-955: column c painted on rows [st, en) (thread-per-column; needs LDS atomics
+// on the device because columns of one word belong to different threads)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define STP_ATOMIC_OR(p, v) atomicOr((p), (v))
+#else
+#define STP_ATOMIC_OR(p, v) (*(p) |= (v))
+#endif
+STP_HD void lines_paint(int tid, int nt, int S, int ud, const int16_t* colEnd, const int16_t* colUd, stp_u64* sT)
+{
+    for (int c = tid; c < S; c += nt) {
+        if (colUd[c] != ud) continue;
+        int st = c, en = colEnd[c];
+        if (ud == 1) { int t = st; st = en; en = t; }
+        if (st < 0) st = 0;
+        if (en > S) en = S;
+        const stp_u64 bit = 1ull << (c & 63);
+        for (int y = st; y < en; y++) STP_ATOMIC_OR(&sT[y * STP_NW + (c >> 6)], bit);
+    }
 }
 
 // getStripe.py:957-978 line refinement, thread per row

@@ -310,12 +310,41 @@ struct stp_drec {
     double total;
 };
 
+// 64 x 64 bit-block transpose across a wave: lane L holds row L (bit c = column c); afterwards lane L
+// holds column L (bit r = row r).  Recursive block swap: at block size j the off-diagonal j x j
+// sub-blocks of every 2j x 2j block are exchanged between lanes L and L ^ j.
+__device__ __forceinline__ stp_u64 wave_transpose64(stp_u64 x, int lane)
+{
+    const stp_u64 masks[6] = {0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
+                              0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        const int j = 32 >> s;
+        const stp_u64 m = masks[s];
+        const unsigned lo = __shfl_xor((unsigned)x, j), hi = __shfl_xor((unsigned)(x >> 32), j);
+        const stp_u64 p = ((stp_u64)hi << 32) | lo;
+        if ((lane & j) == 0) { const stp_u64 t = ((x >> j) ^ p) & m; x ^= (t << j); }
+        else { const stp_u64 t = ((p >> j) ^ x) & m; x ^= t; }
+    }
+    return x;
+}
+// column (64 * cg + lane) of a row-major bit matrix as 7 words, all 64 lanes of the wave cooperating
+__device__ __forceinline__ void wave_load_cols(const stp_u64* m, int S, int cg, int lane, stp_u64* col)
+{
+#pragma unroll
+    for (int k = 0; k < STP_NW; k++) {
+        const int r = 64 * k + lane;
+        const stp_u64 x = (r < S) ? m[r * STP_NW + cg] : 0ull;
+        col[k] = wave_transpose64(x, lane);
+    }
+}
+
 // K-C: hysteresis + verticalLine + block + line joining + totals, one workgroup per image, every mask
 // bit-packed in LDS.  Only TWO 22.4 KB bit matrices are resident (bufA: low -> vert, bufB: edges ->
 // testmat): after verticalLine the edge map is parked in global memory (escr, L2-resident) and re-read
 // one row per lane during refinement; the 3-column OR of `block` is formed on the fly.  53 KB of LDS
 // -> three workgroups per CU (this kernel is latency bound: serial scans, one-lane grouping).
-__global__ __launch_bounds__(512) void k_lines(const stp_u64* __restrict__ low, const stp_u64* __restrict__ high,
+__global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ low, const stp_u64* __restrict__ high,
                                                 const double* __restrict__ band, int W, int hw,
                                                 const int32_t* __restrict__ fstart, const int32_t* __restrict__ fS,
                                                 const int16_t* __restrict__ fnz, int f0, int imgs_per_frame,
@@ -358,8 +387,19 @@ __global__ __launch_bounds__(512) void k_lines(const stp_u64* __restrict__ low, 
     for (int i = tid; i < S * STP_NW; i += nt) eimg[i] = bufB[i];   // park the edge map
     __threadfence_block();
     __syncthreads();
+    lines_v3(tid, nt, S, bufA, bufB);                  // 3-column OR into the (now free) edge buffer
+    __syncthreads();
     if (dbg_stop == 3) { if (tid == 0) rec_count[img] = (int)bufA[3]; return; }
-    lines_block(tid, nt, S, minH, bufA, colT, colEnd, colUd);
+    {   // block + keep test, one column per lane held as 7 words (waves 0..6 <-> the 7 word-columns)
+        const int lane = tid & 63, cg = tid >> 6;
+        if (cg < STP_NW) {
+            stp_u64 v3[STP_NW], v[STP_NW];
+            wave_load_cols(bufB, S, cg, lane, v3);
+            wave_load_cols(bufA, S, cg, lane, v);
+            const int c = 64 * cg + lane;
+            if (c < S) col_block_scan(v3, v, c, S, minH, &colT[c], &colEnd[c], &colUd[c]);
+        }
+    }
     if (tid == 0) s_nrec = 0;
     __syncthreads();
     if (dbg_stop == 4) { if (tid == 0) rec_count[img] = colT[3]; return; }
@@ -377,7 +417,15 @@ __global__ __launch_bounds__(512) void k_lines(const stp_u64* __restrict__ low, 
         __syncthreads();
         lines_refine(tid, nt, S, eimg, bufA, bufB);
         __syncthreads();
-        lines_colstat(tid, nt, S, bufB, cnt, minr, maxr);
+        {   // column counts / first / last row from the transposed testmat
+            const int lane = tid & 63, cg = tid >> 6;
+            if (cg < STP_NW) {
+                stp_u64 tc[STP_NW];
+                wave_load_cols(bufB, S, cg, lane, tc);
+                const int c = 64 * cg + lane;
+                if (c < S) col_stat(tc, S, &cnt[c], &minr[c], &maxr[c]);
+            }
+        }
         if (want_dbg) {
             stp_u64* d = dbg + (size_t)img * 4 * (STP_FRAME_MAX * STP_NW) + (size_t)(1 + ud) * (STP_FRAME_MAX * STP_NW);
             for (int i = tid; i < S * STP_NW; i += nt) d[i] = bufB[i];

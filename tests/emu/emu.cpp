@@ -120,7 +120,8 @@ int emu_lines(const stp_u64* low, const stp_u64* high, const double* band, int W
     while (lines_hyst_sweep_strip(0, 1, S, buf0.data(), buf1.data())) sweeps++;
     if (sweeps_out) *sweeps_out = sweeps;
     lines_vline(0, 1, S, buf1.data(), buf2.data());
-    lines_block(0, 1, S, minH, buf2.data(), colT.data(), colEnd.data(), colUd.data());
+    lines_v3(0, 1, S, buf2.data(), buf0.data());
+    lines_block_cols(0, 1, S, minH, buf2.data(), buf0.data(), colT.data(), colEnd.data(), colUd.data());
     memcpy(dbg, buf1.data(), BW * 8);
     memcpy(dbg + BW, buf2.data(), BW * 8);
     for (int i = 0; i < S; i++) { cols[i] = colT[i]; cols[400 + i] = colEnd[i]; cols[800 + i] = colUd[i]; }
@@ -129,7 +130,7 @@ int emu_lines(const stp_u64* low, const stp_u64* high, const double* band, int W
         lines_zero(0, 1, S * STP_NW, buf0.data());
         lines_paint(0, 1, S, ud, colEnd.data(), colUd.data(), buf0.data());
         lines_refine(0, 1, S, buf1.data(), buf2.data(), buf0.data());
-        lines_colstat(0, 1, S, buf0.data(), cnt.data(), minr.data(), maxr.data());
+        lines_colstat_cols(0, 1, S, buf0.data(), cnt.data(), minr.data(), maxr.data());
         memcpy(dbg + (size_t)(1 + ud) * BW, buf0.data(), BW * 8);
         int nrow = 0, wcnt[8] = {0};
         lines_cols_count(0, 1, S, cnt.data(), wcnt);
