@@ -139,16 +139,19 @@ STP_HD void gray_p2(int tid, int nt, stp_tile T, int a, const double* sadj, floa
 // brightness loop needs no workgroup barrier; the blur keeps the row-major tap order of cv.filter2D.
 // sg: (GT_Y+2) x (GT_X+2) g plane of the whole tile; sadjw: 10 x (GT_X+2) doubles of this wave.
 #define GS_ROWS 8
+// sadjw holds kv * adj (kv = 1/9): every tap of cv.filter2D multiplies by the same kv, so the product
+// is formed (and rounded) once per pixel and the nine outputs that use it only add.
 STP_HD void gray_wadj(int lane, int strip, double b, const double* sg, double* sadjw)
 {
     const int WW = GT_X + 2;
     const double k = (1.0 - 0.0) / (b - 0.0);
+    const double kv = 1.0 / 9.0;
     const double* g0 = sg + (strip * GS_ROWS) * WW;          // strip rows -1 .. 8 are sg rows strip*8 .. +9
 #pragma unroll
-    for (int r = 0; r < GS_ROWS + 2; r++) sadjw[r * WW + lane + 1] = stp_bright_px(g0[r * WW + lane + 1], b, k);
+    for (int r = 0; r < GS_ROWS + 2; r++) sadjw[r * WW + lane + 1] = kv * stp_bright_px(g0[r * WW + lane + 1], b, k);
     if (lane < 2 * (GS_ROWS + 2)) {                           // the two halo columns
         const int r = lane >> 1, c = (lane & 1) ? WW - 1 : 0;
-        sadjw[r * WW + c] = stp_bright_px(g0[r * WW + c], b, k);
+        sadjw[r * WW + c] = kv * stp_bright_px(g0[r * WW + c], b, k);
     }
 }
 STP_HD void gray_wblur(int lane, int strip, stp_tile T, const double* sadjw, float* __restrict__ gray_img)
@@ -161,20 +164,20 @@ STP_HD void gray_wblur(int lane, int strip, stp_tile T, const double* sadjw, flo
     if (rb > 1.0) rb = 1.0;
     const float r32 = (float)rb;
     const int x = T.tx0 + lane;
-    double w0[3], w1[3], w2[3];                               // three rows of the 3-column window
+    double w0[3], w1[3], w2[3];                               // three rows of the 3-column window (products kv*adj)
 #pragma unroll
     for (int c = 0; c < 3; c++) { w0[c] = sadjw[0 * WW + lane + c]; w1[c] = sadjw[1 * WW + lane + c]; }
 #pragma unroll
     for (int q = 0; q < GS_ROWS; q++) {
 #pragma unroll
         for (int c = 0; c < 3; c++) w2[c] = sadjw[(q + 2) * WW + lane + c];
-        double acc = 0.0;
+        double acc = 0.0;                                     // row-major tap order of cv.filter2D
 #pragma unroll
-        for (int c = 0; c < 3; c++) acc = acc + kv * w0[c];
+        for (int c = 0; c < 3; c++) acc = acc + w0[c];
 #pragma unroll
-        for (int c = 0; c < 3; c++) acc = acc + kv * w1[c];
+        for (int c = 0; c < 3; c++) acc = acc + w1[c];
 #pragma unroll
-        for (int c = 0; c < 3; c++) acc = acc + kv * w2[c];
+        for (int c = 0; c < 3; c++) acc = acc + w2[c];
         if (acc < 0.0) acc = 0.0;
         if (acc > 1.0) acc = 1.0;
         const float g32 = (float)acc;
