@@ -466,52 +466,66 @@ __global__ __launch_bounds__(256) void k_stripe_mean(stp_bandref B, const stp_re
 // ---------------------------------------------------------------------------------------------
 // StripeSearch's medpixel = np.quantile(submat[submat > 0], 0.5) (getStripe.py:885): exact order
 // statistics over the frame's positive pixels (positive doubles order like their bit patterns).
-// a[k0], k0 = (N-1)/2, by a 5-pass radix select with 13-bit digits (8192-bin LDS histogram, bins
-// scanned in parallel); a[k1], k1 = N/2, from one more pass: it equals a[k0] when more than k1 values
-// are <= a[k0], else the smallest value above a[k0].  out[f*3 + {0,1,2}] = a[k0], a[k1], N.
+// out[f*3 + {0,1,2}] = a[k0], a[k1], N with k0 = (N-1)/2, k1 = N/2 (numpy's lerp is done on the host).
+//   pass A (inside k_frame_compact's walk): N and the min / max key;  pass B: 8192-bin histogram of the top 13 bits of (key - min)
+//   (range-normalised digits spread the pixels over the bins: no same-address LDS atomics pile-up);
+//   when the selected bin holds <= STP_MED_CAP keys (continuous data: a few dozen) pass C gathers them
+//   into LDS, tracks the smallest key of the higher bins, and ranks are counted in LDS.  Heavily
+//   duplicated data (integer counts) keeps refining 13 bits per pass and ends with a <=/successor pass.
+// One wave walks one frame row at a time (coalesced 512 B segments of the band, no index division).
 #define STP_MED_BINS 8192
+#define STP_MED_CAP 1024
 __global__ __launch_bounds__(1024) void k_medpixel(stp_bandref B, const int32_t* __restrict__ fstart,
-                                                    const int32_t* __restrict__ fn0, double* __restrict__ out)
+                                                    const int32_t* __restrict__ fn0,
+                                                    const unsigned long long* __restrict__ fstat,
+                                                    double* __restrict__ out)
 {
     __shared__ unsigned int hist[STP_MED_BINS];
     __shared__ unsigned int part[1024];
-    __shared__ unsigned long long s_prefix, s_min;
-    __shared__ unsigned int s_k, s_n, s_le;
-    const int f = blockIdx.x, tid = threadIdx.x;
+    __shared__ unsigned long long cand[STP_MED_CAP];
+    __shared__ unsigned long long s_prefix, s_hi, s_key[2];
+    __shared__ unsigned int s_k, s_le, s_cnt, s_m;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t st = fstart[f];
     const int n0 = fn0[f];
-    const int64_t tot = (int64_t)n0 * n0;
-    auto load = [&](int64_t i) -> double {
-        const int r = (int)(i / n0), c = (int)(i - (int64_t)r * n0);
-        return B.d[(st + r) * (int64_t)B.W + (c - r + B.hw)];
+    auto scan = [&](auto&& fn) {
+        for (int r = wave; r < n0; r += 16) {
+            const double* p = B.d + (st + r) * (int64_t)B.W + (B.hw - r);
+            double v[7];                        // the whole row (<= 400 pixels) in flight before any use
+#pragma unroll
+            for (int q = 0; q < 7; q++) { const int c = lane + 64 * q; v[q] = c < n0 ? p[c] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 7; q++)
+                if (v[q] > 0.0) fn((unsigned long long)__double_as_longlong(v[q]));
+        }
     };
-    if (tid == 0) { s_n = 0; s_le = 0; s_min = ~0ull; }
+    if (tid == 0) { s_le = 0; s_hi = ~0ull; s_m = 0; s_key[0] = s_key[1] = ~0ull; }
     __syncthreads();
-    unsigned int loc = 0;
-    for (int64_t i = tid; i < tot; i += 1024) loc += (load(i) > 0.0);
-    atomicAdd(&s_n, loc);
-    __syncthreads();
-    const unsigned int N = s_n;
+    // pass A (count, min and max key of the positive pixels) was done by k_frame_compact
+    const unsigned int N = (unsigned int)fstat[f * 3];
     if (N == 0) {
         if (tid == 0) { out[f * 3] = NAN; out[f * 3 + 1] = NAN; out[f * 3 + 2] = 0.0; }
         return;
     }
-    unsigned int k = (N - 1) / 2;
-    unsigned long long prefix = 0;
-    const int shifts[5] = {51, 38, 25, 12, 0};
-    const int widths[5] = {13, 13, 13, 13, 12};
-    for (int pass = 0; pass < 5; pass++) {
-        const int shift = shifts[pass], nbins = 1 << widths[pass];
+    const unsigned long long kmin = fstat[f * 3 + 1];
+    const unsigned int k0 = (N - 1) / 2, k1 = N / 2;
+    unsigned int k = k0;
+    unsigned long long prefix = 0;              // in the (key - kmin) domain
+    const unsigned long long range = fstat[f * 3 + 2] - kmin;
+    const int hb = range ? 64 - __clzll((long long)range) : 0;
+    int width = hb < 13 ? hb : 13, shift = hb - width;
+    bool gathered = false;
+    while (width > 0) {
+        const int hs = shift + width;           // hs <= 63 here except possibly the very first pass
         for (int i = tid; i < STP_MED_BINS; i += 1024) hist[i] = 0;
         __syncthreads();
-        for (int64_t i = tid; i < tot; i += 1024) {
-            const double v = load(i);
-            if (!(v > 0.0)) continue;
-            const unsigned long long key = (unsigned long long)__double_as_longlong(v);
-            const int hs = shift + widths[pass];
-            const bool match = (pass == 0) || ((key >> hs) == (prefix >> hs));
-            if (match) atomicAdd(&hist[(key >> shift) & (nbins - 1)], 1u);
-        }
+        const unsigned long long pfx_hi = hs >= 64 ? 0ull : (prefix >> hs);
+        const unsigned int dmask = (1u << width) - 1u;
+        scan([&](unsigned long long key) {
+            const unsigned long long rel = key - kmin;
+            const unsigned long long hi = hs >= 64 ? 0ull : (rel >> hs);
+            if (hi == pfx_hi) atomicAdd(&hist[(unsigned int)(rel >> shift) & dmask], 1u);
+        });
         __syncthreads();
         // parallel scan: 8 bins per lane -> partial sums -> inclusive scan -> locate the bin of rank k
         unsigned int mine = 0;
@@ -530,28 +544,59 @@ __global__ __launch_bounds__(1024) void k_medpixel(stp_bandref B, const int32_t*
             int d = tid * 8;
             for (;; d++) { if (acc + hist[d] > k) break; acc += hist[d]; }
             s_k = k - acc;
+            s_cnt = hist[d];
             s_prefix = prefix | ((unsigned long long)d << shift);
         }
         __syncthreads();
         k = s_k; prefix = s_prefix;
+        const unsigned int cnt = s_cnt;
         __syncthreads();
+        if (shift == 0) break;
+        if (cnt <= STP_MED_CAP) { gathered = true; break; }
+        width = shift < 13 ? shift : 13;
+        shift -= width;
     }
-    const unsigned long long key0 = prefix;
+    if (gathered) {
+        // pass C: keys of the selected bin -> LDS; smallest key of any higher bin = successor fallback
+        const unsigned long long sel = prefix >> shift;
+        unsigned long long hi_mn = ~0ull;
+        scan([&](unsigned long long key) {
+            const unsigned long long b = (key - kmin) >> shift;
+            if (b == sel) { const unsigned int slot = atomicAdd(&s_m, 1u); if (slot < STP_MED_CAP) cand[slot] = key; }
+            else if (b > sel && key < hi_mn) hi_mn = key;
+        });
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long a = __shfl_xor(hi_mn, o); hi_mn = a < hi_mn ? a : hi_mn; }
+        if (lane == 0 && hi_mn != ~0ull) atomicMin(&s_hi, hi_mn);
+        __syncthreads();
+        const unsigned int m = s_m < STP_MED_CAP ? s_m : STP_MED_CAP;
+        if ((unsigned int)tid < m) {
+            const unsigned long long x = cand[tid];
+            unsigned int lo = 0, le = 0;
+            for (unsigned int j = 0; j < m; j++) { const unsigned long long y = cand[j]; lo += (y < x); le += (y <= x); }
+            const unsigned int ka = k, kb = k + (k1 - k0);
+            if (lo <= ka && ka < le) s_key[0] = x;          // equal keys write the same value
+            if (lo <= kb && kb < le) s_key[1] = x;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            out[f * 3] = __longlong_as_double((long long)s_key[0]);
+            out[f * 3 + 1] = __longlong_as_double((long long)((k + (k1 - k0) < m) ? s_key[1] : s_hi));
+            out[f * 3 + 2] = (double)N;
+        }
+        return;
+    }
+    const unsigned long long key0 = kmin + prefix;
     unsigned int le = 0;
     unsigned long long mn = ~0ull;
-    for (int64_t i = tid; i < tot; i += 1024) {
-        const double v = load(i);
-        if (!(v > 0.0)) continue;
-        const unsigned long long key = (unsigned long long)__double_as_longlong(v);
+    scan([&](unsigned long long key) {
         if (key <= key0) le++;
         else if (key < mn) mn = key;
-    }
+    });
     atomicAdd(&s_le, le);
-    atomicMin(&s_min, mn);
+    atomicMin(&s_hi, mn);
     __syncthreads();
     if (tid == 0) {
-        const unsigned int k1 = N / 2;
-        const unsigned long long key1 = (s_le > k1) ? key0 : s_min;
+        const unsigned long long key1 = (s_le > k1) ? key0 : s_hi;
         out[f * 3] = __longlong_as_double((long long)key0);
         out[f * 3 + 1] = __longlong_as_double((long long)key1);
         out[f * 3 + 2] = (double)N;

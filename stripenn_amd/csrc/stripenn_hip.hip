@@ -18,29 +18,52 @@
 
 // K0: zero-column removal of every frame (getStripe.py:809-821).  One workgroup per frame,
 // one lane per column; rows are walked sequentially so the column sum has numpy's axis-0
-// order; consecutive lanes read consecutive band addresses (coalesced).
+// order (eight row loads in flight at a time); consecutive lanes read consecutive band addresses
+// (coalesced).  The same walk yields the count and the min / max bit pattern of the frame's positive
+// pixels (fstat[f*3 + {0,1,2}]), which is k_medpixel's first radix-select pass.
 __global__ __launch_bounds__(512) void k_frame_compact(const double* __restrict__ band, int W, int hw,
                                                         const int32_t* __restrict__ fstart,
                                                         const int32_t* __restrict__ fn0, int32_t* __restrict__ S_out,
-                                                        int16_t* __restrict__ nz_out)
+                                                        int16_t* __restrict__ nz_out,
+                                                        unsigned long long* __restrict__ fstat)
 {
     __shared__ int s_wave[8];
+    __shared__ unsigned long long s_n, s_mn, s_mx;
     const int f = blockIdx.x, c = threadIdx.x;
     const int64_t st = fstart[f];
     const int n0 = fn0[f];
+    if (c == 0) { s_n = 0; s_mn = ~0ull; s_mx = 0; }
     double sum = 0.0;
+    unsigned long long cnt = 0, mn = ~0ull, mx = 0;
     if (c < n0) {
-        for (int r = 0; r < n0; r++) {
-            double v = band[(st + r) * (int64_t)W + (c - r + hw)];
-            if (v != v) v = 0.0;
-            sum += v;
+        const double* p = band + st * (int64_t)W + (c + hw);
+        for (int r0 = 0; r0 < n0; r0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = (r0 + q < n0) ? p[(int64_t)(r0 + q) * (W - 1)] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                double x = v[q];
+                if (x > 0.0) {
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(x);
+                    cnt++; mn = key < mn ? key : mn; mx = key > mx ? key : mx;
+                }
+                if (x != x) x = 0.0;
+                if (r0 + q < n0) sum += x;
+            }
         }
     }
     const bool flag = (c < n0) && (sum != 0.0);
     const unsigned long long bal = __ballot(flag);
     const int lane = c & 63, wv = c >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o);
+        const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+    }
     if (lane == 0) s_wave[wv] = __popcll(bal);
     __syncthreads();
+    if (lane == 0 && cnt) { atomicAdd(&s_n, cnt); atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
     int base = 0, total = 0;
     for (int i = 0; i < 8; i++) {
         if (i < wv) base += s_wave[i];
@@ -48,7 +71,11 @@ __global__ __launch_bounds__(512) void k_frame_compact(const double* __restrict_
     }
     const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
     if (flag) nz_out[f * STP_FRAME_MAX + pos] = (int16_t)c;
-    if (c == 0) S_out[f] = (total > 10) ? total : 0;   // getStripe.py:818
+    __syncthreads();
+    if (c == 0) {
+        S_out[f] = (total > 10) ? total : 0;   // getStripe.py:818
+        fstat[f * 3] = s_n; fstat[f * 3 + 1] = s_mn; fstat[f * 3 + 2] = s_mx;
+    }
 }
 
 // K-A: image build + brightness + mean blur + grey for all brightness levels of one tile.
@@ -834,42 +861,46 @@ int stp_frames_create(stp_ctx* ctx, const stp_band* band, const int32_t* start, 
     FRCHK(hipMemcpyAsync(fr->d_start, fr->h_start.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     FRCHK(hipMemcpyAsync(fr->d_n0, fr->h_n0.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     FRCHK(hipMemsetAsync(fr->d_nz, 0, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), ctx->stream));
+    double* d_med = nullptr;
+    unsigned long long* d_fstat = nullptr;
+    FRCHK(pool_alloc(ctx, (size_t)n * 3 * sizeof(double), (void**)&d_med));
+    {
+        hipError_t ea = pool_alloc(ctx, (size_t)n * 3 * sizeof(unsigned long long), (void**)&d_fstat);
+        if (ea != hipSuccess) pool_release(ctx, d_med, (size_t)n * 3 * sizeof(double));
+        FRCHK(ea);
+    }
     {
         double bytes = 0;
         for (int i = 0; i < n; i++) bytes += 8.0 * fr->h_n0[i] * fr->h_n0[i];
         prof_scope ps(ctx, "frame_compact", bytes);
         hipLaunchKernelGGL(k_frame_compact, dim3(n), dim3(512), 0, ctx->stream, band->d, band->W, band->hw, fr->d_start,
-                           fr->d_n0, fr->d_S, fr->d_nz);
+                           fr->d_n0, fr->d_S, fr->d_nz, d_fstat);
     }
     FRCHK(hipGetLastError());
     {
         // medpixel: two order statistics per frame by radix select, numpy's lerp on the host
-        double* d_med = nullptr;
-        FRCHK(pool_alloc(ctx, (size_t)n * 3 * sizeof(double), (void**)&d_med));
-        {
-            double bytes = 0;
-            for (int i = 0; i < n; i++) bytes += 8.0 * fr->h_n0[i] * fr->h_n0[i];
-            prof_scope ps(ctx, "medpixel", bytes);
-            stp_bandref B{band->d, band->nrows, band->W, band->hw};
-            hipLaunchKernelGGL(k_medpixel, dim3(n), dim3(1024), 0, ctx->stream, B, fr->d_start, fr->d_n0, d_med);
-        }
-        std::vector<double> hm((size_t)n * 3);
-        hipError_t e1 = hipMemcpyAsync(hm.data(), d_med, hm.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-        if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
-        pool_release(ctx, d_med, (size_t)n * 3 * sizeof(double));
-        FRCHK(e1);
-        for (int i = 0; i < n; i++) {
-            const double a = hm[3 * i], b = hm[3 * i + 1], N = hm[3 * i + 2];
-            if (N < 1) { fr->h_med[i] = NAN; continue; }
-            // numpy _lerp with t = frac((N-1)*0.5): t = 0 -> a ; t = 0.5 -> b - (b-a)*(1-t)
-            const bool even = (((long long)N) % 2) == 0;
-            fr->h_med[i] = even ? (b - (b - a) * (1 - 0.5)) : (a + (b - a) * 0.0);
-        }
+        double bytes = 0;
+        for (int i = 0; i < n; i++) bytes += 8.0 * fr->h_n0[i] * fr->h_n0[i];
+        prof_scope ps(ctx, "medpixel", bytes);
+        stp_bandref B{band->d, band->nrows, band->W, band->hw};
+        hipLaunchKernelGGL(k_medpixel, dim3(n), dim3(1024), 0, ctx->stream, B, fr->d_start, fr->d_n0, d_fstat, d_med);
     }
-    FRCHK(hipMemcpyAsync(fr->h_S.data(), fr->d_S, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    FRCHK(hipMemcpyAsync(fr->h_nz.data(), fr->d_nz, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), hipMemcpyDeviceToHost,
-                         ctx->stream));
-    FRCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<double> hm((size_t)n * 3);
+    hipError_t e1 = hipMemcpyAsync(hm.data(), d_med, hm.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e1 == hipSuccess) e1 = hipMemcpyAsync(fr->h_S.data(), fr->d_S, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e1 == hipSuccess) e1 = hipMemcpyAsync(fr->h_nz.data(), fr->d_nz, (size_t)n * STP_FRAME_MAX * sizeof(int16_t),
+                                              hipMemcpyDeviceToHost, ctx->stream);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+    pool_release(ctx, d_med, (size_t)n * 3 * sizeof(double));
+    pool_release(ctx, d_fstat, (size_t)n * 3 * sizeof(unsigned long long));
+    FRCHK(e1);
+    for (int i = 0; i < n; i++) {
+        const double a = hm[3 * i], b = hm[3 * i + 1], N = hm[3 * i + 2];
+        if (N < 1) { fr->h_med[i] = NAN; continue; }
+        // numpy _lerp with t = frac((N-1)*0.5): t = 0 -> a ; t = 0.5 -> b - (b-a)*(1-t)
+        const bool even = (((long long)N) % 2) == 0;
+        fr->h_med[i] = even ? (b - (b - a) * (1 - 0.5)) : (a + (b - a) * 0.0);
+    }
 #undef FRCHK
     *out = fr;
     return STP_OK;

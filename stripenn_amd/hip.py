@@ -140,6 +140,8 @@ class Context:
     def band_upload(self, band):
         band = np.ascontiguousarray(band, dtype=np.float64)
         nrows, W = band.shape
+        if W % 2:
+            raise ValueError('band width must be 2*halfwidth (columns d = -hw .. hw-1), got %d' % W)
         return Band(self, band_host=band, nrows=nrows, hw=W // 2)
 
     def band_wrap(self, dptr, nrows, hw, keepalive=None):

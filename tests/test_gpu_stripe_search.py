@@ -132,3 +132,37 @@ def test_plateaus_and_other_parameters(hip_ctx):
                 assert [tuple(int(v) for v in q) for q in r] == [(int(a['b_index']), int(a['ud']), int(a['x']), int(a['y']), int(a['w']), int(a['h'])) for a in mine]
                 assert np.array_equal(mine['total'], tot)
     fr.close(); band.close()
+
+
+@pytest.mark.parametrize('kind', ['continuous', 'counts', 'constant', 'two_values', 'wide_range', 'small'])
+def test_medpixel_order_statistics(hip_ctx, kind):
+    """medpixel = np.quantile(D[D > 0], 0.5) (getStripe.py:885) on data that exercises every select path:
+    continuous values (LDS gather), integer counts / constants (13-bit refinement to the last digit),
+    values spanning the whole exponent range, and frames below the gather capacity."""
+    rng = np.random.default_rng(5)
+    n, hw = 900, 512
+    if kind == 'continuous':
+        A = rng.gamma(0.7, 3.0, (n, n))
+    elif kind == 'counts':
+        A = rng.poisson(1.3, (n, n)).astype(np.float64)
+    elif kind == 'constant':
+        A = np.full((n, n), 2.5)
+    elif kind == 'two_values':
+        A = rng.choice([0.0, 1.0, 1.0000000000000002], (n, n))
+    elif kind == 'wide_range':
+        A = np.exp(rng.uniform(-600, 600, (n, n)))
+    else:
+        A = rng.gamma(0.7, 3.0, (n, n)) * (rng.random((n, n)) < 0.004)
+    A = np.triu(A) + np.triu(A, 1).T
+    A[np.arange(n), np.arange(n)] += 1.0           # no empty columns
+    i = np.arange(n)[:, None]; d = np.arange(-hw, hw)[None, :]     # band[i, d + hw] = A[i, i + d]
+    j = i + d
+    band_h = np.where((j >= 0) & (j < n) & (np.abs(d) <= 399), A[i, np.clip(j, 0, n - 1)], 0.0)
+    band = hip_ctx.band_upload(np.ascontiguousarray(band_h))
+    st = np.array([0, 100, 300, 500, 0], dtype=np.int32)
+    en = np.array([299, 499, 699, 899, 20], dtype=np.int32)
+    fr = band.frames(st, en)
+    for f in range(len(st)):
+        D = A[st[f]:en[f] + 1, st[f]:en[f] + 1]
+        assert fr.medpixel[f] == np.quantile(D[D > 0], 0.5), (kind, f)
+    fr.close(); band.close()
