@@ -243,10 +243,12 @@ __device__ __forceinline__ int bg_count_ge(const double* __restrict__ srt, int n
 template <bool BIG>
 __global__ __launch_bounds__(256) void k_pvalue(stp_bandref B, const double* __restrict__ srt /* sorted lu,ru,ld,rd */,
                                                  const int* __restrict__ nvalid, int ncolbg, int bs,
-                                                 const stp_pv_stripe* __restrict__ st, double* __restrict__ out)
+                                                 const stp_pv_stripe* __restrict__ st, double* __restrict__ out, int HR)
 {
-    __shared__ double pv[STP_SCORE_MAXROWS];
-    __shared__ double part[3][STP_SCORE_MAXROWS];
+    // LDS sized by the host for the tallest stripe of the batch: pv[HR] | part[3][HR]
+    extern __shared__ double s_dyn[];
+    double* const pv = s_dyn;
+    double* const part[3] = {s_dyn + HR, s_dyn + 2 * HR, s_dyn + 3 * HR};
     __shared__ double s_res[2];
     const stp_pv_stripe s = st[blockIdx.x];
     const int h = s.row1 - s.row0;
@@ -292,14 +294,19 @@ template <bool BIG>
 __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double* __restrict__ exval,
                                                      const stp_score_stripe* __restrict__ st, double* __restrict__ out_g,
                                                      double* __restrict__ out_mean, double* __restrict__ out_total,
-                                                     int* __restrict__ out_status)
+                                                     int* __restrict__ out_status, int HR, int CW)
 {
-    __shared__ double ex[STP_NDIAG];
-    __shared__ double rowm[3][STP_SCORE_MAXROWS];
-    __shared__ double diff[STP_SCORE_MAXROWS];
-    __shared__ int16_t keepc[3][STP_SCORE_MAXCOLS];
-    __shared__ int16_t keepr[STP_SCORE_MAXROWS];
-    __shared__ uint8_t rowdel[STP_SCORE_MAXROWS];
+    // LDS sized by the host for the tallest / widest stripe of the batch (HR rows, CW columns per block):
+    // ex[400] | rowm[3][HR] | diff[max(HR, 256)] | keepr[HR] | keepc[3][CW] | rowdel[HR]
+    extern __shared__ double s_dyn[];
+    double* const ex = s_dyn;
+    double* const rowm_base = ex + STP_NDIAG;
+    double* const rowm[3] = {rowm_base, rowm_base + HR, rowm_base + 2 * HR};
+    double* const diff = rowm_base + 3 * HR;
+    int16_t* const keepr = (int16_t*)(diff + (HR > 256 ? HR : 256));
+    int16_t* const keepc_base = keepr + HR;
+    int16_t* const keepc[3] = {keepc_base, keepc_base + CW, keepc_base + 2 * CW};
+    uint8_t* const rowdel = (uint8_t*)(keepc_base + 3 * CW);
     __shared__ int nkc[3], nkr;
     __shared__ double s_res[2];
     __shared__ double s_tot;
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
     // on pixels; a benign write race sets the flag)
     if (tid < 3) nkc[tid] = 0;
     for (int b = 0; b < 3; b++)
-        for (int c = tid; c < STP_SCORE_MAXCOLS; c += nt) keepc[b][c] = 0;
+        for (int c = tid; c < CW; c += nt) keepc[b][c] = 0;
     __syncthreads();
     for (int b = 0; b < 3; b++) {
         const int w = s.col1[b] - s.col0[b];

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(512) void k_frame_compact(const double* __restrict_
 }
 
 // K-A: image build + brightness + mean blur + grey for all brightness levels of one tile.
+template <int AMAX>
 __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, int W, int hw,
                                                const int32_t* __restrict__ fstart, const int32_t* __restrict__ fS,
                                                const int16_t* __restrict__ fnz, int f0,
@@ -86,8 +87,11 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
                                                const double* __restrict__ bvals, int nb, int a,
                                                float* __restrict__ gray)
 {
-    __shared__ double sg[(GT_Y + 2 * GT_AMAX) * (GT_X + 2 * GT_AMAX)];
-    __shared__ double sadj[(GT_Y + 2 * GT_AMAX) * (GT_X + 2 * GT_AMAX)];
+    // AMAX = 1 (bfilter 3): 39 KB of LDS -> 4 workgroups per CU; the generic instance is sized for bfilter <= 7
+    constexpr int SG_N = (GT_Y + 2 * AMAX) * (GT_X + 2 * AMAX);
+    constexpr int SADJ_W = 4 * (GS_ROWS + 2) * (GT_X + 2);
+    __shared__ double sg[SG_N];
+    __shared__ double sadj[SG_N > SADJ_W ? SG_N : SADJ_W];
     const int fl = blockIdx.z, lev = blockIdx.y, f = f0 + fl;
     const int S = fS[f];
     if (S == 0) return;
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
     T.S = S; T.ty0 = (blockIdx.x / tpr) * GT_Y; T.tx0 = (blockIdx.x % tpr) * GT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
     const int tid = threadIdx.x, nt = blockDim.x;
-    if (a == 1) {
+    if (AMAX == 1) {
         // bfilter 3 (default): compaction map of the tile's rows / columns staged in LDS, then all band
         // loads of a lane issued back to back (fixed trip count, no dependent global index loads)
         __shared__ int16_t s_ny[GT_Y + 2], s_nx[GT_X + 2];
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
         gray_p0(tid, nt, band, W, hw, (int64_t)fstart[f], fnz + (size_t)f * STP_FRAME_MAX, T, a, Mlev[lev], sg);
     }
     __syncthreads();
-    if (a == 1) {
+    if (AMAX == 1) {
         // wave-strip form: no workgroup barrier in the brightness loop (LDS ops of one wave are in order)
         const int lane = tid & 63, strip = tid >> 6;
         double* sadjw = sadj + strip * ((GS_ROWS + 2) * (GT_X + 2));
@@ -983,8 +987,12 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     {
         prof_scope ps(ctx, "gray", ipx * 12.0);          // stage A of SURVEY 8(d): 8 B read + 4 B written per image px
         const int tiles = ((STP_FRAME_MAX + GT_X - 1) / GT_X) * ((STP_FRAME_MAX + GT_Y - 1) / GT_Y);
-        hipLaunchKernelGGL(k_gray, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
-                           fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray);
+        if (a == 1)
+            hipLaunchKernelGGL(k_gray<1>, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
+                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray);
+        else
+            hipLaunchKernelGGL(k_gray<GT_AMAX>, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
+                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray);
     }
     HIPCHK(hipGetLastError());
     {
@@ -1309,13 +1317,18 @@ int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int
         for (int64_t i = 0; i < n; i++) bytes += (8.0 * (st[i].col1 - st[i].col0) + 16000.0) * (st[i].row1 - st[i].row0);
         prof_scope ps(ctx, "pvalue", bytes);
         bool big = bs > 128;
-        for (int64_t i = 0; i < n && !big; i++) big = (st[i].col1 - st[i].col0) > 128;
+        int hmax = 1;
+        for (int64_t i = 0; i < n; i++) {
+            big = big || (st[i].col1 - st[i].col0) > 128;
+            hmax = std::max(hmax, (int)(st[i].row1 - st[i].row0));
+        }
+        const size_t lds = 4 * sizeof(double) * (size_t)hmax;
         if (!big)
-            hipLaunchKernelGGL(k_pvalue<false>, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bg->sorted,
-                               (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p);
+            hipLaunchKernelGGL(k_pvalue<false>, dim3((unsigned)n), dim3(256), lds, ctx->stream, bref(band), (const double*)bg->sorted,
+                               (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p, hmax);
         else
-            hipLaunchKernelGGL(k_pvalue<true>, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bg->sorted,
-                               (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p);
+            hipLaunchKernelGGL(k_pvalue<true>, dim3((unsigned)n), dim3(256), lds, ctx->stream, bref(band), (const double*)bg->sorted,
+                               (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p, hmax);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_p, bO.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1348,14 +1361,23 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
             for (int b = 0; b < 3; b++) bytes += 8.0 * (st[i].col1[b] - st[i].col0[b]) * (st[i].row1 - st[i].row0);
         prof_scope ps(ctx, "stripiness", bytes);
         bool big = false;
-        for (int64_t i = 0; i < n && !big; i++)
-            for (int b = 0; b < 3; b++) big = big || (st[i].col1[b] - st[i].col0[b]) > 128;
+        int hmax = 1, wmax = 1;
+        for (int64_t i = 0; i < n; i++) {
+            hmax = std::max(hmax, (int)(st[i].row1 - st[i].row0));
+            for (int b = 0; b < 3; b++) {
+                wmax = std::max(wmax, (int)(st[i].col1[b] - st[i].col0[b]));
+                big = big || (st[i].col1[b] - st[i].col0[b]) > 128;
+            }
+        }
+        const int HR = (hmax + 3) & ~3, CW = (wmax + 3) & ~3;     // keeps every sub-array 8-byte aligned
+        const size_t lds = sizeof(double) * (STP_NDIAG + 3 * (size_t)HR + std::max(HR, 256)) +
+                           sizeof(int16_t) * ((size_t)HR + 3 * (size_t)CW) + (size_t)HR;
         if (!big)
-            hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bE.p,
-                               (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n));
+            hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)n), dim3(256), lds, ctx->stream, bref(band), (const double*)bE.p,
+                               (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n), HR, CW);
         else
-            hipLaunchKernelGGL(k_stripiness<true>, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const double*)bE.p,
-                               (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n));
+            hipLaunchKernelGGL(k_stripiness<true>, dim3((unsigned)n), dim3(256), lds, ctx->stream, bref(band), (const double*)bE.p,
+                               (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n), HR, CW);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out_g, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
