@@ -261,17 +261,23 @@ __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, c
 // transposed vertical-pass tile (aliased later by the magnitude tile) and the smoothed tile: ~43 KB.  Blocks are mapped XCD-aware: blocks b, b+8, b+16, ... share an XCD
 // (round-robin dispatch), so they get consecutive tiles of the same (frame, level) and the overlapping
 // halos of neighbouring tiles are served by that XCD's L2.
+#ifndef STP_CANNY_MINBLK
+#define STP_CANNY_MINBLK 4
+#endif
 static __host__ __device__ size_t canny_pipe_smem_bytes(int R)
 {
     const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
     size_t fixed = (32 + 2 * VH + VH * 2 * R + VH * CT_SP) * sizeof(double);
     size_t v = (size_t)GW * CT_VP * sizeof(float);
-    size_t m = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(float);
-    return fixed + v + m;
+    // the magnitude tile and the NMS candidate queues share the vertical-pass buffer (sV is dead between
+    // the horizontal pass and the next image's vertical pass): 38.9 KB at R = 8 -> 4 workgroups per CU
+    size_t m = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(float) + 4 * 512 * sizeof(uint16_t);
+    return fixed + (v > m ? v : m);
 }
+#define CANNY_PIPE_BITS_BYTES (2 * CT_Y * 8)
 
 template <int RT>
-__global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
+__global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
                                                      int nf, int nlev, int nb, const double* __restrict__ gw,
                                                      stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_fastdiv fd)
 {
@@ -294,9 +300,9 @@ __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gr
     double* sBB = sB + 2 * VH;                   // border-column bleed-over table, VH x 2R
     double* sS = sBB + VH * 2 * R;
     float* sV = (float*)(sS + VH * CT_SP);
-    float* sM = sV + (CT_X + 2 * R + 4) * CT_VP;   // magnitude tile (f32), own slot: see the loop below
-    stp_u64* sBits = (stp_u64*)(smem + canny_pipe_smem_bytes(R));   // class bit-rows + candidate queues
-    uint16_t* sQ = (uint16_t*)(sBits + 2 * CT_Y);
+    float* sM = sV;                               // magnitude tile (f32) over the dead vertical-pass buffer
+    uint16_t* sQ = (uint16_t*)(sM + (CT_Y + 2) * (CT_X + 2));      // 4 wave queues of 512 candidates
+    stp_u64* sBits = (stp_u64*)(smem + canny_pipe_smem_bytes(R));   // class bit-rows
     const int tid = threadIdx.x, nt = blockDim.x;
     if (tid < 2 * R + 1) sW[tid] = gw[tid];
     canny_p1b(tid, nt, T, R, gw, sB);            // bleed-over factors depend on the tile geometry only
@@ -330,9 +336,7 @@ __global__ __launch_bounds__(256) void k_canny_pipe(const float* __restrict__ gr
         else canny_p3(tid, nt, T, sS, sM);
         __syncthreads();
         canny_nms_pack(tid, T, sS, sM, sQ, sBits, low + img * (STP_FRAME_MAX * STP_NW), high + img * (STP_FRAME_MAX * STP_NW));
-        // no barrier here: the next image's vertical pass touches only global memory and sV, so a wave that
-        // has finished its share of the NMS moves on; the barrier after that pass orders this NMS (reads of
-        // sS / sM, the wave-private queues) before the next horizontal pass rewrites sS
+        __syncthreads();     // sM / sQ alias sV: the NMS must be done before the next vertical pass writes it
     }
 }
 
@@ -1002,10 +1006,10 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         const stp_fastdiv fd = make_fastdiv(prm->gauss_w, R);
         const unsigned pgrid = (unsigned)(((nf * nlev + 7) / 8) * 8 * tiles);
         if (R == 8)
-            hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_NMS_BYTES, ctx->stream, d_gray,
+            hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES, ctx->stream, d_gray,
                                fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high, fd);
         else if (R == 10)
-            hipLaunchKernelGGL(k_canny_pipe<10>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_NMS_BYTES, ctx->stream, d_gray,
+            hipLaunchKernelGGL(k_canny_pipe<10>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES, ctx->stream, d_gray,
                                fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high, fd);
         else
             hipLaunchKernelGGL(k_canny, cg, dim3(256), canny_smem_bytes(R) + CANNY_NMS_BYTES, ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
