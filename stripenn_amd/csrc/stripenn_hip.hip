@@ -497,48 +497,63 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
 }
 
 // Record compaction: per-image slots -> one dense array in the reference's row order (image index
-// = (frame, level, brightness) order; slot order inside an image).  One workgroup, 1024 lanes.
+// = (frame, level, brightness) order; slot order inside an image).  Workgroup g owns 64 images: it sums
+// the counts of all earlier images (its base offset), scans its own 64 counts, and copies with 16 lanes
+// per image.  The last workgroup also publishes the total and the overflow flag.
+#define CR_IPB 64
 __global__ __launch_bounds__(1024) void k_compact_recs(const stp_drec* __restrict__ recs, const int32_t* __restrict__ cnt,
                                                         int nimg, int f0, int nlev, int nb, stp_stripe_rec* __restrict__ out,
                                                         long long cap, long long* __restrict__ total_overflow)
 {
-    __shared__ int s_part[1024];
-    __shared__ int s_over;
-    const int tid = threadIdx.x;
-    const int per = (nimg + 1023) / 1024;
-    const int i0 = tid * per, i1 = min(nimg, i0 + per);
-    if (tid == 0) s_over = 0;
-    __syncthreads();
-    int loc = 0;
-    for (int i = i0; i < i1; i++) {
+    __shared__ int s_wsum[16], s_wover[16];
+    __shared__ int s_cnt[CR_IPB], s_off[CR_IPB];
+    __shared__ long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i0 = blockIdx.x * CR_IPB;
+    const bool last = (blockIdx.x == gridDim.x - 1);
+    // base = sum of the (clamped) counts of images [0, i0); the last block also looks for overflow anywhere
+    int loc = 0, over = 0;
+    const int lim = last ? nimg : i0;
+    for (int i = tid; i < lim; i += 1024) {
         int c = cnt[i];
-        if (c > STP_RCAP) { c = STP_RCAP; s_over = 1; }
-        loc += c;
+        if (c > STP_RCAP) { c = STP_RCAP; over = 1; }
+        if (i < i0) loc += c;
     }
-    s_part[tid] = loc;
+    for (int o = 32; o > 0; o >>= 1) { loc += __shfl_xor(loc, o); over |= __shfl_xor(over, o); }
+    if (lane == 0) { s_wsum[wv] = loc; s_wover[wv] = over; }
+    if (tid < CR_IPB) {
+        int c = (i0 + tid < nimg) ? cnt[i0 + tid] : 0;
+        s_cnt[tid] = c > STP_RCAP ? STP_RCAP : c;
+    }
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {           // inclusive scan
-        int v = (tid >= o) ? s_part[tid - o] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    long long pos = s_part[tid] - loc;
-    const int ipf = nlev * nb;
-    for (int i = i0; i < i1; i++) {
-        int c = cnt[i];
-        if (c > STP_RCAP) c = STP_RCAP;
-        const int fl = i / ipf, lev = (i % ipf) / nb, bi = i % nb;
-        for (int k = 0; k < c; k++, pos++) {
-            if (pos >= cap) continue;
-            const stp_drec d = recs[(size_t)i * STP_RCAP + k];
-            stp_stripe_rec r;
-            r.frame = f0 + fl; r.level = lev; r.b_index = bi; r.ud = d.ud;
-            r.x = d.x; r.y = d.y; r.w = d.w; r.h = d.h; r.total = d.total;
-            out[pos] = r;
+    if (tid < 64) {                                   // one wave: base + exclusive scan of the 64 counts
+        int b = (lane < 16) ? s_wsum[lane] : 0, ov = (lane < 16) ? s_wover[lane] : 0;
+        for (int o = 32; o > 0; o >>= 1) { b += __shfl_xor(b, o); ov |= __shfl_xor(ov, o); }
+        const int c = s_cnt[lane];
+        int incl = c;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        s_off[lane] = incl - c;
+        if (lane == 63) {
+            s_base = b;
+            if (last) { total_overflow[0] = (long long)b + incl; total_overflow[1] = ov; }
         }
     }
-    if (tid == 1023) { total_overflow[0] = s_part[1023]; total_overflow[1] = s_over; }
+    __syncthreads();
+    const int il = tid >> 4, k0 = tid & 15, i = i0 + il;
+    if (i >= nimg) return;
+    const int c = s_cnt[il];
+    const long long pos0 = s_base + s_off[il];
+    const int ipf = nlev * nb;
+    const int fl = i / ipf, lev = (i % ipf) / nb, bi = i % nb;
+    for (int k = k0; k < c; k += 16) {
+        const long long pos = pos0 + k;
+        if (pos >= cap) continue;
+        const stp_drec d = recs[(size_t)i * STP_RCAP + k];
+        stp_stripe_rec r;
+        r.frame = f0 + fl; r.level = lev; r.b_index = bi; r.ud = d.ud;
+        r.x = d.x; r.y = d.y; r.w = d.w; r.h = d.h; r.total = d.total;
+        out[pos] = r;
+    }
 }
 
 // ============================================================================================
@@ -566,6 +581,7 @@ struct stp_ctx {
     size_t ws_bytes[WS_NSLOTS] = {0};
     void* pin = nullptr;                   // pinned host staging buffer (records)
     size_t pin_bytes = 0;
+    long long rec_guess = 0;               // records of the previous search chunk (+25 %): speculative D2H size
     // size-bucketed free lists: short-lived per-call device buffers are recycled instead of going through
     // hipMalloc / hipFree (both synchronise the device and cost ~0.1 ms each)
     std::vector<std::pair<size_t, void*>> pool_free;
@@ -1070,19 +1086,27 @@ int stp_stripe_search(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
         if (rc) return rc;
         {
             prof_scope ps(ctx, "compact_recs", (double)nimg * 4.0);
-            hipLaunchKernelGGL(k_compact_recs, dim3(1), dim3(1024), 0, ctx->stream, (const stp_drec*)pRecs,
+            hipLaunchKernelGGL(k_compact_recs, dim3((unsigned)((nimg + CR_IPB - 1) / CR_IPB)), dim3(1024), 0, ctx->stream, (const stp_drec*)pRecs,
                                (const int32_t*)pCnt, (int)nimg, f0, n_levels, nb, (stp_stripe_rec*)pOut, (long long)ocap,
                                (long long*)pTot);
         }
         HIPCHK(hipGetLastError());
+        // one round trip in the common case: the count travels with as many records as the previous
+        // chunk of this context produced (+25 %); only a larger result needs a second copy
+        const size_t guess = std::min(ocap, (size_t)ctx->rec_guess);
         HIPCHK(hipMemcpyAsync(h_tot, pTot, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        if (guess) HIPCHK(hipMemcpyAsync(h_out, pOut, guess * sizeof(stp_stripe_rec), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         const long long n = h_tot[0];
         if (h_tot[1]) overflow = true;
         if ((size_t)n > ocap) return set_err(ctx, STP_E_CAPACITY, "more than 32 candidate stripes per image on average");
+        ctx->rec_guess = n + n / 4 + 64;
         if (n > 0) {
-            HIPCHK(hipMemcpyAsync(h_out, pOut, (size_t)n * sizeof(stp_stripe_rec), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if ((size_t)n > guess) {
+                HIPCHK(hipMemcpyAsync(h_out + guess, (stp_stripe_rec*)pOut + guess, ((size_t)n - guess) * sizeof(stp_stripe_rec),
+                                      hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+            }
             for (long long k = 0; k < n; k++) {
                 if (total < cap) out[total] = h_out[k];
                 total++;
