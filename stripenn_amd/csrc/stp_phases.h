@@ -709,6 +709,82 @@ STP_HD int lines_hyst_sweep_strip(int tid, int nt, int S, const stp_u64* sLow, s
     return changed;
 }
 
+// Register form of the strip sweep (the one k_lines runs): a lane owns one item (8 rows x 1 word) for the
+// whole closure and keeps its low / E rows in registers.  A sweep first reads what it needs from the
+// other items -- the rows above / below the strip and the edge bits of the words left / right of it, all
+// loads issued up front -- then walks down and up entirely in registers (no LDS round trip per row) and
+// writes its rows back only if they grew.  Words other lanes are rewriting may be read old or new: E
+// only grows, so either is a valid lower bound, and a sweep in which nobody changed has seen final values.
+struct stp_hyst_item {
+    stp_u64 L[STP_HYST_STRIP], E[STP_HYST_STRIP];
+    int r0, w;
+};
+STP_HD stp_u64 stp_dil1(stp_u64 x) { return x | (x << 1) | (x >> 1); }
+STP_HD void hyst_item_load(int item, int S, const stp_u64* sLow, const stp_u64* sE, stp_hyst_item* it)
+{
+    const int st = item / STP_NW, w = item - st * STP_NW;
+    it->r0 = st * STP_HYST_STRIP; it->w = w;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < STP_HYST_STRIP; k++) {
+        const int r = it->r0 + k;
+        it->L[k] = (r < S) ? sLow[r * STP_NW + w] : 0ull;
+        it->E[k] = (r < S) ? sE[r * STP_NW + w] : 0ull;
+    }
+}
+STP_HD int hyst_item_sweep(int S, stp_hyst_item* it, stp_u64* sE)
+{
+    constexpr int N = STP_HYST_STRIP;
+    const int r0 = it->r0, w = it->w;
+    // carry-in bits of rows r0-1 .. r0+N from the neighbouring words: bit 0 <- left word's bit 63,
+    // bit 63 <- right word's bit 0 (bm_shl1 / bm_shr1)
+    unsigned cl = 0, cr = 0;                      // bit k: carry into row r0-1+k from the left / right word
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < N + 2; k++) {
+        const int r = r0 - 1 + k;
+        if (r >= 0 && r < S) {
+            if (w > 0) cl |= (unsigned)(sE[r * STP_NW + w - 1] >> 63) << k;
+            if (w < STP_NW - 1) cr |= (unsigned)(sE[r * STP_NW + w + 1] & 1ull) << k;
+        }
+    }
+#define STP_HYST_CIN(k) ((stp_u64)((cl >> (k)) & 1u) | ((stp_u64)((cr >> (k)) & 1u) << 63))
+    const stp_u64 up = (r0 - 1 >= 0) ? sE[(r0 - 1) * STP_NW + w] : 0ull;
+    const stp_u64 dn = (r0 + N < S) ? sE[(r0 + N) * STP_NW + w] : 0ull;
+    stp_u64 D[N + 2];                              // dilated rows r0-1 .. r0+N
+    D[0] = stp_dil1(up) | STP_HYST_CIN(0);
+    D[N + 1] = stp_dil1(dn) | STP_HYST_CIN(N + 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < N; k++) D[k + 1] = stp_dil1(it->E[k]) | STP_HYST_CIN(k + 1);
+    stp_u64 grown = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int q = 0; q < 2 * N - 1; q++) {
+        const int k = q < N ? q : 2 * N - 2 - q;  // down 0..N-1, then up N-2..0
+        const stp_u64 lowv = it->L[k], cur = it->E[k];
+        const stp_u64 seed = (D[k] | D[k + 1] | D[k + 2]) & lowv & ~cur;
+        if (seed) {
+            const stp_u64 nv = stp_runfill(lowv, seed) | cur;
+            it->E[k] = nv;
+            D[k + 1] = stp_dil1(nv) | STP_HYST_CIN(k + 1);
+            grown |= 1ull << k;
+        }
+    }
+    if (!grown) return 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < N; k++)
+        if ((grown >> k) & 1ull) sE[(r0 + k) * STP_NW + w] = it->E[k];
+    return 1;
+#undef STP_HYST_CIN
+}
+
 STP_HD void stp_fa(stp_u64 x, stp_u64 y, stp_u64 c, stp_u64* s, stp_u64* co)
 {
     stp_u64 t = x ^ y;

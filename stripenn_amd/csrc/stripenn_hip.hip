@@ -413,9 +413,15 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
     lines_load(tid, nt, S, limg, himg, bufA, bufB);
     __syncthreads();
     if (dbg_stop == 1) { if (tid == 0) rec_count[img] = (int)bufB[3]; return; }      // timing-only ablation
-    for (int it = 0; it < 4 * STP_FRAME_MAX * STP_FRAME_MAX; it++) {
-        int ch = lines_hyst_sweep_strip(tid, nt, S, bufA, bufB);
-        if (!__syncthreads_or(ch)) break;
+    {   // hysteresis closure: one (8-row strip x word) item per lane, rows held in registers across sweeps
+        const int nitem = ((S + STP_HYST_STRIP - 1) / STP_HYST_STRIP) * STP_NW;       // <= 350 < blockDim
+        const bool has = tid < nitem;
+        stp_hyst_item hit;
+        hyst_item_load(has ? tid : 0, S, bufA, bufB, &hit);
+        for (int it = 0; it < 4 * STP_FRAME_MAX * STP_FRAME_MAX; it++) {
+            const int ch = has ? hyst_item_sweep(S, &hit, bufB) : 0;
+            if (!__syncthreads_or(ch)) break;
+        }
     }
     if (dbg_stop == 2) { if (tid == 0) rec_count[img] = (int)bufB[3]; return; }
     lines_vline(tid, nt, S, bufB, bufA);               // low is dead: vert goes to bufA

@@ -117,7 +117,17 @@ int emu_lines(const stp_u64* low, const stp_u64* high, const double* band, int W
     std::vector<double> rs(400);
     lines_load(0, 1, S, low, high, buf0.data(), buf1.data());
     int sweeps = 0;
-    while (lines_hyst_sweep_strip(0, 1, S, buf0.data(), buf1.data())) sweeps++;
+    {   // k_lines' register form: every item keeps its rows across sweeps (items run in lane order here)
+        const int nitem = ((S + STP_HYST_STRIP - 1) / STP_HYST_STRIP) * STP_NW;
+        std::vector<stp_hyst_item> items(nitem);
+        for (int i = 0; i < nitem; i++) hyst_item_load(i, S, buf0.data(), buf1.data(), &items[i]);
+        for (;;) {
+            int ch = 0;
+            for (int i = 0; i < nitem; i++) ch |= hyst_item_sweep(S, &items[i], buf1.data());
+            if (!ch) break;
+            sweeps++;
+        }
+    }
     if (sweeps_out) *sweeps_out = sweeps;
     lines_vline(0, 1, S, buf1.data(), buf2.data());
     lines_v3(0, 1, S, buf2.data(), buf0.data());
