@@ -374,6 +374,89 @@ __device__ __forceinline__ void wave_load_cols(const stp_u64* m, int S, int cg, 
     }
 }
 
+// lines_group_pairs (getStripe.py:994-1078) on one wave for nrow <= 64 candidate columns, lane c <-> cidx[c].
+// The reference's grouping loop, restated per index c (a_c: cidx[c+1] == cidx[c] + 1, c <= nrow-2):
+//   * a maximal run [s..e] of adjacent columns (e > s) is flushed once: X gets round(weighted mean), the
+//     weights taken in order by the run's first lane (same f64 operation order as the serial form);
+//   * an index c <= nrow-2 outside any run is flushed as a single: X gets cidx[c];
+//   * when a run ends exactly at nrow-2, the stale [Current] left behind is flushed at the end: X gets
+//     cidx[nrow-2]; the last index is never flushed on its own; nrow <= 1 gives X = {0}.
+// X = sorted(set(...)) is a 448-bit LDS bitmap; ranks by popcount give xs[]; neighbour pairs are tested one
+// per lane and appended in order by ballot.  All lanes of the wave must call; returns the new record count.
+__device__ int lines_group_pairs_wave(int lane, int S, int ud, int maxW, int nrow, const int16_t* minr, const int16_t* maxr,
+                                      const int16_t* cidx, const int16_t* clen, int16_t* xs, stp_u64* seen, stp_lrec* recs,
+                                      int nrec, int cap)
+{
+    if (lane < STP_NW) seen[lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int ci = (lane < nrow) ? cidx[lane] : -4;
+    const int cn = (lane + 1 < nrow) ? cidx[lane + 1] : -8;
+    const bool a = (lane + 1 < nrow) && (cn - ci == 1);
+    const stp_u64 A = __ballot(a);
+    const bool aprev = lane > 0 && ((A >> (lane - 1)) & 1ull);
+    int mv = -1;                                        // the X value this lane contributes
+    if (nrow <= 1) { if (lane == 0) mv = 0; }
+    else if (a && !aprev) {                             // first lane of a run: [lane .. e]
+        const stp_u64 rest = ~A >> lane;                // a is false at nrow-1, so a zero bit exists
+        const int e = lane + __ffsll((long long)rest) - 1;
+        long ssum = 0;
+        for (int q = lane; q <= e; q++) ssum += clen[q];
+        double temp = 0.0;
+        for (int q = lane; q <= e; q++) temp = temp + (double)cidx[q] * ((double)clen[q] / (double)ssum);
+        mv = (int)nearbyint(temp);
+    } else if (!a && !aprev && lane <= nrow - 2) {
+        mv = ci;                                        // single: cidx * (clen / clen)
+    } else if (!a && aprev && lane == nrow - 2) {
+        mv = ci;                                        // stale [Current] flushed after the loop
+    }
+    if (mv >= 0 && mv < S) atomicOr((unsigned long long*)&seen[mv >> 6], 1ull << (mv & 63));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int nx = 0, rank = 0;
+#pragma unroll
+    for (int w = 0; w < STP_NW; w++) {
+        const stp_u64 v = seen[w];
+        nx += __popcll(v);
+        if (mv >= 0 && mv < S) {
+            if (w < (mv >> 6)) rank += __popcll(v);
+            else if (w == (mv >> 6)) rank += __popcll(v & ((1ull << (mv & 63)) - 1ull));
+        }
+    }
+    if (mv >= 0 && mv < S) xs[rank] = (int16_t)mv;      // equal values share a rank
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool emit = false;
+    stp_lrec r;
+    r.ud = (int16_t)ud; r.x = r.y = r.w = r.h = 0;
+    if (lane + 1 < nx) {
+        const int n = xs[lane], m = xs[lane + 1];
+        const int gap = m - n;
+        if (gap > 1 && gap <= maxW) {
+            const int p1 = gap > 4 ? m - 2 : m;
+            int MIN = S, MAX = -1;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int ctr = q ? m : n;
+                const int lo = ctr - 1 < 0 ? 0 : ctr - 1, hi = ctr + 2 > S ? S : ctr + 2;
+                for (int xx = lo; xx < hi; xx++) {
+                    if (minr[xx] < MIN) MIN = minr[xx];
+                    if (maxr[xx] > MAX) MAX = maxr[xx];
+                }
+            }
+            if (ud == 1) MAX = p1; else MIN = n;
+            r.x = (int16_t)n; r.y = (int16_t)MIN; r.w = (int16_t)(p1 - n + 1); r.h = (int16_t)(MAX - MIN + 1);
+            emit = true;
+        }
+    }
+    const stp_u64 em = __ballot(emit);
+    if (emit) {
+        const int pos = nrec + __popcll(em & ((1ull << lane) - 1ull));
+        if (pos < cap) recs[pos] = r;
+    }
+    return nrec + __popcll(em);
+}
+
 // K-C: hysteresis + verticalLine + block + line joining + totals, one workgroup per image, every mask
 // bit-packed in LDS.  Only TWO 22.4 KB bit matrices are resident (bufA: low -> vert, bufB: edges ->
 // testmat): after verticalLine the edge map is parked in global memory (escr, L2-resident) and re-read
@@ -396,6 +479,7 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
     __shared__ int16_t cidx[STP_FRAME_MAX], clen[STP_FRAME_MAX], xs[STP_FRAME_MAX + 8];
     __shared__ stp_lrec lrec[STP_RCAP];
     __shared__ int s_nrec, s_nrow, s_wcnt[8];
+    __shared__ stp_u64 s_seen[STP_NW];
     int16_t* colT = cidx;                              // block lengths: only copied out for the parity tests
     double* rs = (double*)bufB;                        // row sums: testmat is dead by then
     const int img = blockIdx.x;
@@ -476,8 +560,12 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
         __syncthreads();
         lines_cols_place(tid, nt, S, cnt, s_wcnt, cidx, clen, &s_nrow);
         __syncthreads();
-        if (tid == 0 && dbg_stop != 6)
-            s_nrec = lines_group_pairs(S, ud, maxW, s_nrow, minr, maxr, cidx, clen, xs, lrec, s_nrec, STP_RCAP);
+        if (tid < 64 && dbg_stop != 6) {               // wave 0; the serial form only for > 64 candidate columns
+            int nr;
+            if (s_nrow <= 64) nr = lines_group_pairs_wave(tid, S, ud, maxW, s_nrow, minr, maxr, cidx, clen, xs, s_seen, lrec, s_nrec, STP_RCAP);
+            else nr = (tid == 0) ? lines_group_pairs(S, ud, maxW, s_nrow, minr, maxr, cidx, clen, xs, lrec, s_nrec, STP_RCAP) : 0;
+            if (tid == 0) s_nrec = nr;
+        }
         __syncthreads();
     }
     if (dbg_stop == 5 || dbg_stop == 6) { if (tid == 0) rec_count[img] = 0; return; }
@@ -1061,7 +1149,7 @@ int stp_stripe_search(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
     if (chunk < 1) chunk = 1;
     if (chunk > fr->n) chunk = fr->n;
     const size_t cimg = (size_t)chunk * ipf;
-    const size_t ocap = cimg * 32;                       // dense records per chunk kept on the device
+    const size_t ocap = cimg * STP_RCAP;                 // dense records per chunk: every image may fill its slots
     void *pGray, *pLow, *pHigh, *pRecs, *pCnt, *pOut, *pTot, *pPar;
     HIPCHK(ws_get(ctx, WS_GRAY, cimg * STP_PITCH * STP_PITCH * sizeof(float), &pGray));
     HIPCHK(ws_get(ctx, WS_LOW, cimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), &pLow));
@@ -1105,7 +1193,7 @@ int stp_stripe_search(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
         HIPCHK(hipStreamSynchronize(ctx->stream));
         const long long n = h_tot[0];
         if (h_tot[1]) overflow = true;
-        if ((size_t)n > ocap) return set_err(ctx, STP_E_CAPACITY, "more than 32 candidate stripes per image on average");
+        if ((size_t)n > ocap) return set_err(ctx, STP_E_CAPACITY, "record compaction overran its buffer");
         ctx->rec_guess = n + n / 4 + 64;
         if (n > 0) {
             if ((size_t)n > guess) {

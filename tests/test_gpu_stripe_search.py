@@ -166,3 +166,37 @@ def test_medpixel_order_statistics(hip_ctx, kind):
         D = A[st[f]:en[f] + 1, st[f]:en[f] + 1]
         assert fr.medpixel[f] == np.quantile(D[D > 0], 0.5), (kind, f)
     fr.close(); band.close()
+
+
+def test_dense_stripes_more_than_64_candidate_columns(hip_ctx):
+    """Line joining with > 64 candidate columns per image (k_lines then runs the one-lane form of the
+    grouping instead of the one-wave form) and hundreds of records per frame, against the oracle."""
+    from stripenn_amd import synth
+    ch = synth.SynthChrom(900, 21, stripe_every=6, stripe_gain=3.0)
+    blk = ch.block(0, 900, 0, 900)
+    Ms = np.quantile(blk[blk > 0], [0.9, 0.97])
+    band = hip_ctx.band_upload(ch.band(HW))
+    st = np.array([100, 300], dtype=np.int32); en = np.array([499, 699], dtype=np.int32)
+    fr = band.frames(st, en)
+    recs = fr.stripe_search(Ms)
+    gw, gr = O.gauss_weights(2.0)
+    exp, widest = [], 0
+    for fi in range(2):
+        D, nz = O.frame_dense(ch.block, int(st[fi]), int(en[fi]))
+        D = np.ascontiguousarray(D[np.ix_(nz, nz)])
+        for li, M in enumerate(Ms):
+            r, tot = O.stripe_search(D, float(M))
+            exp += [(fi, li) + tuple(int(v) for v in r[k]) + (float(tot[k]),) for k in range(len(r))]
+            if fi == 0:
+                g = O.gplane(D, float(M))
+                for b in O.brightness_levels():
+                    E = O.canny(O.gray(g, b, 3), gw, gr)
+                    V = O.vertical_line(E)
+                    for ud in (1, 2):
+                        tm, _ = O.join_dbg(E, V, ud, 10, 8)
+                        widest = max(widest, int((tm.sum(axis=0) >= 3).sum()))
+    assert widest > 64, 'input no longer exercises the > 64 column path'
+    got = [(int(r['frame']), int(r['level']), int(r['b_index']), int(r['ud']), int(r['x']), int(r['y']), int(r['w']),
+            int(r['h']), float(r['total'])) for r in recs]
+    assert len(got) > 500 and got == exp
+    fr.close(); band.close()
