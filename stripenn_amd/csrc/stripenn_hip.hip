@@ -481,7 +481,6 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
     __shared__ int s_nrec, s_nrow, s_wcnt[8];
     __shared__ stp_u64 s_seen[STP_NW];
     int16_t* colT = cidx;                              // block lengths: only copied out for the parity tests
-    double* rs = (double*)bufB;                        // row sums: testmat is dead by then
     const int img = blockIdx.x;
     const int f = f0 + img / imgs_per_frame;
     const int S = fS[f];
@@ -573,19 +572,26 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
     const int nst = nrec < STP_RCAP ? nrec : STP_RCAP;
     stp_drec* out = recs + (size_t)img * STP_RCAP;
     const int64_t st = fstart[f];
-    for (int k = 0; k < nst; k++) {
-        stp_lrec rc = lrec[k];
-        lines_rowsum(tid, nt, S, band, W, hw, st, s_nz, rc, rs);
-        __syncthreads();
-        if (tid == 0) {
-            double tot = 0.0;
-            for (int i = 0; i < rc.h; i++) tot += rs[i];
-            stp_drec d;
-            d.ud = rc.ud; d.x = rc.x; d.y = rc.y; d.w = rc.w; d.h = rc.h; d.pad0 = d.pad1 = d.pad2 = 0;
-            d.total = tot;
-            out[k] = d;
+    {   // totals (getStripe.py:1094): one record per wave at a time -- row sums by the 64 lanes into the wave's
+        // own slice of the (now dead) bit matrices, then lane 0 adds the rows in order
+        const int wv = tid >> 6, lane = tid & 63;
+        double* rsw = (wv < 4 ? (double*)bufA : (double*)bufB) + (wv & 3) * 448;
+        for (int k = wv; k < nst; k += 8) {
+            const stp_lrec rc = lrec[k];
+            lines_rowsum(lane, 64, S, band, W, hw, st, s_nz, rc, rsw);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                double tot = 0.0;
+                for (int i = 0; i < rc.h; i++) tot += rsw[i];
+                stp_drec d;
+                d.ud = rc.ud; d.x = rc.x; d.y = rc.y; d.w = rc.w; d.h = rc.h; d.pad0 = d.pad1 = d.pad2 = 0;
+                d.total = tot;
+                out[k] = d;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
     }
     if (tid == 0) rec_count[img] = nrec;
 }
