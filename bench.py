@@ -63,32 +63,48 @@ def _cpu_task(args):
     return len(nz) * len(nz), len(recs)
 
 
-def _noop(_):
-    return 0
+def _cpu_worker(args):
+    """One pool worker: its share of the unit list, one unit after the other, until the deadline."""
+    j, cores, deadline = args
+    tasks = _G['tasks']
+    t0 = time.time()
+    px, done, t_last = 0.0, 0, t0
+    for k in range(j, len(tasks), cores):
+        if time.time() >= deadline:
+            break
+        r = _cpu_task(tasks[k])
+        px += r[0]; done += 1
+        t_last = time.time()
+    return px, done, t0, t_last
 
 
 def cpu_baseline(band_h, hw, st, en, Ms, wall_budget_s=12.0):
-    """Oracle ("port") on all host cores, time-bounded: units are handed out one by one and the clock
-    stops at the last unit completed inside the budget."""
+    """Oracle ("port") on all host cores, time-bounded: every worker walks its share of the units until
+    the deadline and returns by itself (no Pool.terminate(), which can dead-lock); the rate is the pixels of
+    all completed units over the span from the first start to the last completion."""
     import multiprocessing as mp
     from oracle import oracle as O
     O.build()
-    _G.update(band=band_h, hw=hw, st=st, en=en)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:                                    # a container CPU quota below the affinity mask is the real core count
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            cores = max(1, min(cores, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
     allt = [(fi, M) for fi in range(len(st)) for M in Ms]
-    tasks = allt * 64
-    px, done, dt = 0.0, 0, 0.0
+    _G.update(band=band_h, hw=hw, st=st, en=en, tasks=allt * 64)
     pool = mp.get_context('fork').Pool(cores)
     try:
-        pool.map(_noop, range(cores * 4))          # start the workers outside the timed region
-        t0 = time.time()
-        for r in pool.imap_unordered(_cpu_task, tasks, chunksize=1):
-            px += r[0]; done += 1
-            dt = time.time() - t0
-            if dt > wall_budget_s:
-                break
-    finally:
+        deadline = time.time() + wall_budget_s
+        res = pool.map(_cpu_worker, [(j, cores, deadline) for j in range(cores)], chunksize=1)
+        pool.close()
+        pool.join()
+    except BaseException:
         pool.terminate()
+        raise
+    px = sum(r[0] for r in res); done = sum(r[1] for r in res)
+    dt = max(r[3] for r in res) - min(r[2] for r in res)
     return {'value': round(px / dt / 1e6, 2), 'unit': 'contact-Mpx/s', 'cores': cores, 'kind': 'port',
             'sample': '%d (frame,maxpixel) units of the same chromosome (%.2fx one step), StripeSearch chain only, '
                       'oracle/stripe_oracle.c via a fork pool on %d host cores, %.1f s wall'
@@ -105,6 +121,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-score', action='store_true', help='StripeSearch chain only (skips the p-value / Stripiness set-up; for very long chromosomes)')
     args = ap.parse_args()
+
+    # the default run takes about a minute; never hang the driver: dump the stacks and exit after 20 min
+    import faulthandler
+    faulthandler.dump_traceback_later(1200, exit=True)
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
