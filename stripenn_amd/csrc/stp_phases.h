@@ -290,7 +290,7 @@ STP_HD void canny_p2(int tid, int nt, stp_tile T, int R, const double* w, const 
 // input is loaded and widened to f64 once instead of 2R+1 times.  Same operation order per output.
 // The vertical pass writes its result TRANSPOSED (sVT[x][y], pitch CT_VP) so that both passes read
 // LDS with consecutive lanes on consecutive words.
-#define CT_VRUN 12   /* vertical outputs per thread: (CT_Y + 4) = 3 * 12 */
+#define CT_VRUN 6    /* vertical outputs per thread: (CT_Y + 4) = 6 * 6; 12 would spill at 128 VGPRs */
 #define CT_HRUN 5    /* horizontal outputs per thread: ceil(68 / 5) = 14 runs x 36 rows = 504 items */
 // vertical pass reading the grey image directly (no LDS copy of the tile): consecutive lanes read
 // consecutive columns of one image row (coalesced); rows shared by neighbouring groups come from L1/L2.
