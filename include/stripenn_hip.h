@@ -61,6 +61,18 @@ int stp_ctx_synchronize(stp_ctx* ctx);
  * (getStripe.py:193,326,432,518,560,684,690,696,808): the host fetches each strip once.
  * halfwidth must be a multiple of 64 and >= 448 + 2*bs (512 covers 5 kb and 1 kb). */
 int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_t halfwidth, stp_band** out);
+/* Build the band on the device straight from cooler's pixel table (the data format one step before the
+ * path; replaces `cooler.Cooler(cool).matrix(balance=norm)` + dense `.fetch`, stripenn.py:80-118):
+ *   bin1_id <= bin2_id (global bin ids), count; pixels with either bin outside [bin_lo, bin_lo + nrows) or
+ *   with |bin2 - bin1| > halfwidth are skipped; value = (count * weight[bin1]) * weight[bin2] (cooler's
+ *   balancing rule; NaN weights give NaN), or (double)count when weight == NULL; each pixel is written at
+ *   (i, j) and mirrored at (j, i); cells without a pixel stay 0.  weight has nbins_total entries (global
+ *   bin ids).  No dense intermediate exists on either side. */
+int stp_band_pack(stp_ctx* ctx, const int64_t* bin1_id, const int64_t* bin2_id, const int32_t* count, int64_t npix,
+                  const double* weight, int64_t nbins_total, int64_t bin_lo, int64_t nrows, int32_t halfwidth,
+                  stp_band** out);
+/* Copy a band back to the host (nrows x 2*halfwidth doubles; parity tests, debugging). */
+int stp_band_download(stp_ctx* ctx, const stp_band* band, double* out_host);
 /* Adopt a band that already lives in device memory (caller keeps ownership of dptr). */
 int stp_band_wrap_device(stp_ctx* ctx, const void* dptr, int64_t nrows, int32_t halfwidth, stp_band** out);
 void stp_band_free(stp_ctx* ctx, stp_band* band);

@@ -312,3 +312,26 @@ def stripe_mean_one(block):
 def medpixel(D):
     """getStripe.py:885"""
     return float(np.quantile(D[D > 0], 0.5))
+
+
+# ------------------------------------------------------------------ band from cooler's pixel table
+def band_from_pixels(bin1, bin2, count, weight, lo, nrows, hw):
+    """CPU restatement of stp_band_pack: what `cooler.Cooler(cool).matrix(balance=...)` + dense fetch
+    (stripenn.py:80-118, getStripe.py:808) would put into the diagonal band.  value = (count * w[bin1]) *
+    w[bin2] (cooler's balancing rule; raw counts when weight is None), written at (i, j) and mirrored at
+    (j, i); cells no stored pixel names are 0.  cooler itself is absent here: parity unpinned for this reader."""
+    bin1 = np.asarray(bin1, np.int64); bin2 = np.asarray(bin2, np.int64)
+    v = np.asarray(count).astype(np.float64)
+    if weight is not None:
+        w = np.asarray(weight, np.float64)
+        v = (v * w[bin1]) * w[bin2]
+    i = bin1 - lo; j = bin2 - lo
+    ok = (i >= 0) & (j >= 0) & (i < nrows) & (j < nrows)
+    i, j, v = i[ok], j[ok], v[ok]
+    d = j - i
+    band = np.zeros((int(nrows), 2 * hw), np.float64)
+    m = (d >= -hw) & (d < hw)
+    band[i[m], d[m] + hw] = v[m]
+    m = (-d >= -hw) & (-d < hw)
+    band[j[m], hw - d[m]] = v[m]
+    return band

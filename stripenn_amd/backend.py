@@ -54,6 +54,10 @@ class HipBackend:
     def open_chrom(self, band_host):
         return self.ctx.band_upload(band_host)
 
+    def pack_chrom(self, px, hw):
+        """Band of one chromosome straight from its cis pixels (dict of stripenn_amd.pixels.PixelSelector.chrom_pixels)."""
+        return self.ctx.band_pack(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], hw)
+
     def close_chrom(self, band):
         band.close()
 

@@ -656,6 +656,25 @@ __global__ __launch_bounds__(1024) void k_compact_recs(const stp_drec* __restric
     }
 }
 
+// Band packer: one lane per stored pixel of cooler's upper-triangular table; every pixel lands in two band
+// cells (itself and its mirror image).  The band was zeroed first; cells no pixel names stay 0.
+__global__ __launch_bounds__(256) void k_band_pack(const int64_t* __restrict__ bin1, const int64_t* __restrict__ bin2,
+                                                    const int32_t* __restrict__ count, int64_t npix,
+                                                    const double* __restrict__ wloc /* weights of [lo, lo+nrows) or null */,
+                                                    int64_t lo, int64_t nrows, int W, int hw, double* __restrict__ band)
+{
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = bin1[p] - lo, j = bin2[p] - lo;
+        if (i < 0 || j < 0 || i >= nrows || j >= nrows) continue;
+        const int64_t d = j - i;
+        if (d > hw || d < -hw) continue;
+        double v = (double)count[p];
+        if (wloc) v = (v * wloc[i]) * wloc[j];
+        if (d >= -hw && d < hw) band[i * (int64_t)W + (d + hw)] = v;
+        if (-d >= -hw && -d < hw) band[j * (int64_t)W + (hw - d)] = v;
+    }
+}
+
 // ============================================================================================
 // host side
 // ============================================================================================
@@ -1058,6 +1077,64 @@ struct dev_buf {                      // per-call device buffer, recycled throug
     ~dev_buf() { if (p) { if (c) pool_release(c, p, n); else (void)hipFree(p); } }
     hipError_t alloc(stp_ctx* ctx, size_t bytes) { c = ctx; n = bytes; return pool_alloc(ctx, bytes, &p); }
 };
+
+int stp_band_pack(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2, const int32_t* count, int64_t npix,
+                  const double* weight, int64_t nbins_total, int64_t lo, int64_t nrows, int32_t hw, stp_band** out)
+{
+    if (!ctx || !out || npix < 0 || (npix > 0 && (!bin1 || !bin2 || !count))) return STP_E_ARG;
+    if (lo < 0 || (weight && lo + nrows > nbins_total)) return set_err(ctx, STP_E_ARG, "bin range outside the weight column");
+    int rc = check_hw(ctx, nrows, hw);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    stp_band* b = new (std::nothrow) stp_band();
+    if (!b) return STP_E_NOMEM;
+    b->nrows = nrows; b->hw = hw; b->W = 2 * hw; b->owned = true;
+    double* d = nullptr;
+    const size_t bytes = (size_t)nrows * b->W * sizeof(double);
+    if (hipMalloc((void**)&d, bytes) != hipSuccess) { delete b; return set_err(ctx, STP_E_NOMEM, "hipMalloc(band) failed"); }
+    const int64_t CH = (int64_t)1 << 23;                 // pixels per staged chunk (160 MB of table columns)
+    const int64_t nch = npix < CH ? npix : CH;
+    dev_buf b1, b2, bc, bw;
+    hipError_t e = hipMemsetAsync(d, 0, bytes, ctx->stream);
+    if (e == hipSuccess && nch) e = b1.alloc(ctx, (size_t)nch * sizeof(int64_t));
+    if (e == hipSuccess && nch) e = b2.alloc(ctx, (size_t)nch * sizeof(int64_t));
+    if (e == hipSuccess && nch) e = bc.alloc(ctx, (size_t)nch * sizeof(int32_t));
+    if (e == hipSuccess && weight) e = bw.alloc(ctx, (size_t)nrows * sizeof(double));
+    if (e == hipSuccess && weight)
+        e = hipMemcpyAsync(bw.p, weight + lo, (size_t)nrows * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    for (int64_t p0 = 0; e == hipSuccess && p0 < npix; p0 += CH) {
+        const int64_t n = npix - p0 < CH ? npix - p0 : CH;
+        e = hipMemcpyAsync(b1.p, bin1 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(b2.p, bin2 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(bc.p, count + p0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) break;
+        {
+            prof_scope ps(ctx, "band_pack", (double)n * 36.0);    // 20 B of table read + two 8 B cells written
+            const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 64);
+            hipLaunchKernelGGL(k_band_pack, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)b1.p, (const int64_t*)b2.p,
+                               (const int32_t*)bc.p, n, weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d);
+        }
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the staging buffers are reused
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(d); delete b;
+        return set_err(ctx, e == hipErrorOutOfMemory ? STP_E_NOMEM : STP_E_HIP, std::string("band pack: ") + hipGetErrorString(e));
+    }
+    b->d = d;
+    *out = b;
+    return STP_OK;
+}
+
+int stp_band_download(stp_ctx* ctx, const stp_band* band, double* out_host)
+{
+    if (!ctx || !band || !out_host) return STP_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(out_host, band->d, (size_t)band->nrows * band->W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return STP_OK;
+}
 
 // Interior bleed-over constant of the given Gaussian weights and exhaustive verification of the
 // multiply + 2 FMA division by it for every float mantissa (cached per weight vector).

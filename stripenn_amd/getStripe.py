@@ -107,6 +107,11 @@ class getStripe:
         nb = self._nbins(chrom)
         size = int(self.chromnames2sizes[chrom])
         hw = self.halfwidth
+        if hasattr(self.unbalLib, 'chrom_pixels') and hasattr(self.backend, 'pack_chrom'):
+            # the source IS cooler's pixel table: the device builds the band from it, no dense fetch at all
+            self._bands[chrom] = self.backend.pack_chrom(self.unbalLib.chrom_pixels(chrom), hw)
+            self.timing['band_build_s'] = self.timing.get('band_build_s', 0.0) + time.time() - t0
+            return self._bands[chrom]
         band = np.zeros((nb, 2 * hw), dtype=np.float64)
         strip = 2048
         dd = np.arange(-hw, hw)[None, :]
@@ -150,6 +155,17 @@ class getStripe:
             size = int(self.chromnames2sizes[str(CHROM)])
             sel = self.backend.select_open()
             try:
+                if hasattr(self.unbalLib, 'chrom_pixels'):
+                    # pixel-table source: the dense symmetric matrix holds every off-diagonal pixel twice
+                    from .pixels import pixel_values
+                    px = self.unbalLib.chrom_pixels(CHROM)
+                    v = pixel_values(px['count'], px['weight'], px['bin1'], px['bin2'])
+                    off = px['bin1'] != px['bin2']
+                    vo = v[off & (v > 0)]
+                    self.backend.select_append(sel, vo)
+                    self.backend.select_append(sel, vo)
+                    self.backend.select_append(sel, v[~off & (v > 0)])
+                    nb = 0
                 strip = max(1, int(16e6 // max(nb, 1)))                 # <= 128 MB of float64 per fetch
                 for r0 in range(0, nb, strip):
                     r1 = min(r0 + strip, nb)

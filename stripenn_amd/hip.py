@@ -16,7 +16,7 @@ _ERRNAMES = {-1: 'STP_E_ARG', -2: 'STP_E_CAPACITY', -3: 'STP_E_HIP', -4: 'STP_E_
 
 EXPORTS = [
     'stp_version', 'stp_ctx_create', 'stp_ctx_destroy', 'stp_last_error', 'stp_ctx_set_stream',
-    'stp_ctx_synchronize', 'stp_band_upload', 'stp_band_wrap_device', 'stp_band_free',
+    'stp_ctx_synchronize', 'stp_band_upload', 'stp_band_pack', 'stp_band_download', 'stp_band_wrap_device', 'stp_band_free',
     'stp_frames_create', 'stp_frames_info', 'stp_frames_free', 'stp_stripe_search', 'stp_dbg_stages',
     'stp_set_profiling', 'stp_get_stats', 'stp_reset_stats',
 ]
@@ -68,6 +68,8 @@ def load():
     L.stp_ctx_synchronize.argtypes = [vp]
     L.stp_band_upload.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.stp_band_wrap_device.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.stp_band_pack.argtypes = [vp, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.stp_band_download.argtypes = [vp, vp, vp]
     L.stp_band_free.argtypes = [vp, vp]
     L.stp_band_free.restype = None
     L.stp_frames_create.argtypes = [vp, vp, vp, vp, C.c_int32, C.POINTER(vp)]
@@ -144,6 +146,19 @@ class Context:
             raise ValueError('band width must be 2*halfwidth (columns d = -hw .. hw-1), got %d' % W)
         return Band(self, band_host=band, nrows=nrows, hw=W // 2)
 
+    def band_pack(self, bin1, bin2, count, weight, lo, nrows, hw):
+        """Band of bins [lo, lo + nrows) built on the device from cooler's pixel table (stp_band_pack)."""
+        bin1 = np.ascontiguousarray(bin1, dtype=np.int64)
+        bin2 = np.ascontiguousarray(bin2, dtype=np.int64)
+        count = np.ascontiguousarray(count, dtype=np.int32)
+        if not (len(bin1) == len(bin2) == len(count)):
+            raise ValueError('pixel columns differ in length')
+        w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
+        h = C.c_void_p()
+        self._chk(self.L.stp_band_pack(self.h, _ptr(bin1), _ptr(bin2), _ptr(count), len(bin1), _ptr(w),
+                                       0 if w is None else len(w), int(lo), int(nrows), int(hw), C.byref(h)))
+        return Band(self, handle=h, nrows=nrows, hw=hw)
+
     def band_wrap(self, dptr, nrows, hw, keepalive=None):
         return Band(self, dptr=dptr, nrows=nrows, hw=hw, keepalive=keepalive)
 
@@ -163,16 +178,23 @@ class Context:
 
 
 class Band:
-    def __init__(self, ctx, band_host=None, dptr=None, nrows=0, hw=0, keepalive=None):
+    def __init__(self, ctx, band_host=None, dptr=None, nrows=0, hw=0, keepalive=None, handle=None):
         self.ctx = ctx
         self.nrows, self.hw = int(nrows), int(hw)
         self.keepalive = keepalive
         h = C.c_void_p()
-        if band_host is not None:
+        if handle is not None:
+            h = handle
+        elif band_host is not None:
             ctx._chk(ctx.L.stp_band_upload(ctx.h, _ptr(band_host), self.nrows, self.hw, C.byref(h)))
         else:
             ctx._chk(ctx.L.stp_band_wrap_device(ctx.h, C.c_void_p(dptr), self.nrows, self.hw, C.byref(h)))
         self.h = h
+
+    def download(self):
+        out = np.empty((self.nrows, 2 * self.hw), dtype=np.float64)
+        self.ctx._chk(self.ctx.L.stp_band_download(self.ctx.h, self.h, _ptr(out)))
+        return out
 
     def close(self):
         if getattr(self, 'h', None) and self.ctx.h:

@@ -1,7 +1,10 @@
 """Opening the contact matrix: cooler when importable (host I/O stays cooler's, as in the reference),
-or a synthetic genome for tests / benchmarks ("synth:" URIs).
+a synthetic genome for tests / benchmarks ("synth:" URIs), or cooler's tables as plain arrays
+("pixels:" URIs, stripenn_amd.pixels) -- from which the device packs the band without dense fetches.
 
     synth:chr1=7000000,chr2=4500000;resol=5000;seed=31
+    pixels:/path/table.npz            (PixelTable.save)
+    pixels:/path/file.mcool::resolutions/5000   (h5py, when importable)
 """
 import numpy as np
 import pandas as pd
@@ -27,6 +30,14 @@ class MatrixInfo:
         return self._sel(balance)
 
 
+def pixel_matrix(table):
+    """MatrixInfo over a PixelTable: `matrix(balance=...)` returns a PixelSelector."""
+    from . import pixels
+    cols = ['chrom', 'start', 'end'] + list(table.weights)
+    return MatrixInfo(table.chromnames, table.chromsizes, table.binsize, cols,
+                      lambda balance: pixels.PixelSelector(table, balance))
+
+
 def open_matrix(cool):
     if str(cool).startswith('synth:'):
         spec = str(cool)[len('synth:'):]
@@ -40,6 +51,15 @@ def open_matrix(cool):
         _, _, sel = synth.make_genome(sizes, resol, seed0=seed, names=names)
         return MatrixInfo(names, sizes, resol, ['chrom', 'start', 'end', 'weight', 'KR', 'VC', 'VC_SQRT'],
                           lambda balance: sel)
+    if str(cool).startswith('pixels:'):
+        from . import pixels
+        spec = str(cool)[len('pixels:'):]
+        if spec.endswith('.npz'):
+            table = pixels.PixelTable.load(spec)
+        else:
+            path, _, group = spec.partition('::')
+            table = pixels.PixelTable.from_cool(path, group or None)
+        return pixel_matrix(table)
     try:
         import cooler
     except ImportError as e:

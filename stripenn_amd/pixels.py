@@ -1,0 +1,181 @@
+"""Contact matrices as cooler's own tables -- the data format on the input side of the hot path.
+
+A .cool file is three tables (cooler schema v3): ``bins`` (chrom, start, end, one column per balancing
+vector), ``pixels`` (bin1_id <= bin2_id, count; sorted by (bin1_id, bin2_id)) and ``indexes``
+(chrom_offset).  ``cooler.Cooler(...).matrix(balance=name).fetch(...)`` -- the only way the reference
+reads it (stripenn.py:80-118, getStripe.py .fetch sites) -- turns a rectangle of that table into a dense
+array: value = count * w[bin1] * w[bin2] (NaN where a weight is NaN), mirrored below the diagonal, 0 where
+no pixel is stored.  ``PixelTable`` holds the same arrays; ``PixelSelector.fetch`` is that dense read
+on the host, and ``chrom_pixels`` hands the cis pixels of one chromosome to the HIP band packer
+(``stp_band_pack``), which builds the resident diagonal band without any dense intermediate.
+
+cooler is absent from the build image (parity of this reader against cooler itself is unpinned); the
+arithmetic above is cooler's documented balancing rule.  Tables travel as .npz (``save`` / ``load``); a
+.cool / .mcool group is read through h5py when it is importable.
+"""
+import numpy as np
+
+
+class PixelTable:
+    def __init__(self, chromnames, chromsizes, binsize, chrom_offset, bin1_id, bin2_id, count, weights=None):
+        self.chromnames = [str(c) for c in chromnames]
+        self.chromsizes = np.asarray(chromsizes, dtype=np.int64)
+        self.binsize = int(binsize)
+        self.chrom_offset = np.asarray(chrom_offset, dtype=np.int64)          # len(chromnames) + 1
+        self.bin1_id = np.ascontiguousarray(bin1_id, dtype=np.int64)
+        self.bin2_id = np.ascontiguousarray(bin2_id, dtype=np.int64)
+        self.count = np.ascontiguousarray(count, dtype=np.int32)
+        self.weights = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in (weights or {}).items()}
+        if len(self.chrom_offset) != len(self.chromnames) + 1:
+            raise ValueError('chrom_offset must have one entry per chromosome plus one')
+        if not (len(self.bin1_id) == len(self.bin2_id) == len(self.count)):
+            raise ValueError('pixel columns differ in length')
+        if len(self.bin1_id) and (np.any(np.diff(self.bin1_id) < 0) or np.any(self.bin1_id > self.bin2_id)):
+            raise ValueError('pixels must be sorted by bin1_id and upper-triangular (bin1_id <= bin2_id)')
+
+    # ------------------------------------------------------------------ geometry
+    def chrom_index(self, chrom):
+        return self.chromnames.index(str(chrom))
+
+    def chrom_bins(self, chrom):
+        k = self.chrom_index(chrom)
+        return int(self.chrom_offset[k]), int(self.chrom_offset[k + 1])
+
+    def weight(self, balance):
+        """balance: False / None / 'NONE' -> raw counts; True -> 'weight'; a name -> that column."""
+        if balance in (False, None, 'NONE'):
+            return None
+        name = 'weight' if balance is True else str(balance)
+        if name not in self.weights:
+            raise ValueError('no balancing column %r in the pixel table' % name)
+        return self.weights[name]
+
+    def rows_slice(self, g0, g1):
+        """Index range of the pixels whose bin1_id lies in [g0, g1) (global bin ids)."""
+        a, b = np.searchsorted(self.bin1_id, [g0, g1], side='left')
+        return int(a), int(b)
+
+    def chrom_pixels(self, chrom):
+        """cis pixels of one chromosome (views, global bin ids) + its first bin and bin count."""
+        lo, hi = self.chrom_bins(chrom)
+        a, b = self.rows_slice(lo, hi)
+        b2 = self.bin2_id[a:b]
+        if len(b2) and b2.max() >= hi:                       # drop trans pixels
+            keep = b2 < hi
+            return self.bin1_id[a:b][keep], b2[keep], self.count[a:b][keep], lo, hi - lo
+        return self.bin1_id[a:b], b2, self.count[a:b], lo, hi - lo
+
+    # ------------------------------------------------------------------ I/O
+    def save(self, path):
+        d = dict(chromnames=np.array(self.chromnames), chromsizes=self.chromsizes, binsize=self.binsize,
+                 chrom_offset=self.chrom_offset, bin1_id=self.bin1_id, bin2_id=self.bin2_id, count=self.count)
+        for k, v in self.weights.items():
+            d['weight__' + k] = v
+        np.savez_compressed(path, **d)
+
+    @classmethod
+    def load(cls, path):
+        z = np.load(path, allow_pickle=False)
+        w = {k[len('weight__'):]: z[k] for k in z.files if k.startswith('weight__')}
+        return cls([str(c) for c in z['chromnames']], z['chromsizes'], int(z['binsize']), z['chrom_offset'],
+                   z['bin1_id'], z['bin2_id'], z['count'], w)
+
+    @classmethod
+    def from_cool(cls, path, group=None):
+        """Read the tables of a .cool file / an .mcool resolution group with h5py (no cooler needed)."""
+        import h5py
+        with h5py.File(path, 'r') as f:
+            g = f[group] if group else f
+            names = [c.decode() if isinstance(c, bytes) else str(c) for c in g['chroms/name'][:]]
+            sizes = g['chroms/length'][:]
+            binsize = int(g.attrs['bin-size'])
+            w = {k: g['bins'][k][:] for k in g['bins'].keys() if k not in ('chrom', 'start', 'end')}
+            return cls(names, sizes, binsize, g['indexes/chrom_offset'][:], g['pixels/bin1_id'][:],
+                       g['pixels/bin2_id'][:], g['pixels/count'][:], w)
+
+    @classmethod
+    def from_synth(cls, names, chroms, resol, hw_limit=None):
+        """Pixel table of synthetic chromosomes (stripenn_amd.synth.SynthChrom): the raw counts of the upper
+        triangle, a 'weight' column (NaN on the masked bins) when the chromosome is balanced."""
+        from . import synth
+        b1, b2, cn, ws, off, sizes = [], [], [], [], [0], []
+        for nm in names:
+            ch = chroms[nm]
+            lo = off[-1]
+            lim = synth.BAND_LIMIT if hw_limit is None else int(hw_limit)
+            for r0 in range(0, ch.nbins, 2048):
+                r1 = min(r0 + 2048, ch.nbins)
+                c1 = min(r1 + lim, ch.nbins)
+                cnt = ch.counts(r0, r1, r0, c1)
+                ii, jj = np.nonzero(cnt)
+                keep = (jj + r0) >= (ii + r0)
+                ii, jj = ii[keep], jj[keep]
+                b1.append(ii + r0 + lo); b2.append(jj + r0 + lo); cn.append(cnt[ii, jj].astype(np.int32))
+            w = ch.w.astype(np.float64).copy()
+            w[ch.nan_bins] = np.nan
+            ws.append(w)
+            off.append(lo + ch.nbins)
+            sizes.append(ch.nbins * int(resol))
+        weights = {'weight': np.concatenate(ws)} if any(chroms[n].balanced for n in names) else {}
+        return cls(names, sizes, resol, off, np.concatenate(b1), np.concatenate(b2), np.concatenate(cn), weights)
+
+
+def pixel_values(count, weight, bin1, bin2):
+    """cooler's balanced value of each stored pixel: (count * w[bin1]) * w[bin2]; raw counts when weight is None."""
+    v = count.astype(np.float64)
+    if weight is not None:
+        v = (v * weight[bin1]) * weight[bin2]
+    return v
+
+
+class PixelSelector:
+    """``cooler.Cooler(...).matrix(balance=...)`` over a PixelTable: ``fetch(region[, region2])`` with cooler's
+    extent rule (0-based half-open bp intervals; bins lo = start // binsize, hi = ceil(end / binsize))."""
+
+    def __init__(self, table, balance=True):
+        self.table = table
+        self.balance = balance
+        self.w = table.weight(balance)
+        self.resol = table.binsize
+        self.nfetch = 0
+
+    def _extent(self, region):
+        region = str(region)
+        t = self.table
+        if ':' not in region:
+            lo, hi = t.chrom_bins(region)
+            return region, 0, hi - lo
+        name, rng = region.rsplit(':', 1)
+        s, e = rng.replace(',', '').split('-')
+        s, e = int(s), int(e)
+        lo, hi = t.chrom_bins(name)
+        if s < 0 or e > (hi - lo) * self.resol or s > e:
+            raise ValueError('Genomic region out of bounds: %s' % region)
+        return name, s // self.resol, -(-e // self.resol)
+
+    def chrom_pixels(self, chrom):
+        b1, b2, cn, lo, n = self.table.chrom_pixels(chrom)
+        return dict(bin1=b1, bin2=b2, count=cn, weight=self.w, lo=lo, nrows=n)
+
+    def fetch(self, region, region2=None):
+        self.nfetch += 1
+        n1, r0, r1 = self._extent(region)
+        n2, c0, c1 = (n1, r0, r1) if region2 is None else self._extent(region2)
+        if n1 != n2:
+            raise ValueError('trans fetch is not on the stripenn path')
+        t = self.table
+        lo, _ = t.chrom_bins(n1)
+        out = np.zeros((r1 - r0, c1 - c0), dtype=np.float64)
+        R0, R1, C0, C1 = r0 + lo, r1 + lo, c0 + lo, c1 + lo
+        # stored pixels (bin1 in rows, bin2 in cols), then their mirror images (bin2 in rows, bin1 in cols)
+        for (A0, A1, B0, B1, mirror) in ((R0, R1, C0, C1, False), (C0, C1, R0, R1, True)):
+            a, b = t.rows_slice(A0, A1)
+            b1 = t.bin1_id[a:b]; b2 = t.bin2_id[a:b]
+            keep = (b2 >= B0) & (b2 < B1)
+            b1, b2 = b1[keep], b2[keep]
+            v = pixel_values(t.count[a:b][keep], self.w, b1, b2)
+            if mirror:
+                out[b2 - R0, b1 - C0] = v
+            else:
+                out[b1 - R0, b2 - C0] = v
+        return out

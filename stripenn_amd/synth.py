@@ -77,8 +77,8 @@ class SynthChrom:
                 else:
                     self._s_lo[c], self._s_hi[c] = max(a - L, 0), a + wd - 1
 
-    def block(self, r0, r1, c0, c1):
-        """Dense float64 block rows [r0, r1) x cols [c0, c1) (bin indices, must be in range)."""
+    def counts(self, r0, r1, c0, c1):
+        """Raw (unweighted) counts of rows [r0, r1) x cols [c0, c1): integer-valued float64, symmetric."""
         r = np.arange(r0, r1, dtype=np.int64)[:, None]
         c = np.arange(c0, c1, dtype=np.int64)[None, :]
         lo = np.minimum(r, c)
@@ -98,7 +98,11 @@ class SynthChrom:
         lam = np.where(in1 | in2, lam * self.stripe_gain, lam)
         cnt = np.floor(lam + np.sqrt(lam) * z + 0.5)
         cnt = np.where(cnt < 0.0, 0.0, cnt)
-        cnt = np.where(d > BAND_LIMIT, 0.0, cnt)
+        return np.where(d > BAND_LIMIT, 0.0, cnt)
+
+    def block(self, r0, r1, c0, c1):
+        """Dense float64 block rows [r0, r1) x cols [c0, c1) (bin indices, must be in range)."""
+        cnt = self.counts(r0, r1, c0, c1)
         val = (cnt * self.w[r0:r1][:, None]) * self.w[c0:c1][None, :]
         if self.nan_bins.size:
             val = np.where(self.nanflag[r0:r1][:, None] | self.nanflag[c0:c1][None, :], np.nan, val)

@@ -57,6 +57,9 @@ class OracleBackend:
     def open_chrom(self, band_host):
         return _Band(band_host)
 
+    def pack_chrom(self, px, hw):
+        return _Band(O.band_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], hw))
+
     def close_chrom(self, band):
         pass
 

@@ -1,0 +1,87 @@
+"""stp_band_pack on the GPU: the band built from cooler's pixel table equals the CPU restatement bit for
+bit (NaN positions included), and the compute pipeline fed from a pixel table reproduces the dense route."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from stripenn_amd import backend as BK, io as sio, pixels, stripenn, synth
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings('ignore')
+RESOL = 5000
+
+
+def _same(a, b):
+    return a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+
+
+def test_packed_band_equals_restatement(hip_ctx):
+    names = ['chrA', 'chrB']
+    chroms = {'chrA': synth.SynthChrom(900, 41), 'chrB': synth.SynthChrom(1300, 42, nan_frac=0.02)}
+    t = pixels.PixelTable.from_synth(names, chroms, RESOL)
+    for balance in (True, False):
+        sel = pixels.PixelSelector(t, balance)
+        for nm in names:
+            px = sel.chrom_pixels(nm)
+            for hw in (512, 576):
+                exp = O.band_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], hw)
+                band = hip_ctx.band_pack(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], hw)
+                assert _same(band.download(), exp), (balance, nm, hw)
+                band.close()
+    # the whole table at once: trans-free here, but bins outside [lo, lo + nrows) must be skipped
+    lo, hi = t.chrom_bins('chrB')
+    band = hip_ctx.band_pack(t.bin1_id, t.bin2_id, t.count, t.weights['weight'], lo, hi - lo, 512)
+    exp = O.band_from_pixels(t.bin1_id, t.bin2_id, t.count, t.weights['weight'], lo, hi - lo, 512)
+    assert _same(band.download(), exp) and np.isnan(exp).any()
+    # and the packed band is what the search consumes: same frames as the uploaded host band
+    up = hip_ctx.band_upload(exp)
+    st = np.array([0, 100, 300], np.int32); en = np.array([299, 499, 699], np.int32)
+    fa, fb = band.frames(st, en), up.frames(st, en)
+    assert np.array_equal(fa.S, fb.S) and np.array_equal(fa.nz, fb.nz) and np.array_equal(fa.medpixel, fb.medpixel)
+    fa.close(); fb.close(); up.close(); band.close()
+    with pytest.raises(ValueError):
+        hip_ctx.band_pack(t.bin1_id[:5], t.bin2_id[:4], t.count[:5], None, 0, 900, 512)
+
+
+def test_pack_chromosome_sized_table_in_chunks(hip_ctx):
+    """chr16-size chromosome: > 8 M stored pixels, i.e. more than one staging chunk."""
+    ch = synth.SynthChrom(19642, 16)
+    t = pixels.PixelTable.from_synth(['chr16'], {'chr16': ch}, RESOL)
+    assert len(t.count) > (1 << 23)
+    px = pixels.PixelSelector(t, True).chrom_pixels('chr16')
+    band = hip_ctx.band_pack(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], 512)
+    exp = O.band_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], 512)
+    assert _same(band.download(), exp)
+    band.close()
+
+
+def test_compute_from_pixel_table_equals_dense_route(tmp_path, monkeypatch):
+    names = ['chrA', 'chrB']
+    chroms = {'chrA': synth.SynthChrom(1500, 51, stripe_every=90, stripe_gain=3.0),
+              'chrB': synth.SynthChrom(1100, 52, stripe_every=90, stripe_gain=3.0)}
+    t = pixels.PixelTable.from_synth(names, chroms, RESOL)
+    p = str(tmp_path / 't.npz')
+    t.save(p)
+
+    class FetchOnly:
+        def __init__(self, sel):
+            self._sel = sel
+
+        def fetch(self, *a):
+            return self._sel.fetch(*a)
+
+    outs = []
+    for route in ('pixels', 'dense'):
+        if route == 'dense':
+            monkeypatch.setattr(stripenn, 'open_matrix', lambda cool: sio.MatrixInfo(
+                t.chromnames, t.chromsizes, t.binsize, ['chrom', 'start', 'end', 'weight'],
+                lambda balance: FetchOnly(pixels.PixelSelector(t, balance))))
+        out = str(tmp_path / route)
+        stripenn.compute('pixels:' + p, out, 'weight', 'all', 2.0, 10, 8, '0.95,0.97,0.99', 1, 0.5, '0', False, 3, 7,
+                         force=True)
+        outs.append([open(os.path.join(out, f)).read() for f in ('result_unfiltered.tsv', 'result_filtered.tsv')])
+    assert outs[0] == outs[1]
+    assert outs[0][0].count('\n') > 10

@@ -1,0 +1,110 @@
+"""cooler's pixel table as the input format (stripenn_amd/pixels.py): the host dense read, the .npz
+round trip, the band restatement, and the whole compute pipeline fed from pixels vs from dense fetches
+(oracle backend; the HIP packer is checked in test_gpu_pixels.py)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle_backend import OracleBackend
+from stripenn_amd import io as sio, pixels, stripenn, synth
+
+warnings.filterwarnings('ignore')
+RESOL = 5000
+
+
+class FetchOnly:
+    """A selector that offers nothing but cooler's `fetch` (forces the dense route of the facade)."""
+
+    def __init__(self, sel):
+        self._sel = sel
+
+    def fetch(self, *a):
+        return self._sel.fetch(*a)
+
+
+def _genome(nbins=(900, 700), seed=41, **kw):
+    names = ['chrA', 'chrB'][:len(nbins)]
+    chroms = {n: synth.SynthChrom(nb, seed + k, **kw) for k, (n, nb) in enumerate(zip(names, nbins))}
+    return names, chroms, pixels.PixelTable.from_synth(names, chroms, RESOL)
+
+
+def _dense_cooler_rule(ch):
+    """Independent dense construction of cooler's balanced matrix of one synthetic chromosome."""
+    n = ch.nbins
+    cnt = ch.counts(0, n, 0, n)
+    w = ch.w.copy(); w[ch.nan_bins] = np.nan
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing='ij')
+    lo, hi = np.minimum(i, j), np.maximum(i, j)
+    with np.errstate(invalid='ignore'):
+        val = (cnt * w[lo]) * w[hi]
+    return np.where(cnt > 0, val, 0.0)
+
+
+def test_selector_fetch_is_coolers_dense_read():
+    names, chroms, t = _genome()
+    sel = pixels.PixelSelector(t, True)
+    for nm in names:
+        D = _dense_cooler_rule(chroms[nm])
+        n = chroms[nm].nbins
+        assert np.array_equal(sel.fetch(nm), D, equal_nan=True)
+        got = sel.fetch('%s:%d-%d' % (nm, 100 * RESOL + 1, 300 * RESOL), '%s:%d-%d' % (nm, 40 * RESOL, n * RESOL))
+        assert np.array_equal(got, D[100:300, 40:n], equal_nan=True)
+    raw = pixels.PixelSelector(t, False).fetch('chrB')
+    assert np.array_equal(raw, chroms['chrB'].counts(0, 700, 0, 700))
+    with pytest.raises(ValueError):
+        sel.fetch('chrA:0-%d' % (901 * RESOL))
+    with pytest.raises(ValueError):
+        pixels.PixelSelector(t, 'KR')
+
+
+def test_table_validation_and_npz_round_trip(tmp_path):
+    names, chroms, t = _genome()
+    p = str(tmp_path / 't.npz')
+    t.save(p)
+    u = pixels.PixelTable.load(p)
+    assert u.chromnames == t.chromnames and u.binsize == t.binsize
+    for a in ('chromsizes', 'chrom_offset', 'bin1_id', 'bin2_id', 'count'):
+        assert np.array_equal(getattr(u, a), getattr(t, a))
+    assert np.array_equal(u.weights['weight'], t.weights['weight'], equal_nan=True)
+    with pytest.raises(ValueError):
+        pixels.PixelTable(['c'], [10 * RESOL], RESOL, [0, 10], [3, 1], [4, 2], [1, 1])      # unsorted
+    with pytest.raises(ValueError):
+        pixels.PixelTable(['c'], [10 * RESOL], RESOL, [0, 10], [5], [4], [1])                # lower triangle
+    info = sio.open_matrix('pixels:' + p)
+    assert list(info.chromnames) == names and info.binsize == RESOL and 'weight' in info.bins().columns
+
+
+def test_band_restatement_equals_dense_route():
+    names, chroms, t = _genome()
+    sel = pixels.PixelSelector(t, True)
+    for nm in names:
+        px = sel.chrom_pixels(nm)
+        band = O.band_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], 512)
+        D = sel.fetch(nm)
+        n = px['nrows']
+        i = np.arange(n)[:, None]; j = i + np.arange(-512, 512)[None, :]
+        exp = np.where((j >= 0) & (j < n), D[i, np.clip(j, 0, n - 1)], 0.0)
+        assert np.array_equal(band, exp, equal_nan=True)
+
+
+def test_compute_from_pixels_equals_compute_from_dense_fetches(tmp_path, monkeypatch):
+    """The pipeline fed by the band packer + pixel-multiset quantile gives the same TSVs as the dense route."""
+    names, chroms, t = _genome(nbins=(900, 700), stripe_every=90, stripe_gain=3.0)
+    p = str(tmp_path / 't.npz')
+    t.save(p)
+    gw = O.gauss_weights(2.0)[0]
+    outs = []
+    for route in ('pixels', 'dense'):
+        if route == 'dense':
+            monkeypatch.setattr(stripenn, 'open_matrix', lambda cool: sio.MatrixInfo(
+                t.chromnames, t.chromsizes, t.binsize, ['chrom', 'start', 'end', 'weight'],
+                lambda balance: FetchOnly(pixels.PixelSelector(t, balance))))
+        out = str(tmp_path / route)
+        stripenn.compute('pixels:' + p, out, 'weight', 'all', 2.0, 10, 8, '0.97,0.99', 1, 0.5, '0', False, 3, 7,
+                         force=True, backend=OracleBackend(gauss_w=gw))
+        outs.append([open(os.path.join(out, f)).read() for f in ('result_unfiltered.tsv', 'result_filtered.tsv')])
+    assert outs[0] == outs[1]
+    assert outs[0][0].count('\n') > 5
