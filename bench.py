@@ -226,9 +226,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    contact_px = float((S.astype(np.float64) ** 2).sum()) * len(Ms)   # per rank per step
+    contact_px = float((S.astype(np.float64) ** 2).sum()) * len(Ms)   # this rank, per step
     image_px = contact_px * 6
-    value = world * contact_px * args.steps / dt / 1e6
+    total_px = contact_px                                              # all ranks (each has its own chromosome)
+    if world > 1:
+        tsum = torch.tensor([contact_px], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        total_px = float(tsum.item())
+    value = total_px * args.steps / dt / 1e6
 
     out = None
     if rank == 0:
@@ -253,7 +258,7 @@ def main():
                                       '0.95-0.99 x 6 brightness levels: frame compaction + StripeSearch chain + p-value and '
                                       'Stripiness of every candidate stripe' % (nb, len(st)),
                           'frames': int(len(st)), 'levels': len(Ms), 'images_per_step': int(len(st) * len(Ms) * 6),
-                          'contact_px_per_step': contact_px, 'stripe_records': int(len(recs)),
+                          'contact_px_per_step': total_px, 'stripe_records': int(len(recs)),
                           'sharding': 'one chromosome per rank, no collective'},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
