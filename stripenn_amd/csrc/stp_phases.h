@@ -295,7 +295,8 @@ STP_HD void canny_p2(int tid, int nt, stp_tile T, int R, const double* w, const 
 // vertical pass reading the grey image directly (no LDS copy of the tile): consecutive lanes read
 // consecutive columns of one image row (coalesced); rows shared by neighbouring groups come from L1/L2.
 // YIN: every row this tile touches (ty0-R-2 .. ty0+CT_Y+R+1) lies inside the image -> no clamping.
-template <int R, bool YIN>
+// XIN: every column the tile touches (tx0-R-2 .. tx0+CT_X+R+1) lies inside the image -> no column select.
+template <int R, bool YIN, bool XIN = false>
 STP_HD void canny_p1_blk_g(int tid, int nt, stp_tile T, const double* w, const float* __restrict__ gimg, float* sVT)
 {
     const int GW = CT_X + 2 * R + 4;
@@ -304,8 +305,8 @@ STP_HD void canny_p1_blk_g(int tid, int nt, stp_tile T, const double* w, const f
         const int xx = i % GW, yg = i / GW;
         const int yy0 = yg * CT_VRUN;
         const int x = T.tx0 - R - 2 + xx;
-        const int xc = x < 0 ? 0 : (x > T.S - 1 ? T.S - 1 : x);
-        const bool xin = (x == xc);
+        const int xc = XIN ? x : (x < 0 ? 0 : (x > T.S - 1 ? T.S - 1 : x));
+        const bool xin = XIN || (x == xc);
         float raw[CT_VRUN + 2 * R];
         if (YIN) {
             const float* col = gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + xc;
@@ -473,6 +474,15 @@ STP_HD void ct_sobel(const double* sS, stp_tile T, int y, int x, double* is, dou
     ct_sobel_off(c, y > 0 ? -CT_SP : 0, y < T.S - 1 ? CT_SP : 0, x > 0 ? -1 : 0, x < T.S - 1 ? 1 : 0, is, js);
 }
 
+// approximate quotient of two non-negative floats with num <= den (hardware reciprocal on the device)
+STP_HD float stp_fdiv32(float num, float den)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return num * __builtin_amdgcn_rcpf(den);
+#else
+    return num / den;
+#endif
+}
 // approximate magnitude (float, one hardware sqrt): relative error < 3e-7, see ct_nms
 STP_HD float stp_mag32(double is, double js)
 {
@@ -517,7 +527,7 @@ STP_HD void canny_p3(int tid, int nt, stp_tile T, const double* sS, float* sM)
 // rounded to float and one hardware square root, relative error < 3e-7 (2^-24 for the rounding, at most
 // 1 ulp(float) for v_sqrt_f32).  A decision taken from h0 values equals the reference's whenever the
 // compared quantities differ by more than the propagated error (< 1e-6 of the largest magnitude
-// involved).  We accept it only when the gap exceeds 1e-5 of that magnitude and the thresholds 0.1 /
+// involved; the float interpolation weight adds < 3e-7 of it).  We accept it only when the gap exceeds 1e-5 of that magnitude and the thresholds 0.1 /
 // 0.2 are missed by more than 1e-6; otherwise (ties, plateaus, near-ties) the five magnitudes are
 // recomputed with the exact glibc kernel (stp_hypot) and the reference's test is evaluated literally.
 // The fallback is taken by ~1e-5 of the candidates on noisy data, by thousands on synthetic plateaus.
@@ -536,14 +546,18 @@ STP_HD int ct_nms(const double* sS, const float* sM, stp_tile T, int y, int x)
     // the LAST matching sector decides (assignment order in _canny.py); the "minus" side neighbours are
     // the mirror images of the "plus" side ones
     int dy1, dx1, dy2, dx2;
-    double wq;
-    if (opp && ai >= aj) { wq = aj / ai; dy1 = -1; dx1 = 0; dy2 = -1; dx2 = 1; }        // 135-180
-    else if (opp && ai <= aj) { wq = ai / aj; dy1 = 0; dx1 = 1; dy2 = -1; dx2 = 1; }    // 90-135
-    else if (same && ai <= aj) { wq = ai / aj; dy1 = 0; dx1 = 1; dy2 = 1; dx2 = 1; }    // 45-90
-    else if (same && ai >= aj) { wq = aj / ai; dy1 = 1; dx1 = 0; dy2 = 1; dx2 = 1; }    // 0-45
+    double num, den;
+    if (opp && ai >= aj) { num = aj; den = ai; dy1 = -1; dx1 = 0; dy2 = -1; dx2 = 1; }        // 135-180
+    else if (opp && ai <= aj) { num = ai; den = aj; dy1 = 0; dx1 = 1; dy2 = -1; dx2 = 1; }    // 90-135
+    else if (same && ai <= aj) { num = ai; den = aj; dy1 = 0; dx1 = 1; dy2 = 1; dx2 = 1; }    // 45-90
+    else if (same && ai >= aj) { num = aj; den = ai; dy1 = 1; dx1 = 0; dy2 = 1; dx2 = 1; }    // 0-45
     else return 0;
     const int o1 = dy1 * MW + dx1, o2 = dy2 * MW + dx2;
-    const double omw = 1.0 - wq;
+    // interpolation weight: a float quotient (relative error < 3e-7, |w| <= 1) is enough for the certified
+    // test below -- it moves lp / lm by < 3e-7 of the largest magnitude; the exact quotient is formed only
+    // when the decision has to be re-evaluated literally
+    double wq = (double)stp_fdiv32((float)num, (float)den);
+    double omw = 1.0 - wq;
     double m = m0, c1p = (double)mp[o1], c2p = (double)mp[o2], c1m = (double)mp[-o1], c2m = (double)mp[-o2];
     double lp = c2p * wq + c1p * omw, lm = c2m * wq + c1m * omw;
     double big = m0;
@@ -552,6 +566,7 @@ STP_HD int ct_nms(const double* sS, const float* sM, stp_tile T, int y, int x)
     const bool certain = fabs(lp - m0) > tol && fabs(lm - m0) > tol && fabs(m0 - 0.1) > 1e-6 && fabs(m0 - 0.2) > 1e-6;
     if (!certain) {                         // exact re-evaluation (glibc hypot of the five pixels)
         double is, js;
+        wq = num / den; omw = 1.0 - wq;
         m = stp_hypot(gi, gj);
         ct_sobel(sS, T, y + dy1, x + dx1, &is, &js); c1p = stp_hypot(is, js);
         ct_sobel(sS, T, y + dy2, x + dx2, &is, &js); c2p = stp_hypot(is, js);

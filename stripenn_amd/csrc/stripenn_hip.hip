@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
     for (int bi = 0; bi < nb; bi++) {
         const size_t img = img0 + bi;
         const float* gimg = gray + img * (STP_PITCH * STP_PITCH);
-        if (yin) canny_p1_blk_g<R, true>(tid, nt, T, sW, gimg, sV);
+        if (yin && xin) canny_p1_blk_g<R, true, true>(tid, nt, T, sW, gimg, sV);
+        else if (yin) canny_p1_blk_g<R, true>(tid, nt, T, sW, gimg, sV);
         else canny_p1_blk_g<R, false>(tid, nt, T, sW, gimg, sV);
         __syncthreads();
 #if defined(STP_ABLATE_CANNY_P1)      /* timing-only build: vertical pass only */

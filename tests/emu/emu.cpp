@@ -78,13 +78,17 @@ void emu_canny2(const float* gray /* pitch 400 */, int S, int R, const double* w
             if (R == 8 && blocked) {       // the device path for sigma 2.0 (k_canny_pipe<8>)
                 std::vector<double> sBB(VH * 16);
                 if (!xin) canny_p1c<8>(0, 1, T, w, sB.data(), sBB.data());
-                if (yin) canny_p1_blk_g<8, true>(0, 1, T, w, gray, sV.data()); else canny_p1_blk_g<8, false>(0, 1, T, w, gray, sV.data());
+                if (yin && xin) canny_p1_blk_g<8, true, true>(0, 1, T, w, gray, sV.data());
+                else if (yin) canny_p1_blk_g<8, true>(0, 1, T, w, gray, sV.data());
+                else canny_p1_blk_g<8, false>(0, 1, T, w, gray, sV.data());
                 if (xin) canny_p2_blk<8, true>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data(), fd);
                 else canny_p2_blk<8, false>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data(), fd);
             } else if (R == 10 && blocked) {
                 std::vector<double> sBB(VH * 20);
                 if (!xin) canny_p1c<10>(0, 1, T, w, sB.data(), sBB.data());
-                if (yin) canny_p1_blk_g<10, true>(0, 1, T, w, gray, sV.data()); else canny_p1_blk_g<10, false>(0, 1, T, w, gray, sV.data());
+                if (yin && xin) canny_p1_blk_g<10, true, true>(0, 1, T, w, gray, sV.data());
+                else if (yin) canny_p1_blk_g<10, true>(0, 1, T, w, gray, sV.data());
+                else canny_p1_blk_g<10, false>(0, 1, T, w, gray, sV.data());
                 if (xin) canny_p2_blk<10, true>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data(), fd);
                 else canny_p2_blk<10, false>(0, 1, T, w, sV.data(), sB.data(), sBB.data(), sS.data(), fd);
             } else {
