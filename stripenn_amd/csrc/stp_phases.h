@@ -292,6 +292,8 @@ STP_HD void canny_p2(int tid, int nt, stp_tile T, int R, const double* w, const 
 // LDS with consecutive lanes on consecutive words.
 #define CT_VRUN 6    /* vertical outputs per thread: (CT_Y + 4) = 6 * 6; 12 would spill at 128 VGPRs */
 #define CT_HRUN 5    /* horizontal outputs per thread: ceil(68 / 5) = 14 runs x 36 rows = 504 items */
+/* columns of the transposed vertical-pass buffer the horizontal pass may touch (runs are whole: 14 x 5 + 2R) */
+#define CT_P2_COLS(R) ((((CT_X + 4) + CT_HRUN - 1) / CT_HRUN) * CT_HRUN + 2 * (R))
 // vertical pass reading the grey image directly (no LDS copy of the tile): consecutive lanes read
 // consecutive columns of one image row (coalesced); rows shared by neighbouring groups come from L1/L2.
 // YIN: every row this tile touches (ty0-R-2 .. ty0+CT_Y+R+1) lies inside the image -> no clamping.
@@ -385,10 +387,10 @@ STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const flo
         const bool yin = (y >= 0 && y < T.S);
         double win[CT_HRUN + 2 * R];
 #pragma unroll
-        for (int k = 0; k < CT_HRUN + 2 * R; k++) {
-            const int col = xx0 + k;                      // sVT column index = image x - (tx0 - R - 2)
-            win[k] = (col < CT_X + 2 * R + 4) ? (double)sVT[col * CT_VP + yy] : 0.0;
-        }
+        for (int k = 0; k < CT_HRUN + 2 * R; k++)         // sVT column index = image x - (tx0 - R - 2)
+            win[k] = (double)sVT[(xx0 + k) * CT_VP + yy];  // columns >= CT_X+2R+4 (last run only) lie in the
+                                                           // buffer's CT_P2_COLS(R) padding and feed only the
+                                                           // outputs xx >= SW that are dropped below
         const double bint = sB[VH + yy] + DBL_EPSILON;
         const bool fast = XIN && fd.ok && yin && (bint == fd.c);      // interior row: the verified constant
 #pragma unroll

@@ -268,7 +268,7 @@ static __host__ __device__ size_t canny_pipe_smem_bytes(int R)
 {
     const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
     size_t fixed = (32 + 2 * VH + VH * 2 * R + VH * CT_SP) * sizeof(double);
-    size_t v = (size_t)GW * CT_VP * sizeof(float);
+    size_t v = (size_t)(CT_P2_COLS(R) > GW ? CT_P2_COLS(R) : GW) * CT_VP * sizeof(float);
     // the magnitude tile and the NMS candidate queues share the vertical-pass buffer (sV is dead between
     // the horizontal pass and the next image's vertical pass): 38.9 KB at R = 8 -> 4 workgroups per CU
     size_t m = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(float) + 4 * 512 * sizeof(uint16_t);

@@ -50,7 +50,7 @@ void emu_gray(const double* band, int W, int hw, int64_t st, const int16_t* nz, 
 void emu_canny2(const float* gray /* pitch 400 */, int S, int R, const double* w, stp_u64* low, stp_u64* high, int blocked)
 {
     const int GW = ct_gw(R), GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
-    std::vector<float> sG(GH * GW), sV(VH * GW > GW * CT_VP ? VH * GW : GW * CT_VP);
+    std::vector<float> sG(GH * GW), sV((VH * GW > GW * CT_VP ? VH * GW : GW * CT_VP) + 8 * CT_VP);   // + the horizontal pass's padding columns
     std::vector<double> sB(2 * VH), sS(VH * CT_SP);
     std::vector<float> sM((CT_Y + 2) * (CT_X + 2));
     std::vector<uint8_t> sC(CT_Y * CT_X);
