@@ -290,6 +290,8 @@ STP_HD void canny_p2(int tid, int nt, stp_tile T, int R, const double* w, const 
 // input is loaded and widened to f64 once instead of 2R+1 times.  Same operation order per output.
 // The vertical pass writes its result TRANSPOSED (sVT[x][y], pitch CT_VP) so that both passes read
 // LDS with consecutive lanes on consecutive words.
+#define STP_GRAY_GUARD 65536   /* bytes of padding before and after the grey images: the last tile row reads up to
+                                  ty0 + CT_Y + R + 1 = 429 < 400 + 40 rows of 1600 B (R <= 12); R + 2 rows in front */
 #define CT_VRUN 6    /* vertical outputs per thread: (CT_Y + 4) = 6 * 6; 12 would spill at 128 VGPRs */
 #define CT_HRUN 5    /* horizontal outputs per thread: ceil(68 / 5) = 14 runs x 36 rows = 504 items */
 /* columns of the transposed vertical-pass buffer the horizontal pass may touch (runs are whole: 14 x 5 + 2R) */
@@ -307,20 +309,20 @@ STP_HD void canny_p1_blk_g(int tid, int nt, stp_tile T, const double* w, const f
         const int xx = i % GW, yg = i / GW;
         const int yy0 = yg * CT_VRUN;
         const int x = T.tx0 - R - 2 + xx;
-        const int xc = XIN ? x : (x < 0 ? 0 : (x > T.S - 1 ? T.S - 1 : x));
-        const bool xin = XIN || (x == xc);
+        const bool xin = XIN || (x >= 0 && x < T.S);
         float raw[CT_VRUN + 2 * R];
-        if (YIN) {
-            const float* col = gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + xc;
+        // Rows / columns outside the image are loaded like any other (the grey buffer carries
+        // STP_GRAY_GUARD bytes of padding on both sides, so a row up to R+2 above the first image or
+        // CT_Y+R+1 below the start of the last tile row is still inside the allocation) and replaced by the constant-mode 0 after
+        // the load: no per-element address clamping in the border tiles.
+        const float* col = gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + x;
 #pragma unroll
-            for (int k = 0; k < CT_VRUN + 2 * R; k++) raw[k] = col[k * STP_PITCH];
-        } else {
+        for (int k = 0; k < CT_VRUN + 2 * R; k++) raw[k] = col[k * STP_PITCH];        // all loads issued before any use
+        if (!YIN) {
 #pragma unroll
-            for (int k = 0; k < CT_VRUN + 2 * R; k++) {        // all loads issued before any use
+            for (int k = 0; k < CT_VRUN + 2 * R; k++) {
                 const int y = T.ty0 - R - 2 + yy0 + k;
-                const int yc = y < 0 ? 0 : (y > T.S - 1 ? T.S - 1 : y);
-                const float g = gimg[yc * STP_PITCH + xc];
-                raw[k] = (y == yc) ? g : 0.0f;
+                if ((unsigned)y >= (unsigned)T.S) raw[k] = 0.0f;
             }
         }
         double win[CT_VRUN + 2 * R];
@@ -392,7 +394,10 @@ STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const flo
                                                            // buffer's CT_P2_COLS(R) padding and feed only the
                                                            // outputs xx >= SW that are dropped below
         const double bint = sB[VH + yy] + DBL_EPSILON;
-        const bool fast = XIN && fd.ok && yin && (bint == fd.c);      // interior row: the verified constant
+        // interior row and (tile-uniform XIN, or this item's own columns) interior columns: the verified constant
+        const int xfirst = T.tx0 - 2 + xx0;
+        const bool cin = XIN || (xfirst >= R && xfirst + CT_HRUN - 1 + R < T.S);
+        const bool fast = cin && fd.ok && yin && (bint == fd.c);
 #pragma unroll
         for (int q = 0; q < CT_HRUN; q++) {
             const int xx = xx0 + q;
@@ -404,6 +409,8 @@ STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const flo
             double s;
             if (XIN) {
                 s = fast ? stp_div_const((double)f, fd.c, fd.rc) : (yin ? (double)f / bint : 0.0);
+            } else if (fast) {
+                s = stp_div_const((double)f, fd.c, fd.rc);
             } else {
                 const int x = T.tx0 - 2 + xx;
                 s = 0.0;

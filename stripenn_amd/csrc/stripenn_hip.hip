@@ -1235,7 +1235,8 @@ int stp_stripe_search(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
     const size_t cimg = (size_t)chunk * ipf;
     const size_t ocap = cimg * STP_RCAP;                 // dense records per chunk: every image may fill its slots
     void *pGray, *pLow, *pHigh, *pRecs, *pCnt, *pOut, *pTot, *pPar;
-    HIPCHK(ws_get(ctx, WS_GRAY, cimg * STP_PITCH * STP_PITCH * sizeof(float), &pGray));
+    HIPCHK(ws_get(ctx, WS_GRAY, cimg * STP_PITCH * STP_PITCH * sizeof(float) + 2 * STP_GRAY_GUARD, &pGray));
+    pGray = (char*)pGray + STP_GRAY_GUARD;            // border tiles of the vertical pass read (and discard) up to R+2 rows outside
     HIPCHK(ws_get(ctx, WS_LOW, cimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), &pLow));
     HIPCHK(ws_get(ctx, WS_HIGH, cimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), &pHigh));
     HIPCHK(ws_get(ctx, WS_RECS, cimg * STP_RCAP * sizeof(stp_drec), &pRecs));
@@ -1320,7 +1321,8 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
     HIPCHK(bM.alloc(ctx, sizeof(double)));
     HIPCHK(bB.alloc(ctx, nb * sizeof(double)));
     HIPCHK(bW.alloc(ctx, (2 * prm->gauss_radius + 1) * sizeof(double)));
-    HIPCHK(bGray.alloc(ctx, nimg * STP_PITCH * STP_PITCH * sizeof(float)));
+    HIPCHK(bGray.alloc(ctx, nimg * STP_PITCH * STP_PITCH * sizeof(float) + 2 * STP_GRAY_GUARD));
+    float* dGray = (float*)((char*)bGray.p + STP_GRAY_GUARD);
     HIPCHK(bLow.alloc(ctx, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
     HIPCHK(bHigh.alloc(ctx, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
     HIPCHK(bRecs.alloc(ctx, nimg * STP_RCAP * sizeof(stp_drec)));
@@ -1332,7 +1334,7 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
     HIPCHK(hipMemcpyAsync(bB.p, prm->bright, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(bW.p, prm->gauss_w, (2 * prm->gauss_radius + 1) * sizeof(double), hipMemcpyHostToDevice,
                           ctx->stream));
-    rc = run_chain(ctx, fr, prm, f, 1, (const double*)bM.p, 1, (const double*)bB.p, (const double*)bW.p, (float*)bGray.p,
+    rc = run_chain(ctx, fr, prm, f, 1, (const double*)bM.p, 1, (const double*)bB.p, (const double*)bW.p, dGray,
                    (stp_u64*)bLow.p, (stp_u64*)bHigh.p, (stp_drec*)bRecs.p, (int32_t*)bCnt.p, 1, (stp_u64*)bDbg.p,
                    (int16_t*)bDbgc.p);
     if (rc) return rc;
@@ -1340,7 +1342,7 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
     std::vector<float> hg((size_t)STP_PITCH * STP_PITCH);
     std::vector<stp_u64> hl(BW), hh(BW), hd(4 * BW);
     std::vector<int16_t> hc(3 * STP_FRAME_MAX);
-    HIPCHK(hipMemcpyAsync(hg.data(), (float*)bGray.p + (size_t)bi * STP_PITCH * STP_PITCH, hg.size() * sizeof(float),
+    HIPCHK(hipMemcpyAsync(hg.data(), dGray + (size_t)bi * STP_PITCH * STP_PITCH, hg.size() * sizeof(float),
                           hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(hl.data(), (stp_u64*)bLow.p + bi * BW, BW * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(hh.data(), (stp_u64*)bHigh.p + bi * BW, BW * 8, hipMemcpyDeviceToHost, ctx->stream));

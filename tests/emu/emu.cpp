@@ -2,6 +2,7 @@
 // TEST-ONLY: lets the CPU test-suite check the kernels' phase code (stripenn_amd/csrc/stp_phases.h)
 // against the oracle without a GPU.  Never linked into the product library.
 #include <vector>
+#include <limits>
 #include <string.h>
 #include "../../include/stripenn_hip.h"
 #include "../../stripenn_amd/csrc/stp_phases.h"
@@ -47,8 +48,14 @@ void emu_gray(const double* band, int W, int hw, int64_t st, const int16_t* nz, 
         }
 }
 
-void emu_canny2(const float* gray /* pitch 400 */, int S, int R, const double* w, stp_u64* low, stp_u64* high, int blocked)
+void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double* w, stp_u64* low, stp_u64* high, int blocked)
 {
+    // as in the library: the grey image sits between two guard regions (filled with NaN here: whatever the
+    // border tiles load from them must never reach a result)
+    const size_t guard = STP_GRAY_GUARD / sizeof(float), npx = (size_t)STP_PITCH * STP_PITCH;
+    std::vector<float> gpad(npx + 2 * guard, std::numeric_limits<float>::quiet_NaN());
+    memcpy(gpad.data() + guard, gray_in, npx * sizeof(float));
+    const float* gray = gpad.data() + guard;
     const int GW = ct_gw(R), GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
     std::vector<float> sG(GH * GW), sV((VH * GW > GW * CT_VP ? VH * GW : GW * CT_VP) + 8 * CT_VP);   // + the horizontal pass's padding columns
     std::vector<double> sB(2 * VH), sS(VH * CT_SP);
