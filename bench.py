@@ -169,10 +169,10 @@ def main():
     def score_inputs(recs, fr):
         """bin rectangles of every candidate stripe (vectorised host arithmetic)"""
         f = recs['frame']
-        base = st[f].astype(np.int64)
-        nzf = fr.nz
-        x0 = base + nzf[f, recs['x']]; x1 = base + nzf[f, recs['x'] + recs['w'] - 1]
-        y0 = base + nzf[f, recs['y']]; y1 = base + nzf[f, recs['y'] + recs['h'] - 1]
+        base = st[f]
+        nzr = fr.nz.ravel(); fo = f * fr.nz.shape[1]
+        x0 = base + nzr.take(fo + recs['x']); x1 = base + nzr.take(fo + recs['x'] + recs['w'] - 1)
+        y0 = base + nzr.take(fo + recs['y']); y1 = base + nzr.take(fo + recs['y'] + recs['h'] - 1)
         n = len(recs)
         pv = np.zeros(n, dtype=BK.PV_STRIPE_DTYPE)
         pv['row0'], pv['row1'] = y0, y1 + 1
