@@ -78,6 +78,13 @@ STP_HD double stp_bright_px(double v, double b, double k)
     return 0.0;
 }
 
+// kv * stp_bright_px(v, b, k) with the same bits for every input (NaN included) in two compares:
+// kv * 1.0 == kv and kv * 0.0 == 0.0 exactly, and the three cases of stp_bright_px are disjoint.
+STP_HD double stp_bright_kv(double v, double b, double k, double kv)
+{
+    return (v > b) ? kv : ((v > 0.0) ? kv * (k * v) : 0.0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernel A (k_gray): D -> g plane (LDS) -> per brightness: adj (LDS) -> mean blur -> grey f32
 // sg / sadj: (GT_Y + 2a) x (GT_X + 2a) doubles, origin (ty0 - a, tx0 - a)
@@ -148,10 +155,10 @@ STP_HD void gray_wadj(int lane, int strip, double b, const double* sg, double* s
     const double kv = 1.0 / 9.0;
     const double* g0 = sg + (strip * GS_ROWS) * WW;          // strip rows -1 .. 8 are sg rows strip*8 .. +9
 #pragma unroll
-    for (int r = 0; r < GS_ROWS + 2; r++) sadjw[r * WW + lane + 1] = kv * stp_bright_px(g0[r * WW + lane + 1], b, k);
+    for (int r = 0; r < GS_ROWS + 2; r++) sadjw[r * WW + lane + 1] = stp_bright_kv(g0[r * WW + lane + 1], b, k, kv);
     if (lane < 2 * (GS_ROWS + 2)) {                           // the two halo columns
         const int r = lane >> 1, c = (lane & 1) ? WW - 1 : 0;
-        sadjw[r * WW + c] = kv * stp_bright_px(g0[r * WW + c], b, k);
+        sadjw[r * WW + c] = stp_bright_kv(g0[r * WW + c], b, k, kv);
     }
 }
 STP_HD void gray_wblur(int lane, int strip, stp_tile T, const double* sadjw, float* __restrict__ gray_img)
@@ -178,8 +185,7 @@ STP_HD void gray_wblur(int lane, int strip, stp_tile T, const double* sadjw, flo
         for (int c = 0; c < 3; c++) acc = acc + w1[c];
 #pragma unroll
         for (int c = 0; c < 3; c++) acc = acc + w2[c];
-        if (acc < 0.0) acc = 0.0;
-        if (acc > 1.0) acc = 1.0;
+        if (acc > 1.0) acc = 1.0;                             // (a sum of products >= 0 starting at +0 is never < 0)
         const float g32 = (float)acc;
         float v = r32 * 0.299f;
         v = v + g32 * 0.587f;
