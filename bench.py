@@ -254,9 +254,12 @@ def main():
                'unit': 'contact-Mpx/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-               'config': {'workload': 'configs[1]: chr16-size 5kb chromosome (%d bins, %d frames), maxpixel sweep '
-                                      '0.95-0.99 x 6 brightness levels: frame compaction + StripeSearch chain + p-value and '
-                                      'Stripiness of every candidate stripe' % (nb, len(st)),
+               'config': {'workload': '%s (%d bins, %d frames), maxpixel sweep 0.95-0.99 x 6 brightness levels: frame '
+                                      'compaction + StripeSearch chain%s'
+                                      % ('configs[1]: chr16-size 5kb chromosome' if nb == CHR16_BINS else
+                                         'configs[4]-like 1kb chr1-size band' if nb > 200000 else 'custom chromosome',
+                                         nb, len(st),
+                                         '' if args.no_score else ' + p-value and Stripiness of every candidate stripe'),
                           'frames': int(len(st)), 'levels': len(Ms), 'images_per_step': int(len(st) * len(Ms) * 6),
                           'contact_px_per_step': total_px, 'stripe_records': int(len(recs)),
                           'sharding': 'one chromosome per rank, no collective'},

@@ -1,0 +1,83 @@
+"""Error contract and edge cases of the C ABI on the GPU (include/stripenn_hip.h): bad arguments come back
+as STP_E_* codes with a message and leave the context usable; empty / degenerate inputs behave like the
+reference (frames with <= 10 non-empty columns are skipped, getStripe.py:818; no edges -> no rows)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from stripenn_amd import hip, synth
+
+pytestmark = pytest.mark.gpu
+HW = 512
+
+
+def _code(exc):
+    return exc.value.code
+
+
+def test_bad_arguments_are_reported_not_fatal(hip_ctx):
+    ch = synth.SynthChrom(700, 9)
+    band_h = ch.band(HW)
+    with pytest.raises(hip.StripennHipError) as e:
+        hip_ctx.band_upload(np.zeros((10, 2 * 100)))             # halfwidth not a multiple of 64 / < 448
+    assert _code(e) == hip.STP_E_ARG
+    with pytest.raises(ValueError):
+        hip_ctx.band_upload(np.zeros((10, 1025)))                # odd width rejected by the binding
+    band = hip_ctx.band_upload(band_h)
+    for st, en in (([0], [400]), ([-1], [100]), ([650], [700]), ([300], [200])):   # 401 wide, negative, past the end, reversed
+        with pytest.raises(hip.StripennHipError) as e:
+            band.frames(np.array(st, np.int32), np.array(en, np.int32))
+        assert _code(e) == hip.STP_E_ARG and 'frame' in str(e.value)
+    fr = band.frames(np.array([0, 100], np.int32), np.array([299, 499], np.int32))
+    M = [float(np.quantile(band_h[band_h > 0], 0.98))]
+    for kw, code in ((dict(bfilter=4), hip.STP_E_UNSUPPORTED), (dict(bfilter=9), hip.STP_E_UNSUPPORTED),
+                     (dict(sigma=3.5), hip.STP_E_UNSUPPORTED), (dict(maxW=1), hip.STP_E_ARG),
+                     (dict(bright=np.linspace(0.1, 1.0, 9)), hip.STP_E_ARG)):
+        with pytest.raises(hip.StripennHipError) as e:
+            fr.stripe_search(M, **kw)
+        assert _code(e) == code, kw
+    # the context is still good after every refusal
+    recs = fr.stripe_search(M)
+    assert len(recs) > 0
+    # capacity protocol: too small a buffer -> STP_E_CAPACITY and the needed count, nothing lost on retry
+    p, keep = fr._params(10, 8, 3, hip.brightness_levels(), *hip.gauss_weights(2.0))
+    Ms = np.ascontiguousarray(M, np.float64)
+    small = np.zeros(3, dtype=hip.REC_DTYPE)
+    cnt = C.c_int64()
+    rc = hip_ctx.L.stp_stripe_search(hip_ctx.h, fr.h, C.byref(p), hip._ptr(Ms), 1, hip._ptr(small), 3, C.byref(cnt))
+    assert rc == hip.STP_E_CAPACITY and cnt.value == len(recs)
+    assert b'capacity' in hip_ctx.L.stp_last_error(hip_ctx.h)
+    assert np.array_equal(fr.stripe_search(M, capacity=3), recs)          # the binding retries with the needed size
+    assert hip_ctx.L.stp_stripe_search(hip_ctx.h, fr.h, None, hip._ptr(Ms), 1, hip._ptr(small), 3, C.byref(cnt)) == hip.STP_E_ARG
+    assert hip_ctx.L.stp_frames_create(None, band.h, None, None, 0, None) == hip.STP_E_ARG
+    fr.close(); band.close()
+
+
+def test_degenerate_frames_and_images(hip_ctx):
+    n = 900
+    band_h = np.zeros((n, 2 * HW))
+    rng = np.random.default_rng(3)
+    i = np.arange(n)
+    # rows 0..399: empty; 400..411: 12 live bins (just above the reference's "> 10 columns" rule);
+    # 500..509: 10 live bins (skipped); 600..899: flat positive matrix (no edges at all)
+    for lo, hi in ((400, 412), (500, 510)):
+        for a in range(lo, hi):
+            for b in range(lo, hi):
+                band_h[a, b - a + HW] = 1.0 + rng.random() if a <= b else band_h[b, a - b + HW]
+    for a in range(600, 900):
+        d = np.arange(-HW, HW); b = a + d
+        ok = (b >= 600) & (b < 900)
+        band_h[a, ok] = 5.0
+    band = hip_ctx.band_upload(band_h)
+    st = np.array([0, 300, 450, 600, 895], np.int32)
+    en = np.array([399, 499, 549, 899, 899], np.int32)
+    fr = band.frames(st, en)
+    assert fr.S.tolist() == [0, 12, 0, 300, 0]                 # empty, 12 kept, 10 -> skipped, full, 5 bins -> skipped
+    assert np.array_equal(fr.nz[1, :12], np.arange(100, 112))
+    assert np.isnan(fr.medpixel[0]) and fr.medpixel[3] == 5.0
+    recs = fr.stripe_search([1.0, 4.0, 50.0])
+    assert len(recs) == 0 or set(recs['frame'].tolist()) <= {1, 3}
+    # flat image: Canny finds nothing, so no records from frame 3 at any level
+    assert not np.any(recs['frame'] == 3)
+    fr.close(); band.close()
