@@ -1211,7 +1211,11 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     }
     HIPCHK(hipGetLastError());
     {
-        static const int lines_stop = getenv("STP_LINES_STOP") ? atoi(getenv("STP_LINES_STOP")) : 0;  // profiling ablation only
+#if defined(STP_ABLATE_LINES_STOPS)   /* timing-only build (make ablate): truncate k_lines after phase N */
+        static const int lines_stop = getenv("STP_LINES_STOP") ? atoi(getenv("STP_LINES_STOP")) : 0;
+#else
+        const int lines_stop = 0;          // the product library has no such switch
+#endif
         prof_scope ps(ctx, "lines", ipx * 9.0);          // stages C-F: 2 + 2 + 1 + 4 B per image px
         hipLaunchKernelGGL(k_lines, dim3((unsigned)nimg), dim3(512), 0, ctx->stream, d_low, d_high, band->d, band->W,
                            band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, ipf, prm->minH, prm->maxW, d_recs, d_cnt,
