@@ -299,7 +299,7 @@ STP_HD void canny_p2(int tid, int nt, stp_tile T, int R, const double* w, const 
 #define STP_GRAY_GUARD 65536   /* bytes of padding before and after the grey images: the last tile row reads up to
                                   ty0 + CT_Y + R + 1 = 429 < 400 + 40 rows of 1600 B (R <= 12); R + 2 rows in front */
 #define CT_VRUN 12   /* vertical outputs per thread: (CT_Y + 4) = 3 * 12 */
-#define CT_HRUN 5    /* horizontal outputs per thread: ceil(68 / 5) = 14 runs x 36 rows = 504 items */
+#define CT_HRUN 10   /* horizontal outputs per thread: ceil(68 / 10) = 7 runs x 36 rows = 252 items (one round) */
 /* columns of the transposed vertical-pass buffer the horizontal pass may touch (runs are whole: 14 x 5 + 2R) */
 #define CT_P2_COLS(R) ((((CT_X + 4) + CT_HRUN - 1) / CT_HRUN) * CT_HRUN + 2 * (R))
 // vertical pass reading the grey image directly (no LDS copy of the tile): consecutive lanes read
