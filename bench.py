@@ -27,10 +27,10 @@ MAXPIXEL = [0.95, 0.96, 0.97, 0.98, 0.99]
 BYTES_PER_IMAGE_PX = {'gray': 12.0, 'canny': 5.0, 'lines': 9.0}  # SURVEY.md 8(d) stages A, B, C-F
 SCORE_KERNELS = ('pvalue', 'stripiness')
 # HBM bytes per launch of the chain kernels for THIS default workload, from rocprofv3 PMC passes
-# (profiles/r01d_pmc.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, KB units, FETCH_SIZE
+# (profiles/r01e_pmc.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, KB units, FETCH_SIZE
 # doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read inside this script.
-PMC_TRAFFIC_BYTES = {'canny': (2 * 911342 + 176180) * 1024.0, 'gray': (2 * 329362 + 1818581) * 1024.0,
-                     'lines': (2 * 173117 + 256093) * 1024.0}
+PMC_TRAFFIC_BYTES = {'canny': (2 * 944518 + 195169) * 1024.0, 'gray': (2 * 329611 + 1818581) * 1024.0,
+                     'lines': (2 * 173244 + 256093) * 1024.0}
 
 
 def frame_table(nbins):
