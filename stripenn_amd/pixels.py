@@ -163,10 +163,21 @@ class PixelSelector:
         n2, c0, c1 = (n1, r0, r1) if region2 is None else self._extent(region2)
         if n1 != n2:
             raise ValueError('trans fetch is not on the stripenn path')
+        lo, _ = self.table.chrom_bins(n1)
+        return self._dense(r0 + lo, r1 + lo, c0 + lo, c1 + lo)
+
+    def __getitem__(self, key):
+        """cooler's `matrix[r0:r1, c0:c1]` with GLOBAL bin indices (getStripe.py:107-158, the `-s` quantile)."""
+        rs, cs = key
+        n = int(self.table.chrom_offset[-1])
+        r0, r1, _ = rs.indices(n)
+        c0, c1, _ = cs.indices(n)
+        return self._dense(r0, max(r1, r0), c0, max(c1, c0))
+
+    def _dense(self, R0, R1, C0, C1):
+        """Dense block of global bins rows [R0, R1) x cols [C0, C1)."""
         t = self.table
-        lo, _ = t.chrom_bins(n1)
-        out = np.zeros((r1 - r0, c1 - c0), dtype=np.float64)
-        R0, R1, C0, C1 = r0 + lo, r1 + lo, c0 + lo, c1 + lo
+        out = np.zeros((R1 - R0, C1 - C0), dtype=np.float64)
         # stored pixels (bin1 in rows, bin2 in cols), then their mirror images (bin2 in rows, bin1 in cols)
         for (A0, A1, B0, B1, mirror) in ((R0, R1, C0, C1, False), (C0, C1, R0, R1, True)):
             a, b = t.rows_slice(A0, A1)
