@@ -519,6 +519,28 @@ STP_HD void canny_p3_in(int tid, int nt, const double* sS, float* sM)
     }
 }
 
+// Border tiles: scipy's 'reflect' with an overshoot of one pixel is edge replication, so writing the
+// one-pixel ring around the image (rows -1 and S, columns -1 and S, where this tile holds them) with its
+// clamped in-image source lets canny_p3_in's plain offsets serve every tile.  Sources are in-image
+// elements (never written here); a corner is written twice with the same value.  Magnitudes of pixels
+// outside the image come out as garbage instead of 0: the NMS never reads them.
+STP_HD void canny_p3_ring(int tid, int nt, stp_tile T, double* sS)
+{
+    const int VH = CT_Y + 4, SW = CT_X + 4;
+    const int y0 = T.ty0 - 2, x0 = T.tx0 - 2;
+    for (int i = tid; i < 2 * SW + 2 * VH; i += nt) {
+        int y, x;
+        if (i < 2 * SW) { y = (i < SW) ? -1 : T.S; x = x0 + (i < SW ? i : i - SW); }
+        else { const int j = i - 2 * SW; x = (j < VH) ? -1 : T.S; y = y0 + (j < VH ? j : j - VH); }
+        const int yy = y - y0, xx = x - x0;
+        if (yy < 0 || yy >= VH || xx < 0 || xx >= SW) continue;          // this tile does not hold that ring element
+        const int cy = y < 0 ? 0 : (y > T.S - 1 ? T.S - 1 : y), cx = x < 0 ? 0 : (x > T.S - 1 ? T.S - 1 : x);
+        const int sy = cy - y0, sx = cx - x0;
+        if (sy < 0 || sy >= VH || sx < 0 || sx >= SW) continue;
+        sS[yy * CT_SP + xx] = sS[sy * CT_SP + sx];
+    }
+}
+
 STP_HD void canny_p3(int tid, int nt, stp_tile T, const double* sS, float* sM)
 {
     const int MH = CT_Y + 2, MW = CT_X + 2;

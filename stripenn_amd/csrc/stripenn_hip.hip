@@ -333,8 +333,11 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
         __syncthreads();
         continue;
 #endif
-        if (xin && yin) canny_p3_in(tid, nt, sS, sM);
-        else canny_p3(tid, nt, T, sS, sM);
+        if (!(xin && yin)) {                      // border tile: replicate the image edge into the ring first
+            canny_p3_ring(tid, nt, T, sS);
+            __syncthreads();
+        }
+        canny_p3_in(tid, nt, sS, sM);
         __syncthreads();
         canny_nms_pack(tid, T, sS, sM, sQ, sBits, low + img * (STP_FRAME_MAX * STP_NW), high + img * (STP_FRAME_MAX * STP_NW));
         __syncthreads();     // sM / sQ alias sV: the NMS must be done before the next vertical pass writes it

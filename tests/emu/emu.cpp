@@ -102,7 +102,10 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
                 canny_p1(0, 1, T, R, w, sG.data(), sV.data());
                 canny_p2(0, 1, T, R, w, sV.data(), sB.data(), sS.data());
             }
-            if (blocked && (R == 8 || R == 10) && xin && yin) { canny_p3_in(0, 1, sS.data(), sM.data()); did_p3 = true; }
+            if (blocked && (R == 8 || R == 10)) {         // k_canny_pipe: ring fill in border tiles, plain offsets everywhere
+                if (!(xin && yin)) canny_p3_ring(0, 1, T, sS.data());
+                canny_p3_in(0, 1, sS.data(), sM.data()); did_p3 = true;
+            }
             if (!did_p3) canny_p3(0, 1, T, sS.data(), sM.data());
             canny_p4(0, 1, T, sS.data(), sM.data(), sC.data());
             canny_p5(0, 1, T, sC.data(), low, high);
