@@ -1588,10 +1588,10 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
         const size_t lds = sizeof(double) * (STP_NDIAG + 3 * (size_t)HR + std::max(HR, 256)) +
                            sizeof(int16_t) * ((size_t)HR + 3 * (size_t)CW) + (size_t)HR;
         if (!big)
-            hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)n), dim3(256), lds, ctx->stream, bref(band), (const double*)bE.p,
+            hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)n), dim3(128), lds, ctx->stream, bref(band), (const double*)bE.p,
                                (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n), HR, CW);
         else
-            hipLaunchKernelGGL(k_stripiness<true>, dim3((unsigned)n), dim3(256), lds, ctx->stream, bref(band), (const double*)bE.p,
+            hipLaunchKernelGGL(k_stripiness<true>, dim3((unsigned)n), dim3(128), lds, ctx->stream, bref(band), (const double*)bE.p,
                                (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n), HR, CW);
     }
     HIPCHK(hipGetLastError());
