@@ -161,7 +161,24 @@ STP_HD void gray_wadj(int lane, int strip, double b, const double* sg, double* s
         sadjw[r * WW + c] = stp_bright_kv(g0[r * WW + c], b, k, kv);
     }
 }
-STP_HD void gray_wblur(int lane, int strip, stp_tile T, const double* sadjw, float* __restrict__ gray_img)
+// Flat-window rule of the Canny stage.  Every smoothed value is a convex combination of the in-image grey
+// values inside its (2R+1)^2 window (the bleed-over division renormalises the truncated sums at the image
+// border), up to 3e-7 relative from the two float roundings; scipy's Sobel is a difference of two (1,2,1)
+// sums of smoothed values, so |isobel|, |jsobel| <= 4 * range and magnitude <= 5.657 * (range + 6e-7), where
+// range = max - min of the grey values that can reach the pixel.  A tile whose whole input window has
+// range < STP_FLAT_RANGE therefore has every magnitude < 0.085 < 0.1: no pixel gets a class, whatever the
+// local-maximum test says, and the tile's four phases are skipped.  k_gray records min / max of the grey
+// values it writes per cell of GC_CY x GC_CX pixels; k_canny_pipe unites the cells its window touches.
+#define STP_FLAT_RANGE 0.015f
+#define GC_CY 8
+#define GC_CX 16
+#define GC_ROWS (STP_FRAME_MAX / GC_CY)                /* 50 */
+#define GC_COLS ((STP_FRAME_MAX + 63) / 64 * 64 / GC_CX) /* 28 */
+
+// vmin / vmax: running min / max of the BIT PATTERNS of the stored grey values (they are >= +0, so the
+// patterns order like the values and one integer min / max instruction each does it)
+STP_HD void gray_wblur(int lane, int strip, stp_tile T, const double* sadjw, float* __restrict__ gray_img,
+                       unsigned* vmin, unsigned* vmax)
 {
     const int WW = GT_X + 2;
     const double kv = 1.0 / 9.0;
@@ -191,7 +208,13 @@ STP_HD void gray_wblur(int lane, int strip, stp_tile T, const double* sadjw, flo
         v = v + g32 * 0.587f;
         v = v + g32 * 0.114f;
         const int y = T.ty0 + strip * GS_ROWS + q;
-        if (y < T.S && x < T.S) gray_img[y * STP_PITCH + x] = v;
+        if (y < T.S && x < T.S) {
+            gray_img[y * STP_PITCH + x] = v;
+            unsigned bits;
+            memcpy(&bits, &v, 4);
+            *vmin = bits < *vmin ? bits : *vmin;
+            *vmax = bits > *vmax ? bits : *vmax;
+        }
 #pragma unroll
         for (int c = 0; c < 3; c++) { w0[c] = w1[c]; w1[c] = w2[c]; }
     }

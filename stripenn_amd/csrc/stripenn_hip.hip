@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
                                                const int16_t* __restrict__ fnz, int f0,
                                                const double* __restrict__ Mlev, int nlev,
                                                const double* __restrict__ bvals, int nb, int a,
-                                               float* __restrict__ gray)
+                                               float* __restrict__ gray, float2* __restrict__ cells)
 {
     // AMAX = 1 (bfilter 3): 39 KB of LDS -> 4 workgroups per CU; the generic instance is sized for bfilter <= 7
     constexpr int SG_N = (GT_Y + 2 * AMAX) * (GT_X + 2 * AMAX);
@@ -143,7 +143,17 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
             gray_wadj(lane, strip, bvals[bi], sg, sadjw);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            gray_wblur(lane, strip, T, sadjw, gray + img * (size_t)(STP_PITCH * STP_PITCH));
+            unsigned vmn = 0x7F800000u, vmx = 0u;              // +inf / +0: a cell without pixels unites to nothing
+            gray_wblur(lane, strip, T, sadjw, gray + img * (size_t)(STP_PITCH * STP_PITCH), &vmn, &vmx);
+            // min / max of the strip's grey values per 16-column cell (see STP_FLAT_RANGE)
+#pragma unroll
+            for (int o = 1; o < GC_CX; o <<= 1) {
+                vmn = min(vmn, (unsigned)__shfl_xor((int)vmn, o));
+                vmx = max(vmx, (unsigned)__shfl_xor((int)vmx, o));
+            }
+            const int crow = T.ty0 / GC_CY + strip, ccol = (T.tx0 + lane) / GC_CX;
+            if (cells && (lane & (GC_CX - 1)) == 0 && crow < GC_ROWS && ccol < GC_COLS)
+                cells[(img * GC_ROWS + crow) * GC_COLS + ccol] = make_float2(__uint_as_float(vmn), __uint_as_float(vmx));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
@@ -279,7 +289,8 @@ static __host__ __device__ size_t canny_pipe_smem_bytes(int R)
 template <int RT>
 __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
                                                      int nf, int nlev, int nb, const double* __restrict__ gw,
-                                                     stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_fastdiv fd)
+                                                     stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_fastdiv fd,
+                                                     const float2* __restrict__ cells /* null: no flat-window skip */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int R = RT;
@@ -313,9 +324,34 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
     if (!xin) canny_p1c<R>(tid, nt, T, sW, sB, sBB);
     __syncthreads();
     const size_t img0 = ((size_t)fl * nlev + lev) * nb;
+    // the min/max cell this lane looks at (the same for all images): the cells overlapping the tile's input
+    // window [ty0-R-2, ty0+CT_Y+R+2) x [tx0-R-2, tx0+CT_X+R+2) clipped to the image, at most 8 x 7
+    int cell_off = -1;
+    bool use_cells = cells != nullptr;
+    {
+        const int wy0 = max(T.ty0 - R - 2, 0), wy1 = min(T.ty0 + CT_Y + R + 2, S);
+        const int wx0 = max(T.tx0 - R - 2, 0), wx1 = min(T.tx0 + CT_X + R + 2, S);
+        const int r0 = wy0 / GC_CY, nr = (wy1 - 1) / GC_CY - r0 + 1, c0 = wx0 / GC_CX, nc = (wx1 - 1) / GC_CX - c0 + 1;
+        const int lane = tid & 63;
+        if (nr * nc > 64) use_cells = false;
+        else if (lane < nr * nc) { const int rr = lane / nc; cell_off = (r0 + rr) * GC_COLS + c0 + (lane - rr * nc); }
+    }
     for (int bi = 0; bi < nb; bi++) {
         const size_t img = img0 + bi;
         const float* gimg = gray + img * (STP_PITCH * STP_PITCH);
+        if (use_cells) {                             // every wave reads the same cells: the verdict is block-uniform
+            float mn = INFINITY, mx = -INFINITY;
+            if (cell_off >= 0) { const float2 v = cells[img * (GC_ROWS * GC_COLS) + cell_off]; mn = v.x; mx = v.y; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+            if (mx - mn < STP_FLAT_RANGE) {          // flat window: no pixel of this tile can reach the low threshold
+                if (tid < CT_Y && T.ty0 + tid < S) {
+                    low[img * (STP_FRAME_MAX * STP_NW) + (T.ty0 + tid) * STP_NW + (T.tx0 >> 6)] = 0ull;
+                    high[img * (STP_FRAME_MAX * STP_NW) + (T.ty0 + tid) * STP_NW + (T.tx0 >> 6)] = 0ull;
+                }
+                continue;
+            }
+        }
         if (yin && xin) canny_p1_blk_g<R, true, true>(tid, nt, T, sW, gimg, sV);
         else if (yin) canny_p1_blk_g<R, true>(tid, nt, T, sW, gimg, sV);
         else canny_p1_blk_g<R, false>(tid, nt, T, sW, gimg, sV);
@@ -695,7 +731,7 @@ struct stp_pending {
     double bytes;
 };
 
-enum { WS_GRAY = 0, WS_LOW, WS_HIGH, WS_RECS, WS_CNT, WS_OUT, WS_TOTAL, WS_PARAMS, WS_EDGES, WS_NSLOTS };
+enum { WS_GRAY = 0, WS_LOW, WS_HIGH, WS_RECS, WS_CNT, WS_OUT, WS_TOTAL, WS_PARAMS, WS_EDGES, WS_CELLS, WS_NSLOTS };
 
 struct stp_ctx {
     int device = 0;
@@ -1180,8 +1216,11 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     double px = 0;
     for (int i = 0; i < nf; i++) px += (double)fr->h_S[f0 + i] * fr->h_S[f0 + i];
     const double ipx = px * ipf;   // image pixels in this launch
-    HIPCHK(hipMemsetAsync(d_low, 0, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), ctx->stream));
-    HIPCHK(hipMemsetAsync(d_high, 0, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), ctx->stream));
+    // (no memset of the class bit-planes: the Canny kernels write every word k_lines reads -- one word per tile
+    //  row for each tile that reaches into the image, zeros included)
+    void* p_cells = nullptr;     // min / max of the grey values per 8 x 16 cell (flat-window rule, bfilter 3 only)
+    if (a == 1 && (R == 8 || R == 10))
+        HIPCHK(ws_get(ctx, WS_CELLS, nimg * GC_ROWS * GC_COLS * sizeof(float2), &p_cells));
     // (measured and dropped: running k_lines of one sub-chunk on a second stream beside gray / canny of the
     //  next -- chain wall 5.99 ms alone vs 6.02 / 6.29 / 6.83 ms with 2 / 4 / 8 sub-chunks)
     prof_scope chain_scope(ctx, "chain_wall", ipx * 26.0);     // gray + canny + lines as one interval
@@ -1190,10 +1229,10 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         const int tiles = ((STP_FRAME_MAX + GT_X - 1) / GT_X) * ((STP_FRAME_MAX + GT_Y - 1) / GT_Y);
         if (a == 1)
             hipLaunchKernelGGL(k_gray<1>, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
-                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray);
+                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray, (float2*)p_cells);
         else
             hipLaunchKernelGGL(k_gray<GT_AMAX>, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
-                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray);
+                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray, (float2*)nullptr);
     }
     HIPCHK(hipGetLastError());
     {
@@ -1204,10 +1243,10 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         const unsigned pgrid = (unsigned)(((nf * nlev + 7) / 8) * 8 * tiles);
         if (R == 8)
             hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES, ctx->stream, d_gray,
-                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high, fd);
+                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high, fd, (const float2*)p_cells);
         else if (R == 10)
             hipLaunchKernelGGL(k_canny_pipe<10>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES, ctx->stream, d_gray,
-                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high, fd);
+                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high, fd, (const float2*)p_cells);
         else
             hipLaunchKernelGGL(k_canny, cg, dim3(256), canny_smem_bytes(R) + CANNY_NMS_BYTES, ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
                                d_low, d_high);

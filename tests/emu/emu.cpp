@@ -2,6 +2,8 @@
 // TEST-ONLY: lets the CPU test-suite check the kernels' phase code (stripenn_amd/csrc/stp_phases.h)
 // against the oracle without a GPU.  Never linked into the product library.
 #include <vector>
+#include <algorithm>
+#include <cmath>
 #include <limits>
 #include <string.h>
 #include "../../include/stripenn_hip.h"
@@ -38,7 +40,7 @@ void emu_gray(const double* band, int W, int hw, int64_t st, const int16_t* nz, 
                     for (int strip = 0; strip < GT_Y / GS_ROWS; strip++) {
                         double* sw = sadj.data() + strip * ((GS_ROWS + 2) * (GT_X + 2));
                         for (int lane = 0; lane < 64; lane++) gray_wadj(lane, strip, bvals[bi], sg.data(), sw);
-                        for (int lane = 0; lane < 64; lane++) gray_wblur(lane, strip, T, sw, gray + (size_t)bi * STP_PITCH * STP_PITCH);
+                        for (int lane = 0; lane < 64; lane++) { unsigned mn = 0, mx = 0; gray_wblur(lane, strip, T, sw, gray + (size_t)bi * STP_PITCH * STP_PITCH, &mn, &mx); }
                     }
                 } else {
                     gray_p1(0, 1, a, bvals[bi], sg.data(), sadj.data());
@@ -77,6 +79,18 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
     for (int ty0 = 0; ty0 < S; ty0 += CT_Y)
         for (int tx0 = 0; tx0 < S; tx0 += CT_X) {
             stp_tile T; T.S = S; T.ty0 = ty0; T.tx0 = tx0;
+            if (blocked && (R == 8 || R == 10)) {
+                // k_canny_pipe's flat-window rule, evaluated here straight from the grey image over the same
+                // cell-aligned window (the kernel unites k_gray's per-cell min / max): skipped tiles stay all-zero
+                const int wy0 = std::max(ty0 - R - 2, 0), wy1 = std::min(ty0 + CT_Y + R + 2, S);
+                const int wx0 = std::max(tx0 - R - 2, 0), wx1 = std::min(tx0 + CT_X + R + 2, S);
+                const int Y0 = wy0 / GC_CY * GC_CY, Y1 = std::min(((wy1 - 1) / GC_CY + 1) * GC_CY, S);
+                const int X0 = wx0 / GC_CX * GC_CX, X1 = std::min(((wx1 - 1) / GC_CX + 1) * GC_CX, S);
+                float mn = INFINITY, mx = -INFINITY;
+                for (int y = Y0; y < Y1; y++)
+                    for (int x = X0; x < X1; x++) { const float v = gray[y * STP_PITCH + x]; mn = std::min(mn, v); mx = std::max(mx, v); }
+                if (mx - mn < STP_FLAT_RANGE) continue;
+            }
             canny_p0(0, 1, gray, T, R, sG.data());
             canny_p1b(0, 1, T, R, w, sB.data());
             const bool yin = (T.ty0 - R - 2 >= 0) && (T.ty0 + CT_Y + R + 1 < S);
