@@ -412,11 +412,12 @@ class getStripe:
         chroms = []
         have_prev = False
         prev_row, prev_tab = 0, 0
+        col_chr = [str(c) for c in df['chr'].tolist()]            # columns read once (not 5 .iloc calls per row)
+        col_p = [df[k].tolist() for k in ('pos1', 'pos2', 'pos3', 'pos4')]
         for i in range(n):
-            chrom = str(df['chr'].iloc[i])
+            chrom = col_chr[i]
             chrLen = self.chromnames2sizes[chrom]
-            pos1, pos2 = df['pos1'].iloc[i], df['pos2'].iloc[i]
-            pos3, pos4 = df['pos3'].iloc[i], df['pos4'].iloc[i]
+            pos1, pos2, pos3, pos4 = col_p[0][i], col_p[1][i], col_p[2][i], col_p[3][i]
             leftmost = pos1 - bs * self.resol
             rightmost = pos2 + bs * self.resol
             if leftmost < 1:

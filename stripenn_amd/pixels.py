@@ -66,12 +66,13 @@ class PixelTable:
         return self.bin1_id[a:b], b2, self.count[a:b], lo, hi - lo
 
     # ------------------------------------------------------------------ I/O
-    def save(self, path):
+    def save(self, path, compressed=False):
+        """.npz; uncompressed by default (loading a deflated 14 M-pixel table costs more than the whole GPU run)."""
         d = dict(chromnames=np.array(self.chromnames), chromsizes=self.chromsizes, binsize=self.binsize,
                  chrom_offset=self.chrom_offset, bin1_id=self.bin1_id, bin2_id=self.bin2_id, count=self.count)
         for k, v in self.weights.items():
             d['weight__' + k] = v
-        np.savez_compressed(path, **d)
+        (np.savez_compressed if compressed else np.savez)(path, **d)
 
     @classmethod
     def load(cls, path):
@@ -138,6 +139,7 @@ class PixelSelector:
         self.w = table.weight(balance)
         self.resol = table.binsize
         self.nfetch = 0
+        self._vals = None            # balanced value of every stored pixel, formed on first dense read
 
     def _extent(self, region):
         region = str(region)
@@ -184,7 +186,9 @@ class PixelSelector:
             b1 = t.bin1_id[a:b]; b2 = t.bin2_id[a:b]
             keep = (b2 >= B0) & (b2 < B1)
             b1, b2 = b1[keep], b2[keep]
-            v = pixel_values(t.count[a:b][keep], self.w, b1, b2)
+            if self._vals is None:
+                self._vals = pixel_values(t.count, self.w, t.bin1_id, t.bin2_id)
+            v = self._vals[a:b][keep]
             if mirror:
                 out[b2 - R0, b1 - C0] = v
             else:
