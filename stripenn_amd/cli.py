@@ -50,6 +50,23 @@ def scoring(
     score.getScore(cool, coordinates, norm, numcores, seed, out, mask, device=device)
 
 
+@app.command('seeimage')
+def seeimag(
+    cool: str = typer.Option(..., '--cool', help='Path to cool file'),
+    position: str = typer.Option(..., '--position', '-p', help='Genomic position (e.g., chr1:135010000-136000000)'),
+    maxpixel: str = typer.Option('0.95,0.96,0.97,0.98,0.99', '--maxpixel', '-m', help='Quantile for the pixel saturation. (e.g., 0.95)'),
+    out: str = typer.Option('./heatmap.png', '--out', '-o', help='Path to output directory'),
+    norm: str = typer.Option('KR', '--norm', help='Normalization method. It should be one of the column name of Cooler.bin(). Check it with Cooler.bins().columns (e.g., KR, VC, VC_SQRT)'),
+    slow: bool = typer.Option(False, '-s', help='Use if system memory is low.'),
+    seed: int = typer.Option(123456789, '--seed', help='Seed used to initialize the PRNG.'),
+    device: int = typer.Option(0, '--device', help='HIP device ordinal.'),
+):
+    """Draws heatmap image of given position and color saturation parameter (maxpixel)."""
+    from . import seeimage
+    seeimage.seeimage(cool, position, maxpixel, norm, out, slow, seed, device=device)
+    return 0
+
+
 def main():
     app()
 
