@@ -785,13 +785,13 @@ STP_HD int lines_hyst_sweep_strip(int tid, int nt, int S, const stp_u64* sLow, s
 }
 
 // Register form of the strip sweep (the one k_lines runs): a lane owns one item (8 rows x 1 word) for the
-// whole closure and keeps its low / E rows in registers.  A sweep first reads what it needs from the
+// whole closure and keeps its E rows in registers (the low rows are read from LDS at their step).  A sweep first reads what it needs from the
 // other items -- the rows above / below the strip and the edge bits of the words left / right of it, all
 // loads issued up front -- then walks down and up entirely in registers (no LDS round trip per row) and
 // writes its rows back only if they grew.  Words other lanes are rewriting may be read old or new: E
 // only grows, so either is a valid lower bound, and a sweep in which nobody changed has seen final values.
 struct stp_hyst_item {
-    stp_u64 L[STP_HYST_STRIP], E[STP_HYST_STRIP];
+    stp_u64 E[STP_HYST_STRIP];
     int r0, w;
 };
 STP_HD stp_u64 stp_dil1(stp_u64 x) { return x | (x << 1) | (x >> 1); }
@@ -804,51 +804,65 @@ STP_HD void hyst_item_load(int item, int S, const stp_u64* sLow, const stp_u64* 
 #endif
     for (int k = 0; k < STP_HYST_STRIP; k++) {
         const int r = it->r0 + k;
-        it->L[k] = (r < S) ? sLow[r * STP_NW + w] : 0ull;
         it->E[k] = (r < S) ? sE[r * STP_NW + w] : 0ull;
     }
 }
-STP_HD int hyst_item_sweep(int S, stp_hyst_item* it, stp_u64* sE)
+STP_HD int hyst_item_sweep(int S, stp_hyst_item* it, const stp_u64* sLow, stp_u64* sE)
 {
     constexpr int N = STP_HYST_STRIP;
     const int r0 = it->r0, w = it->w;
     // carry-in bits of rows r0-1 .. r0+N from the neighbouring words: bit 0 <- left word's bit 63,
-    // bit 63 <- right word's bit 0 (bm_shl1 / bm_shr1)
-    unsigned cl = 0, cr = 0;                      // bit k: carry into row r0-1+k from the left / right word
+    // bit 63 <- right word's bit 0 (bm_shl1 / bm_shr1); bit k of cl / cr belongs to row r0-1+k
+    unsigned cl = 0, cr = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int k = 0; k < N + 2; k++) {
         const int r = r0 - 1 + k;
-        if (r >= 0 && r < S) {
-            if (w > 0) cl |= (unsigned)(sE[r * STP_NW + w - 1] >> 63) << k;
-            if (w < STP_NW - 1) cr |= (unsigned)(sE[r * STP_NW + w + 1] & 1ull) << k;
+        if (r >= 0 && r < S) {               // only the 32-bit half holding the wanted bit is read (little endian)
+            const unsigned* h = (const unsigned*)(sE + r * STP_NW + w);
+            if (w > 0) cl |= (h[-1] >> 31) << k;                    // high half of word w-1: its bit 63
+            if (w < STP_NW - 1) cr |= (h[2] & 1u) << k;              // low half of word w+1: its bit 0
         }
     }
 #define STP_HYST_CIN(k) ((stp_u64)((cl >> (k)) & 1u) | ((stp_u64)((cr >> (k)) & 1u) << 63))
+#define STP_HYST_D(k) (stp_dil1(it->E[(k) - 1]) | STP_HYST_CIN(k))      /* dilated own row k-1 (1 <= k <= N) */
     const stp_u64 up = (r0 - 1 >= 0) ? sE[(r0 - 1) * STP_NW + w] : 0ull;
     const stp_u64 dn = (r0 + N < S) ? sE[(r0 + N) * STP_NW + w] : 0ull;
-    stp_u64 D[N + 2];                              // dilated rows r0-1 .. r0+N
-    D[0] = stp_dil1(up) | STP_HYST_CIN(0);
-    D[N + 1] = stp_dil1(dn) | STP_HYST_CIN(N + 1);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int k = 0; k < N; k++) D[k + 1] = stp_dil1(it->E[k]) | STP_HYST_CIN(k + 1);
+    const stp_u64 Dtop = stp_dil1(up) | STP_HYST_CIN(0), Dbot = stp_dil1(dn) | STP_HYST_CIN(N + 1);
+    // a three-row window of dilated rows slides down and then up (no per-row array: the register budget of
+    // k_lines is 80 VGPRs, and anything spilled here would put scratch-memory latency into every step)
     stp_u64 grown = 0;
+    stp_u64 above = Dtop, cur = STP_HYST_D(1);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int q = 0; q < 2 * N - 1; q++) {
-        const int k = q < N ? q : 2 * N - 2 - q;  // down 0..N-1, then up N-2..0
-        const stp_u64 lowv = it->L[k], cur = it->E[k];
-        const stp_u64 seed = (D[k] | D[k + 1] | D[k + 2]) & lowv & ~cur;
+    for (int k = 0; k < N; k++) {                     // downwards: row k sees the already updated row k-1
+        const stp_u64 below = (k + 1 < N) ? STP_HYST_D(k + 2) : Dbot;
+        const stp_u64 lowv = (r0 + k < S) ? sLow[(r0 + k) * STP_NW + w] : 0ull, e = it->E[k];   // low stays in LDS
+        const stp_u64 seed = (above | cur | below) & lowv & ~e;
         if (seed) {
-            const stp_u64 nv = stp_runfill(lowv, seed) | cur;
-            it->E[k] = nv;
-            D[k + 1] = stp_dil1(nv) | STP_HYST_CIN(k + 1);
+            it->E[k] = stp_runfill(lowv, seed) | e;
+            cur = STP_HYST_D(k + 1);
             grown |= 1ull << k;
         }
+        above = cur; cur = below;
+    }
+    stp_u64 below2 = STP_HYST_D(N);                   // row N-1 as left by the downward pass
+    cur = (N >= 2) ? STP_HYST_D(N - 1) : 0ull;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = N - 2; k >= 0; k--) {                // upwards: row k sees the already updated row k+1
+        const stp_u64 abv = (k >= 1) ? STP_HYST_D(k) : Dtop;
+        const stp_u64 lowv = (r0 + k < S) ? sLow[(r0 + k) * STP_NW + w] : 0ull, e = it->E[k];
+        const stp_u64 seed = (abv | cur | below2) & lowv & ~e;
+        if (seed) {
+            it->E[k] = stp_runfill(lowv, seed) | e;
+            cur = STP_HYST_D(k + 1);
+            grown |= 1ull << k;
+        }
+        below2 = cur; cur = abv;
     }
     if (!grown) return 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -857,6 +871,7 @@ STP_HD int hyst_item_sweep(int S, stp_hyst_item* it, stp_u64* sE)
     for (int k = 0; k < N; k++)
         if ((grown >> k) & 1ull) sE[(r0 + k) * STP_NW + w] = it->E[k];
     return 1;
+#undef STP_HYST_D
 #undef STP_HYST_CIN
 }
 
@@ -1127,14 +1142,13 @@ STP_HD void lines_refine(int tid, int nt, int S, const stp_u64* sE, const stp_u6
         stp_u64* trow = sT + r * STP_NW;
         const stp_u64* erow = sE + r * STP_NW;
         const stp_u64* vrow = sV + r * STP_NW;
-        // runs are determined from the row as painted (st/en lists are built before the L loop)
-        stp_u64 orig[STP_NW];
-        for (int w = 0; w < STP_NW; w++) orig[w] = trow[w];
+        // runs are determined from the row as painted (st/en lists are built before the L loop).  The live
+        // row serves: a run's rewrite below only touches bits inside [st, en] and the scan resumes at en + 1
         int x = 0;
         while (true) {
-            int st = row_next_set(orig, x, S);
+            int st = row_next_set(trow, x, S);
             if (st >= S) break;
-            int en = row_next_clear(orig, st, S) - 1;
+            int en = row_next_clear(trow, st, S) - 1;
             int any = 0;
             for (int w = st >> 6; w <= en >> 6; w++) any |= (erow[w] & word_range_mask(w, st, en)) != 0;
             if (any) {          // testmat[r, st:en] = vert[r, st:en]   (column en untouched)

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
         stp_hyst_item hit;
         hyst_item_load(has ? tid : 0, S, bufA, bufB, &hit);
         for (int it = 0; it < 4 * STP_FRAME_MAX * STP_FRAME_MAX; it++) {
-            const int ch = has ? hyst_item_sweep(S, &hit, bufB) : 0;
+            const int ch = has ? hyst_item_sweep(S, &hit, bufA, bufB) : 0;
             if (!__syncthreads_or(ch)) break;
         }
     }

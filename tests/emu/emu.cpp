@@ -151,7 +151,7 @@ int emu_lines(const stp_u64* low, const stp_u64* high, const double* band, int W
         for (int i = 0; i < nitem; i++) hyst_item_load(i, S, buf0.data(), buf1.data(), &items[i]);
         for (;;) {
             int ch = 0;
-            for (int i = 0; i < nitem; i++) ch |= hyst_item_sweep(S, &items[i], buf1.data());
+            for (int i = 0; i < nitem; i++) ch |= hyst_item_sweep(S, &items[i], buf0.data(), buf1.data());
             if (!ch) break;
             sweeps++;
         }
