@@ -322,9 +322,10 @@ STP_HD void canny_p2(int tid, int nt, stp_tile T, int R, const double* w, const 
 #define STP_GRAY_GUARD 65536   /* bytes of padding before and after the grey images: the last tile row reads up to
                                   ty0 + CT_Y + R + 1 = 429 < 400 + 40 rows of 1600 B (R <= 12); R + 2 rows in front */
 #define CT_VRUN 12   /* vertical outputs per thread: (CT_Y + 4) = 3 * 12 */
-#define CT_HRUN 10   /* horizontal outputs per thread: ceil(68 / 10) = 7 runs x 36 rows = 252 items (one round) */
-/* columns of the transposed vertical-pass buffer the horizontal pass may touch (runs are whole: 14 x 5 + 2R) */
-#define CT_P2_COLS(R) ((((CT_X + 4) + CT_HRUN - 1) / CT_HRUN) * CT_HRUN + 2 * (R))
+#define CT_HRUN_R(R) ((R) <= 8 ? 10 : 5)   /* horizontal outputs per thread: 7 runs x 36 rows = 252 items (one round) at
+                                             radius <= 8; radius 10 would spill with a 30-double window: 14 runs of 5 */
+/* columns of the transposed vertical-pass buffer the horizontal pass may touch (runs are whole: runs x HRUN + 2R) */
+#define CT_P2_COLS(R) ((((CT_X + 4) + CT_HRUN_R(R) - 1) / CT_HRUN_R(R)) * CT_HRUN_R(R) + 2 * (R))
 // vertical pass reading the grey image directly (no LDS copy of the tile): consecutive lanes read
 // consecutive columns of one image row (coalesced); rows shared by neighbouring groups come from L1/L2.
 // YIN: every row this tile touches (ty0-R-2 .. ty0+CT_Y+R+1) lies inside the image -> no clamping.
@@ -332,33 +333,34 @@ STP_HD void canny_p2(int tid, int nt, stp_tile T, int R, const double* w, const 
 template <int R, bool YIN, bool XIN = false>
 STP_HD void canny_p1_blk_g(int tid, int nt, stp_tile T, const double* w, const float* __restrict__ gimg, float* sVT)
 {
+    constexpr int VRUN = (R <= 8) ? CT_VRUN : CT_VRUN / 2;   // radius 10 (sigma 2.5) would spill with 12 outputs per lane
     const int GW = CT_X + 2 * R + 4;
-    const int NG = (CT_Y + 4) / CT_VRUN;
+    const int NG = (CT_Y + 4) / VRUN;
     for (int i = tid; i < GW * NG; i += nt) {
         const int xx = i % GW, yg = i / GW;
-        const int yy0 = yg * CT_VRUN;
+        const int yy0 = yg * VRUN;
         const int x = T.tx0 - R - 2 + xx;
         const bool xin = XIN || (x >= 0 && x < T.S);
-        float raw[CT_VRUN + 2 * R];
+        float raw[VRUN + 2 * R];
         // Rows / columns outside the image are loaded like any other (the grey buffer carries
         // STP_GRAY_GUARD bytes of padding on both sides, so a row up to R+2 above the first image or
         // CT_Y+R+1 below the start of the last tile row is still inside the allocation) and replaced by the constant-mode 0 after
         // the load: no per-element address clamping in the border tiles.
         const float* col = gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + x;
 #pragma unroll
-        for (int k = 0; k < CT_VRUN + 2 * R; k++) raw[k] = col[k * STP_PITCH];        // all loads issued before any use
+        for (int k = 0; k < VRUN + 2 * R; k++) raw[k] = col[k * STP_PITCH];        // all loads issued before any use
         if (!YIN) {
 #pragma unroll
-            for (int k = 0; k < CT_VRUN + 2 * R; k++) {
+            for (int k = 0; k < VRUN + 2 * R; k++) {
                 const int y = T.ty0 - R - 2 + yy0 + k;
                 if ((unsigned)y >= (unsigned)T.S) raw[k] = 0.0f;
             }
         }
-        double win[CT_VRUN + 2 * R];
+        double win[VRUN + 2 * R];
 #pragma unroll
-        for (int k = 0; k < CT_VRUN + 2 * R; k++) win[k] = xin ? (double)raw[k] : 0.0;
+        for (int k = 0; k < VRUN + 2 * R; k++) win[k] = xin ? (double)raw[k] : 0.0;
 #pragma unroll
-        for (int q = 0; q < CT_VRUN; q++) {
+        for (int q = 0; q < VRUN; q++) {
             double o = win[q + R] * w[R];
 #pragma unroll
             for (int k = R; k >= 1; k--) o += (win[q + R - k] + win[q + R + k]) * w[R - k];
@@ -409,26 +411,27 @@ template <int R, bool XIN>
 STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const float* sVT, const double* sB,
                          const double* sBB, double* sS, stp_fastdiv fd)
 {
+    constexpr int HRUN = CT_HRUN_R(R);
     const int VH = CT_Y + 4, SW = CT_X + 4;
-    const int NG = (SW + CT_HRUN - 1) / CT_HRUN;
+    const int NG = (SW + HRUN - 1) / HRUN;
     for (int i = tid; i < VH * NG; i += nt) {
         const int yy = i % VH, xg = i / VH;
-        const int xx0 = xg * CT_HRUN;
+        const int xx0 = xg * HRUN;
         const int y = T.ty0 - 2 + yy;
         const bool yin = (y >= 0 && y < T.S);
-        double win[CT_HRUN + 2 * R];
+        double win[HRUN + 2 * R];
 #pragma unroll
-        for (int k = 0; k < CT_HRUN + 2 * R; k++)         // sVT column index = image x - (tx0 - R - 2)
+        for (int k = 0; k < HRUN + 2 * R; k++)         // sVT column index = image x - (tx0 - R - 2)
             win[k] = (double)sVT[(xx0 + k) * CT_VP + yy];  // columns >= CT_X+2R+4 (last run only) lie in the
                                                            // buffer's CT_P2_COLS(R) padding and feed only the
                                                            // outputs xx >= SW that are dropped below
         const double bint = sB[VH + yy] + DBL_EPSILON;
         // interior row and (tile-uniform XIN, or this item's own columns) interior columns: the verified constant
         const int xfirst = T.tx0 - 2 + xx0;
-        const bool cin = XIN || (xfirst >= R && xfirst + CT_HRUN - 1 + R < T.S);
+        const bool cin = XIN || (xfirst >= R && xfirst + HRUN - 1 + R < T.S);
         const bool fast = cin && fd.ok && yin && (bint == fd.c);
 #pragma unroll
-        for (int q = 0; q < CT_HRUN; q++) {
+        for (int q = 0; q < HRUN; q++) {
             const int xx = xx0 + q;
             if (xx >= SW) break;
             double o = win[q + R] * w[R];
