@@ -1027,28 +1027,44 @@ STP_HD stp_u64 word_range_mask(int w, int lo, int hi)   // bits of word w inside
 //   a run of z zeros: the first 5-buffer of them only fill the gap buffer; one more closes the run
 //                     (count > MAX -> MAX = count, END = J; count = buffer = 0); after that every 6th
 //                     zero closes again, which is a no-op because count is 0, so buffer = rest % 6.
+// The words are walked in order with compile-time indices (a run-time index into a 7-word register array costs
+// a 14-select chain per access): bit j of t = x ^ ((x << 1) | carry) marks a row whose value differs from the row
+// above, i.e. the end of the run that started at `prev`.
 STP_HD void col_block_scan(const stp_u64* v3, const stp_u64* v, int c, int S, int minH, int16_t* t_out, int16_t* end_out,
                            int16_t* ud_out)
 {
     int count = 0, MAX = 0, END = 0, J = 0, buffer = 0;
-    int i = 0;
-    while (i < S) {
-        if ((v3[i >> 6] >> (i & 63)) & 1ull) {
-            const int e = row_next_clear(v3, i, S);
-            count += e - i; J = e - 1; i = e;
-        } else {
-            const int e = row_next_set(v3, i, S);
-            int z = e - i;
-            if (z <= 5 - buffer) buffer += z;
-            else {
-                z -= (5 - buffer) + 1;
-                if (count > MAX) { MAX = count; END = J; }
-                count = 0;
-                buffer = z % 6;
-            }
-            i = e;
+    int prev = 0;
+    stp_u64 bit = v3[0] & 1ull;                 // value of the run that starts at row 0
+    stp_u64 carry = bit;
+#define STP_RUN_END(p) do { \
+        const int len_ = (p) - prev; \
+        if (bit) { count += len_; J = (p) - 1; } \
+        else if (len_ <= 5 - buffer) buffer += len_; \
+        else { \
+            if (count > MAX) { MAX = count; END = J; } \
+            count = 0; \
+            buffer = (len_ - (5 - buffer) - 1) % 6; \
+        } \
+        prev = (p); bit ^= 1ull; } while (0)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < STP_NW; k++) {
+        const stp_u64 x = v3[k];
+        stp_u64 t = x ^ ((x << 1) | carry);
+        const int left = S - 64 * k;            // rows of this word that exist
+        if (left <= 0) t = 0ull;
+        else if (left < 64) t &= (1ull << left) - 1ull;
+        while (t) {
+            const int p = 64 * k + stp_ctz64(t);
+            t &= t - 1ull;
+            STP_RUN_END(p);
         }
+        carry = x >> 63;
     }
+    if (S > prev) STP_RUN_END(S);
+#undef STP_RUN_END
     if (count > MAX) { MAX = count; END = J; }
     const int t = MAX;
     if (END < c) END = END - t + 1;
@@ -1056,7 +1072,10 @@ STP_HD void col_block_scan(const stp_u64* v3, const stp_u64* v, int c, int S, in
     if (above < 0) above = 0;
     if (bottom > S - 1) bottom = S - 1;
     int any = 0;
-    for (int w = above >> 6; w <= (bottom >> 6); w++) any |= (v[w] & word_range_mask(w, above, bottom)) != 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int w = 0; w < STP_NW; w++) any |= (v[w] & word_range_mask(w, above, bottom)) != 0;
     *t_out = (int16_t)t; *end_out = (int16_t)END;
     *ud_out = (int16_t)((t > minH && any) ? (END > c ? 2 : 1) : 0);
 }

@@ -535,7 +535,7 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
     for (int i = tid; i < S; i += nt) s_nz[i] = fnz[(size_t)f * STP_FRAME_MAX + i];
     lines_load(tid, nt, S, limg, himg, bufA, bufB);
     __syncthreads();
-    if (dbg_stop == 1) { if (tid == 0) rec_count[img] = (int)bufB[3]; return; }      // timing-only ablation
+    if (dbg_stop == 1) { if (tid == 0) rec_count[img] = (int)(bufB[3] & 0); return; }      // timing-only ablation
     {   // hysteresis closure: one (8-row strip x word) item per lane, rows held in registers across sweeps
         const int nitem = ((S + STP_HYST_STRIP - 1) / STP_HYST_STRIP) * STP_NW;       // <= 350 < blockDim
         const bool has = tid < nitem;
@@ -546,14 +546,14 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
             if (!__syncthreads_or(ch)) break;
         }
     }
-    if (dbg_stop == 2) { if (tid == 0) rec_count[img] = (int)bufB[3]; return; }
+    if (dbg_stop == 2) { if (tid == 0) rec_count[img] = (int)(bufB[3] & 0); return; }
     lines_vline(tid, nt, S, bufB, bufA);               // low is dead: vert goes to bufA
     for (int i = tid; i < S * STP_NW; i += nt) eimg[i] = bufB[i];   // park the edge map
     __threadfence_block();
     __syncthreads();
     lines_v3(tid, nt, S, bufA, bufB);                  // 3-column OR into the (now free) edge buffer
     __syncthreads();
-    if (dbg_stop == 3) { if (tid == 0) rec_count[img] = (int)bufA[3]; return; }
+    if (dbg_stop == 3) { if (tid == 0) rec_count[img] = (int)(bufA[3] & 0); return; }
     {   // block + keep test, one column per lane held as 7 words (waves 0..6 <-> the 7 word-columns)
         const int lane = tid & 63, cg = tid >> 6;
         if (cg < STP_NW) {
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
     }
     if (tid == 0) s_nrec = 0;
     __syncthreads();
-    if (dbg_stop == 4) { if (tid == 0) rec_count[img] = colT[3]; return; }
+    if (dbg_stop == 4) { if (tid == 0) rec_count[img] = colT[3] & 0; return; }
     if (want_dbg) {
         stp_u64* d = dbg + (size_t)img * 4 * (STP_FRAME_MAX * STP_NW);
         for (int i = tid; i < S * STP_NW; i += nt) { d[i] = eimg[i]; d[STP_FRAME_MAX * STP_NW + i] = bufA[i]; }
@@ -579,8 +579,10 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
         __syncthreads();
         lines_paint(tid, nt, S, ud, colEnd, colUd, bufB);
         __syncthreads();
+        if (dbg_stop == 7) { if (tid == 0) rec_count[img] = (int)(bufB[3] & 0); return; }
         lines_refine(tid, nt, S, eimg, bufA, bufB);
         __syncthreads();
+        if (dbg_stop == 8) { if (tid == 0) rec_count[img] = (int)(bufB[3] & 0); return; }
         {   // column counts / first / last row from the transposed testmat
             const int lane = tid & 63, cg = tid >> 6;
             if (cg < STP_NW) {
@@ -595,6 +597,7 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
             for (int i = tid; i < S * STP_NW; i += nt) d[i] = bufB[i];
         }
         __syncthreads();
+        if (dbg_stop == 9) { if (tid == 0) rec_count[img] = cnt[3] & 0; return; }
         lines_cols_count(tid, nt, S, cnt, s_wcnt);
         __syncthreads();
         lines_cols_place(tid, nt, S, cnt, s_wcnt, cidx, clen, &s_nrow);
