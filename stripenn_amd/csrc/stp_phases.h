@@ -202,7 +202,7 @@ STP_HD void gray_wblur(int lane, int strip, stp_tile T, const double* sadjw, flo
         for (int c = 0; c < 3; c++) acc = acc + w1[c];
 #pragma unroll
         for (int c = 0; c < 3; c++) acc = acc + w2[c];
-        if (acc > 1.0) acc = 1.0;                             // (a sum of products >= 0 starting at +0 is never < 0)
+        acc = fmin(acc, 1.0);                                 // np.clip upper bound (the sum is finite and >= +0: one v_min_f64)
         const float g32 = (float)acc;
         float v = r32 * 0.299f;
         v = v + g32 * 0.587f;
