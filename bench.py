@@ -29,8 +29,8 @@ SCORE_KERNELS = ('pvalue', 'stripiness')
 # HBM bytes per launch of the chain kernels for THIS default workload, from rocprofv3 PMC passes
 # (profiles/r01e_pmc.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, KB units, FETCH_SIZE
 # doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read inside this script.
-PMC_TRAFFIC_BYTES = {'canny': (2 * 921158 + 269002) * 1024.0, 'gray': (2 * 331793 + 1850574) * 1024.0,
-                     'lines': (2 * 173265 + 256093) * 1024.0}
+PMC_TRAFFIC_BYTES = {'canny': (2 * 922851 + 254623) * 1024.0, 'gray': (2 * 331738 + 1850574) * 1024.0,
+                     'lines': (2 * 109698 + 64509) * 1024.0}
 
 
 def frame_table(nbins):
