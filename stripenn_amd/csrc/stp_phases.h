@@ -144,21 +144,27 @@ STP_HD void gray_p2(int tid, int nt, stp_tile T, int a, const double* sadj, floa
 // 8-row strips, one per wave, lane = column.  A wave writes the adj values of ITS strip (+1 halo row
 // above / below, +1 halo column left / right) into its own LDS slice and then blurs them, so the
 // brightness loop needs no workgroup barrier; the blur keeps the row-major tap order of cv.filter2D.
-// sg: (GT_Y+2) x (GT_X+2) g plane of the whole tile; sadjw: 10 x (GT_X+2) doubles of this wave.
+// sg: (GT_Y+2) x (GT_X+2) g plane of the whole tile; srow: ONE row of GT_X+2 products owned by this wave.
 #define GS_ROWS 8
-// sadjw holds kv * adj (kv = 1/9): every tap of cv.filter2D multiplies by the same kv, so the product
-// is formed (and rounded) once per pixel and the nine outputs that use it only add.
-STP_HD void gray_wadj(int lane, int strip, double b, const double* sg, double* sadjw)
+// A wave owns an 8-row strip and walks its 10 product rows (strip rows -1 .. 8) top to bottom.  Every tap of
+// cv.filter2D multiplies by the same kv = 1/9, so the product kv * adj is formed (and rounded) once per pixel
+// and the nine outputs that use it only add.  Only the newest product row travels through LDS (a lane needs its
+// neighbours' two columns); the two rows above it stay in the lane's registers.  One row per wave instead of ten
+// keeps the kernel's LDS at 20 KB (7 workgroups per CU instead of 4).
+struct stp_gray_lane {
+    double w0[3], w1[3];           // products of the two previous rows, columns lane .. lane+2
+    unsigned vmin, vmax;           // bit patterns of the smallest / largest grey value stored (see STP_FLAT_RANGE)
+};
+STP_HD void gray_wrow_put(int lane, int strip, int r, double b, const double* sg, double* srow)
 {
     const int WW = GT_X + 2;
     const double k = (1.0 - 0.0) / (b - 0.0);
     const double kv = 1.0 / 9.0;
-    const double* g0 = sg + (strip * GS_ROWS) * WW;          // strip rows -1 .. 8 are sg rows strip*8 .. +9
-#pragma unroll
-    for (int r = 0; r < GS_ROWS + 2; r++) sadjw[r * WW + lane + 1] = stp_bright_kv(g0[r * WW + lane + 1], b, k, kv);
-    if (lane < 2 * (GS_ROWS + 2)) {                           // the two halo columns
-        const int r = lane >> 1, c = (lane & 1) ? WW - 1 : 0;
-        sadjw[r * WW + c] = stp_bright_kv(g0[r * WW + c], b, k, kv);
+    const double* g = sg + (strip * GS_ROWS + r) * WW;       // strip rows -1 .. 8 are sg rows strip*8 .. +9
+    srow[lane + 1] = stp_bright_kv(g[lane + 1], b, k, kv);
+    if (lane < 2) {                                           // the two halo columns
+        const int c = lane ? WW - 1 : 0;
+        srow[c] = stp_bright_kv(g[c], b, k, kv);
     }
 }
 // Flat-window rule of the Canny stage.  Every smoothed value is a convex combination of the in-image grey
@@ -175,49 +181,55 @@ STP_HD void gray_wadj(int lane, int strip, double b, const double* sg, double* s
 #define GC_ROWS (STP_FRAME_MAX / GC_CY)                /* 50 */
 #define GC_COLS ((STP_FRAME_MAX + 63) / 64 * 64 / GC_CX) /* 28 */
 
-// vmin / vmax: running min / max of the BIT PATTERNS of the stored grey values (they are >= +0, so the
-// patterns order like the values and one integer min / max instruction each does it)
-STP_HD void gray_wblur(int lane, int strip, stp_tile T, const double* sadjw, float* __restrict__ gray_img,
-                       unsigned* vmin, unsigned* vmax)
+// The lane's three products of row r; from the third row on they complete the 3 x 3 window of grey pixel
+// (strip row r - 2, column lane).  The grey values are >= +0, so their bit patterns order like the values and
+// one integer min / max instruction each tracks the range.
+STP_HD void gray_wrow_get(int lane, int strip, int r, stp_tile T, const double* srow, stp_gray_lane* st,
+                          float* __restrict__ gray_img)
 {
-    const int WW = GT_X + 2;
-    const double kv = 1.0 / 9.0;
-    double rb = 0.0;
-    for (int t = 0; t < 9; t++) rb = rb + kv * 1.0;
-    if (rb < 0.0) rb = 0.0;
-    if (rb > 1.0) rb = 1.0;
-    const float r32 = (float)rb;
-    const int x = T.tx0 + lane;
-    double w0[3], w1[3], w2[3];                               // three rows of the 3-column window (products kv*adj)
+    double w2[3];
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int c = 0; c < 3; c++) { w0[c] = sadjw[0 * WW + lane + c]; w1[c] = sadjw[1 * WW + lane + c]; }
-#pragma unroll
-    for (int q = 0; q < GS_ROWS; q++) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) w2[c] = sadjw[(q + 2) * WW + lane + c];
+#endif
+    for (int c = 0; c < 3; c++) w2[c] = srow[lane + c];
+    if (r >= 2) {
+        const double kv = 1.0 / 9.0;
+        double rb = 0.0;
+        for (int t = 0; t < 9; t++) rb = rb + kv * 1.0;
+        if (rb < 0.0) rb = 0.0;
+        if (rb > 1.0) rb = 1.0;
+        const float r32 = (float)rb;
         double acc = 0.0;                                     // row-major tap order of cv.filter2D
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-        for (int c = 0; c < 3; c++) acc = acc + w0[c];
+#endif
+        for (int c = 0; c < 3; c++) acc = acc + st->w0[c];
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-        for (int c = 0; c < 3; c++) acc = acc + w1[c];
+#endif
+        for (int c = 0; c < 3; c++) acc = acc + st->w1[c];
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
+#endif
         for (int c = 0; c < 3; c++) acc = acc + w2[c];
         acc = fmin(acc, 1.0);                                 // np.clip upper bound (the sum is finite and >= +0: one v_min_f64)
         const float g32 = (float)acc;
         float v = r32 * 0.299f;
         v = v + g32 * 0.587f;
         v = v + g32 * 0.114f;
-        const int y = T.ty0 + strip * GS_ROWS + q;
+        const int y = T.ty0 + strip * GS_ROWS + (r - 2), x = T.tx0 + lane;
         if (y < T.S && x < T.S) {
             gray_img[y * STP_PITCH + x] = v;
             unsigned bits;
             memcpy(&bits, &v, 4);
-            *vmin = bits < *vmin ? bits : *vmin;
-            *vmax = bits > *vmax ? bits : *vmax;
+            st->vmin = bits < st->vmin ? bits : st->vmin;
+            st->vmax = bits > st->vmax ? bits : st->vmax;
         }
-#pragma unroll
-        for (int c = 0; c < 3; c++) { w0[c] = w1[c]; w1[c] = w2[c]; }
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int c = 0; c < 3; c++) { st->w0[c] = st->w1[c]; st->w1[c] = w2[c]; }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -87,11 +87,11 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
                                                const double* __restrict__ bvals, int nb, int a,
                                                float* __restrict__ gray, float2* __restrict__ cells)
 {
-    // AMAX = 1 (bfilter 3): 39 KB of LDS -> 4 workgroups per CU; the generic instance is sized for bfilter <= 7
+    // AMAX = 1 (bfilter 3): 20 KB of LDS -> 7 workgroups per CU; the generic instance is sized for bfilter <= 7
     constexpr int SG_N = (GT_Y + 2 * AMAX) * (GT_X + 2 * AMAX);
-    constexpr int SADJ_W = 4 * (GS_ROWS + 2) * (GT_X + 2);
+    constexpr int SADJ_W = 4 * (GT_X + 2);               // bfilter 3: one product row per wave
     __shared__ double sg[SG_N];
-    __shared__ double sadj[SG_N > SADJ_W ? SG_N : SADJ_W];
+    __shared__ double sadj[AMAX == 1 ? SADJ_W : SG_N];
     const int fl = blockIdx.z, lev = blockIdx.y, f = f0 + fl;
     const int S = fS[f];
     if (S == 0) return;
@@ -137,14 +137,24 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
     if (AMAX == 1) {
         // wave-strip form: no workgroup barrier in the brightness loop (LDS ops of one wave are in order)
         const int lane = tid & 63, strip = tid >> 6;
-        double* sadjw = sadj + strip * ((GS_ROWS + 2) * (GT_X + 2));
+        double* srow = sadj + strip * (GT_X + 2);
         for (int bi = 0; bi < nb; bi++) {
             const size_t img = ((size_t)fl * nlev + lev) * nb + bi;
-            gray_wadj(lane, strip, bvals[bi], sg, sadjw);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            unsigned vmn = 0x7F800000u, vmx = 0u;              // +inf / +0: a cell without pixels unites to nothing
-            gray_wblur(lane, strip, T, sadjw, gray + img * (size_t)(STP_PITCH * STP_PITCH), &vmn, &vmx);
+            float* gimg = gray + img * (size_t)(STP_PITCH * STP_PITCH);
+            stp_gray_lane st;
+            st.vmin = 0x7F800000u; st.vmax = 0u;                // +inf / +0: a cell without pixels unites to nothing
+#pragma unroll
+            for (int c = 0; c < 3; c++) st.w0[c] = st.w1[c] = 0.0;
+#pragma unroll
+            for (int r = 0; r < GS_ROWS + 2; r++) {
+                gray_wrow_put(lane, strip, r, bvals[bi], sg, srow);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                gray_wrow_get(lane, strip, r, T, srow, &st, gimg);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the reads above precede the next row's writes
+                __builtin_amdgcn_wave_barrier();
+            }
+            unsigned vmn = st.vmin, vmx = st.vmax;
             // min / max of the strip's grey values per 16-column cell (see STP_FLAT_RANGE)
 #pragma unroll
             for (int o = 1; o < GC_CX; o <<= 1) {

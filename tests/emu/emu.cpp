@@ -38,9 +38,17 @@ void emu_gray(const double* band, int W, int hw, int64_t st, const int16_t* nz, 
             for (int bi = 0; bi < nb; bi++) {
                 if (a == 1) {       // wave-strip form (the device path for bfilter 3): lanes replayed one by one
                     for (int strip = 0; strip < GT_Y / GS_ROWS; strip++) {
-                        double* sw = sadj.data() + strip * ((GS_ROWS + 2) * (GT_X + 2));
-                        for (int lane = 0; lane < 64; lane++) gray_wadj(lane, strip, bvals[bi], sg.data(), sw);
-                        for (int lane = 0; lane < 64; lane++) { unsigned mn = 0, mx = 0; gray_wblur(lane, strip, T, sw, gray + (size_t)bi * STP_PITCH * STP_PITCH, &mn, &mx); }
+                        double* srow = sadj.data() + strip * (GT_X + 2);
+                        stp_gray_lane st[64];
+                        for (int lane = 0; lane < 64; lane++) {
+                            st[lane].vmin = 0x7F800000u; st[lane].vmax = 0u;
+                            for (int c = 0; c < 3; c++) st[lane].w0[c] = st[lane].w1[c] = 0.0;
+                        }
+                        for (int r = 0; r < GS_ROWS + 2; r++) {
+                            for (int lane = 0; lane < 64; lane++) gray_wrow_put(lane, strip, r, bvals[bi], sg.data(), srow);
+                            for (int lane = 0; lane < 64; lane++)
+                                gray_wrow_get(lane, strip, r, T, srow, &st[lane], gray + (size_t)bi * STP_PITCH * STP_PITCH);
+                        }
                     }
                 } else {
                     gray_p1(0, 1, a, bvals[bi], sg.data(), sadj.data());
