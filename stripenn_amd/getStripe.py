@@ -285,10 +285,21 @@ class getStripe:
             if a > b:
                 a, b = b, a
             pos = '%s:%d-%d' % (chrom, a, b)
-            mat = nantozero(np.array(self.unbalLib.fetch(pos, pos), dtype=np.float64))
-            matsum = np.sum(mat, axis=1)
-            poolsum += int(len(matsum) - np.count_nonzero(matsum == 0))
+            live = self._rows_nonzero(pos, pos)[0]
+            poolsum += int(np.count_nonzero(live))
         return poolsum
+
+    def _rows_nonzero(self, p1, p2):
+        """(rows whose sum over the fetched block is non-zero after NaN -> 0, the block or None).  A selector that
+        can answer from its own tables (PixelSelector.row_nonzero) spares the dense block; it is then fetched
+        only by the caller that really needs its pixels."""
+        fast = getattr(self.unbalLib, 'row_nonzero', None)
+        if fast is not None:
+            live = fast(p1, p2)
+            if live is not None:
+                return live, None
+        mat = nantozero(np.array(self.unbalLib.fetch(p1, p2), dtype=np.float64))
+        return np.sum(mat, axis=1) != 0, mat
 
     def null_samplesizes(self, chromnames2, n_available_col):
         """:278-283 (the sample-size array keeps its unfiltered indexing, as in the reference)"""
@@ -320,33 +331,27 @@ class getStripe:
             for it in range(itera):
                 last_it = it
                 p1, p2, r0, r1, c0, c1 = self._unit_regions(chrom, it, chrsize, unitsize)
-                mat = nantozero(np.array(self.unbalLib.fetch(p1, p2), dtype=np.float64))
-                nrow = mat.shape[0]
-                matsum = np.sum(mat, axis=1)
-                zero = set(np.where(matsum == 0)[0].tolist())
-                pool = [x for x in range(nrow) if x not in zero]
+                live, mat = self._rows_nonzero(p1, p2)
+                pool = np.nonzero(live)[0].tolist()
                 pool = [x for x in pool if x > 20 and x < (unitsize - 20)]
                 if it == 0:
-                    pool = [x for x in pool if x > 410 and x < mat.shape[1]]
+                    pool = [x for x in pool if x > 410 and x < (c1 - c0)]
                 n_pool.append(len(pool))
                 if len(pool) == 0:
                     continue
                 k = len(pool) if len(pool) < sss else sss
                 randval = prng.choices(pool, k=k)
-                collected += self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if it > 0 else 0, bs, mat)
+                collected += self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if it > 0 else 0, bs, mat, (p1, p2))
             depl = int(ss) - collected                             # :416-477
             if depl > 0:
                 rich = int(np.argmax(n_pool))
                 p1, p2, r0, r1, c0, c1 = self._unit_regions(chrom, rich, chrsize, unitsize)
-                mat = nantozero(np.array(self.unbalLib.fetch(p1, p2), dtype=np.float64))
-                nrow = mat.shape[0]
-                matsum = np.sum(mat, axis=1)
-                zero = set(np.where(matsum == 0)[0].tolist())
-                pool = [x for x in range(nrow) if x not in zero]
+                live, mat = self._rows_nonzero(p1, p2)
+                pool = np.nonzero(live)[0].tolist()
                 pool = [x for x in pool if x > 20 and x < (unitsize - 20)]
                 randval = prng.choices(pool, k=depl)
                 # the reference tests the loop variable `it` left over from the unit loop (:458)
-                self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if last_it > 0 else 0, bs, mat)
+                self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if last_it > 0 else 0, bs, mat, (p1, p2))
         return [np.column_stack([np.zeros((400, 0))] + t) for t in tabs]
 
     @staticmethod
@@ -355,7 +360,7 @@ class getStripe:
         out = [np.column_stack([np.zeros((400, 0))] + [p[k] for p in parts]) for k in range(4)]
         return out[0], out[1], out[2], out[3]
 
-    def _null_batch(self, band, tabs, randval, r0, r1, c0, c1, yoff, bs, mat):
+    def _null_batch(self, band, tabs, randval, r0, r1, c0, c1, yoff, bs, mat, regions=None):
         """One batch of sampled rows.  The resident band serves every window unless a Python slice
         of the reference wraps around (negative start) or leaves the band; then the unit matrix the
         host has just fetched for the pool is handed to the kernel instead."""
@@ -365,7 +370,11 @@ class getStripe:
         xmin, xmax = min(randval), max(randval)
         wraps = (xmin - up - bs < 0) or (xmin + yoff - 399 - up < 0)
         reach = 399 + up + (bs - up) + bs + abs((c0 + yoff) - r0)      # farthest |col - row| a window touches
-        unit = mat if (wraps or reach >= self.halfwidth) else None
+        unit = None
+        if wraps or reach >= self.halfwidth:
+            if mat is None:                      # the pool came from the selector's own tables: fetch the block now
+                mat = nantozero(np.array(self.unbalLib.fetch(*regions), dtype=np.float64))
+            unit = mat
         samples = np.zeros(len(randval), dtype=NULL_SAMPLE_DTYPE)
         samples['row0'], samples['nrow'] = r0, r1 - r0
         samples['col0'], samples['ncol'] = c0, c1 - c0

@@ -168,6 +168,34 @@ class PixelSelector:
         lo, _ = self.table.chrom_bins(n1)
         return self._dense(r0 + lo, r1 + lo, c0 + lo, c1 + lo)
 
+    def row_nonzero(self, region, region2=None):
+        """Which rows of `fetch(region, region2)` have a non-zero sum after NaN -> 0 (what nulldist's pools
+        ask of the unit matrix, getStripe.py:329-331), straight from the pixel table.  Returns None when the
+        table holds negative values (then only the dense sum can tell)."""
+        n1, r0, r1 = self._extent(region)
+        n2, c0, c1 = (n1, r0, r1) if region2 is None else self._extent(region2)
+        if n1 != n2:
+            raise ValueError('trans fetch is not on the stripenn path')
+        t = self.table
+        if self._vals is None:
+            self._vals = pixel_values(t.count, self.w, t.bin1_id, t.bin2_id)
+        if getattr(self, '_nonneg', None) is None:
+            self._nonneg = not bool(np.any(self._vals < 0))
+        if not self._nonneg:
+            return None
+        lo, _ = t.chrom_bins(n1)
+        R0, R1, C0, C1 = r0 + lo, r1 + lo, c0 + lo, c1 + lo
+        hit = np.zeros(r1 - r0, dtype=bool)
+        a, b = t.rows_slice(R0, R1)                                  # stored pixels: bin1 in rows, bin2 in cols
+        b2 = t.bin2_id[a:b]
+        ok = (b2 >= C0) & (b2 < C1) & (self._vals[a:b] > 0)
+        hit[np.unique(t.bin1_id[a:b][ok] - R0)] = True
+        a, b = t.rows_slice(C0, C1)                                  # mirror images: bin2 in rows, bin1 in cols
+        b2 = t.bin2_id[a:b]
+        ok = (b2 >= R0) & (b2 < R1) & (self._vals[a:b] > 0)
+        hit[np.unique(b2[ok] - R0)] = True
+        return hit
+
     def __getitem__(self, key):
         """cooler's `matrix[r0:r1, c0:c1]` with GLOBAL bin indices (getStripe.py:107-158, the `-s` quantile)."""
         rs, cs = key

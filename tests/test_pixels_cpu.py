@@ -130,3 +130,19 @@ def test_global_bin_slicing_and_slow_quantile():
     fast = obj.getQuantile_original(Info, names, [0.95, 0.99])
     for n in names:
         assert np.all(np.isfinite(slow[n])) and np.allclose(slow[n], fast[n], rtol=0.05)
+
+
+def test_row_nonzero_equals_dense_row_sums():
+    names, chroms, t = _genome(nan_frac=0.05)
+    for balance in (True, False):
+        sel = pixels.PixelSelector(t, balance)
+        for nm, n in (('chrA', 900), ('chrB', 700)):
+            for (r0, r1, c0, c1) in ((0, n, 0, n), (100, 300, 0, 700), (405, 500, 5, 900 if nm == 'chrA' else 700), (0, 50, 400, 600)):
+                p1 = '%s:%d-%d' % (nm, r0 * RESOL + 1, r1 * RESOL)
+                p2 = '%s:%d-%d' % (nm, c0 * RESOL + 1, min(c1, n) * RESOL)
+                D = sel.fetch(p1, p2)
+                D = np.where(np.isnan(D), 0.0, D)
+                assert np.array_equal(sel.row_nonzero(p1, p2), D.sum(axis=1) != 0), (balance, nm, r0, r1, c0, c1)
+    # a table with a negative value cannot answer without the dense sum
+    neg = pixels.PixelTable(['c'], [20 * RESOL], RESOL, [0, 20], [1, 2], [3, 4], [5, -5])
+    assert pixels.PixelSelector(neg, False).row_nonzero('c') is None
