@@ -324,6 +324,7 @@ class getStripe:
             ss = samplesize[c]                                     # (index into the unfiltered array, :295-298)
             chrsize, itera, unitsize = self._unit_geometry(chrom)
             band = self._band(chrom)
+            self._null_pending = []
             n_pool = []
             collected = 0
             sss = int(ss / itera)
@@ -352,6 +353,7 @@ class getStripe:
                 randval = prng.choices(pool, k=depl)
                 # the reference tests the loop variable `it` left over from the unit loop (:458)
                 self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if last_it > 0 else 0, bs, mat, (p1, p2))
+            self._null_flush(band, tabs, bs)
         return [np.column_stack([np.zeros((400, 0))] + t) for t in tabs]
 
     @staticmethod
@@ -380,10 +382,32 @@ class getStripe:
         samples['col0'], samples['ncol'] = c0, c1 - c0
         samples['x'] = np.asarray(randval, dtype=np.int32)
         samples['yoff'] = yoff
+        if unit is None:
+            # served by the resident band: nothing on the host depends on the result, so the batch only takes
+            # its place in the tables now and all such batches of the chromosome go to the device in one launch
+            for t in tabs:
+                t.append(None)
+            self._null_pending.append((len(tabs[0]) - 1, samples))
+            return len(randval)
         lu, ru, ld, rd = self.backend.null_windows(band, samples, bs, unit)
         for t, a in zip(tabs, (lu, ru, ld, rd)):
             t.append(a)
         return len(randval)
+
+    def _null_flush(self, band, tabs, bs):
+        """Run the deferred band-served batches of one chromosome as one device call and drop the results
+        into their places (column order = batch order, as the reference appends them)."""
+        pend, self._null_pending = self._null_pending, []
+        if not pend:
+            return
+        allsamp = np.concatenate([p[1] for p in pend])
+        res = self.backend.null_windows(band, allsamp, bs, None)
+        o = 0
+        for pos, samp in pend:
+            n = len(samp)
+            for t, a in zip(tabs, res):
+                t[pos] = a[:, o:o + n]
+            o += n
 
     # ------------------------------------------------------------------ observed mean (score only)
     def getMean(self, df, mask='0'):

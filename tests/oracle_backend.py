@@ -86,10 +86,16 @@ class OracleBackend:
         n = len(samples)
         if n == 0:
             return [np.zeros((400, 0)) for _ in range(4)]
-        s0 = samples[0]
         src = band.block if unit_matrix is None else (lambda r0, r1, c0, c1: unit_matrix)
-        return O.null_windows(src, int(s0['row0']), int(s0['nrow']), int(s0['col0']), int(s0['ncol']),
-                              samples['x'].astype(np.int64), int(s0['yoff']), bs)
+        # one oracle call per run of samples that share a unit geometry (the facade batches several units per call)
+        geo = np.stack([samples[k].astype(np.int64) for k in ('row0', 'nrow', 'col0', 'ncol', 'yoff')], axis=1)
+        cuts = [0] + [i for i in range(1, n) if not np.array_equal(geo[i], geo[i - 1])] + [n]
+        parts = []
+        for a, b in zip(cuts, cuts[1:]):
+            s0 = samples[a]
+            parts.append(O.null_windows(src, int(s0['row0']), int(s0['nrow']), int(s0['col0']), int(s0['ncol']),
+                                        samples['x'][a:b].astype(np.int64), int(s0['yoff']), bs))
+        return [np.concatenate([p[k] for p in parts], axis=1) for k in range(4)]
 
     def set_background(self, lu, ru, ld, rd):
         self.bg = (np.asarray(lu), np.asarray(ru), np.asarray(ld), np.asarray(rd))
