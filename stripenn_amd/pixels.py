@@ -189,11 +189,11 @@ class PixelSelector:
         a, b = t.rows_slice(R0, R1)                                  # stored pixels: bin1 in rows, bin2 in cols
         b2 = t.bin2_id[a:b]
         ok = (b2 >= C0) & (b2 < C1) & (self._vals[a:b] > 0)
-        hit[np.unique(t.bin1_id[a:b][ok] - R0)] = True
+        hit[t.bin1_id[a:b][ok] - R0] = True
         a, b = t.rows_slice(C0, C1)                                  # mirror images: bin2 in rows, bin1 in cols
         b2 = t.bin2_id[a:b]
         ok = (b2 >= R0) & (b2 < R1) & (self._vals[a:b] > 0)
-        hit[np.unique(b2[ok] - R0)] = True
+        hit[b2[ok] - R0] = True
         return hit
 
     def __getitem__(self, key):
