@@ -157,9 +157,8 @@ class getStripe:
             try:
                 if hasattr(self.unbalLib, 'chrom_pixels'):
                     # pixel-table source: the dense symmetric matrix holds every off-diagonal pixel twice
-                    from .pixels import pixel_values
-                    px = self.unbalLib.chrom_pixels(CHROM)
-                    v = pixel_values(px['count'], px['weight'], px['bin1'], px['bin2'])
+                    px = self.unbalLib.chrom_pixels(CHROM, with_values=True)
+                    v = px['values']
                     off = px['bin1'] != px['bin2']
                     vo = v[off & (v > 0)]
                     self.backend.select_append(sel, vo)

@@ -155,9 +155,22 @@ class PixelSelector:
             raise ValueError('Genomic region out of bounds: %s' % region)
         return name, s // self.resol, -(-e // self.resol)
 
-    def chrom_pixels(self, chrom):
-        b1, b2, cn, lo, n = self.table.chrom_pixels(chrom)
-        return dict(bin1=b1, bin2=b2, count=cn, weight=self.w, lo=lo, nrows=n)
+    def values(self):
+        """Balanced value of every stored pixel of the table (formed once per selector)."""
+        if self._vals is None:
+            t = self.table
+            self._vals = pixel_values(t.count, self.w, t.bin1_id, t.bin2_id)
+        return self._vals
+
+    def chrom_pixels(self, chrom, with_values=False):
+        t = self.table
+        b1, b2, cn, lo, n = t.chrom_pixels(chrom)
+        out = dict(bin1=b1, bin2=b2, count=cn, weight=self.w, lo=lo, nrows=n)
+        if with_values:                       # the cis pixels are the chromosome's row slice minus trans pixels
+            a, b = t.rows_slice(lo, lo + n)
+            v = self.values()[a:b]
+            out['values'] = v if len(v) == len(b1) else v[t.bin2_id[a:b] < lo + n]
+        return out
 
     def fetch(self, region, region2=None):
         self.nfetch += 1
@@ -177,8 +190,7 @@ class PixelSelector:
         if n1 != n2:
             raise ValueError('trans fetch is not on the stripenn path')
         t = self.table
-        if self._vals is None:
-            self._vals = pixel_values(t.count, self.w, t.bin1_id, t.bin2_id)
+        self.values()
         if getattr(self, '_nonneg', None) is None:
             self._nonneg = not bool(np.any(self._vals < 0))
         if not self._nonneg:
@@ -214,9 +226,7 @@ class PixelSelector:
             b1 = t.bin1_id[a:b]; b2 = t.bin2_id[a:b]
             keep = (b2 >= B0) & (b2 < B1)
             b1, b2 = b1[keep], b2[keep]
-            if self._vals is None:
-                self._vals = pixel_values(t.count, self.w, t.bin1_id, t.bin2_id)
-            v = self._vals[a:b][keep]
+            v = self.values()[a:b][keep]
             if mirror:
                 out[b2 - R0, b1 - C0] = v
             else:
