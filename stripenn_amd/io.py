@@ -63,5 +63,12 @@ def open_matrix(cool):
     try:
         import cooler
     except ImportError as e:
-        raise ImportError('cooler is required to open %r (only "synth:" inputs work without it)' % cool) from e
+        try:                                   # no cooler: read the file's tables directly (cooler URI "path::group")
+            import h5py  # noqa: F401
+        except ImportError:
+            raise ImportError('cooler or h5py is required to open %r (only "synth:" / "pixels:*.npz" inputs work '
+                              'without them)' % cool) from e
+        from . import pixels
+        path, _, group = str(cool).partition('::')
+        return pixel_matrix(pixels.PixelTable.from_cool(path, group.lstrip('/') or None))
     return cooler.Cooler(cool)
