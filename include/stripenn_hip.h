@@ -209,6 +209,12 @@ int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rects, i
 typedef struct stp_select stp_select;
 int stp_select_create(stp_ctx* ctx, stp_select** out);
 int stp_select_append(stp_ctx* ctx, stp_select* sel, const double* values_host, int64_t n);
+/* Append the balanced values of cooler pixels (bin1_id <= bin2_id, count; value = (count * w[bin1]) * w[bin2], or
+ * (double)count when weight == NULL) as the dense symmetric matrix would hold them: an off-diagonal pixel counts
+ * twice (getStripe.py:160-176 takes the quantile over the full square matrix).  The values are formed on the
+ * device from the table columns; nothing dense and no host-side product array exists. */
+int stp_select_append_pixels(stp_ctx* ctx, stp_select* sel, const int64_t* bin1_id, const int64_t* bin2_id,
+                             const int32_t* count, int64_t npix, const double* weight, int64_t nbins_total);
 int stp_select_count(stp_ctx* ctx, stp_select* sel, int64_t* n_positive);
 int stp_select_ranks(stp_ctx* ctx, stp_select* sel, const int64_t* ranks, int32_t nranks, double* out);
 void stp_select_free(stp_ctx* ctx, stp_select* sel);

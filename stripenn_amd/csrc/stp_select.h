@@ -22,6 +22,20 @@ __global__ __launch_bounds__(256) void k_sel_count(const double* __restrict__ v,
     if ((threadIdx.x & 63) == 0 && loc) atomicAdd(cnt, loc);
 }
 
+// balanced value of every stored pixel, twice for off-diagonal ones (slot 2p+1 stays 0 = ignored on the diagonal)
+__global__ __launch_bounds__(256) void k_sel_pixel_values(const int64_t* __restrict__ b1, const int64_t* __restrict__ b2,
+                                                           const int32_t* __restrict__ cnt, long long n,
+                                                           const double* __restrict__ w, long long nbins, double* __restrict__ out)
+{
+    for (long long p = blockIdx.x * 256ll + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
+        const long long i = b1[p], j = b2[p];
+        double v = (double)cnt[p];
+        if (w) v = (i >= 0 && j >= 0 && i < nbins && j < nbins) ? (v * w[i]) * w[j] : 0.0;
+        out[2 * p] = v;
+        out[2 * p + 1] = (i != j) ? v : 0.0;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ v, long long n, int shift, int width, int pass,
                                                    stp_sel_state* __restrict__ st)
 {

@@ -1726,6 +1726,46 @@ int stp_select_append(stp_ctx* ctx, stp_select* s, const double* values_host, in
     return STP_OK;
 }
 
+static unsigned sel_grid(long long n);
+
+int stp_select_append_pixels(stp_ctx* ctx, stp_select* s, const int64_t* bin1, const int64_t* bin2, const int32_t* count,
+                             int64_t npix, const double* weight, int64_t nbins_total)
+{
+    if (!ctx || !s || npix < 0 || (npix > 0 && (!bin1 || !bin2 || !count)) || (weight && nbins_total <= 0)) return STP_E_ARG;
+    if (npix == 0) return STP_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t CH = (int64_t)1 << 23;                 // pixels per staged chunk
+    const int64_t nch = npix < CH ? npix : CH;
+    dev_buf d1, d2, dc, dw;
+    HIPCHK(d1.alloc(ctx, (size_t)nch * sizeof(int64_t)));
+    HIPCHK(d2.alloc(ctx, (size_t)nch * sizeof(int64_t)));
+    HIPCHK(dc.alloc(ctx, (size_t)nch * sizeof(int32_t)));
+    if (weight) {
+        HIPCHK(dw.alloc(ctx, (size_t)nbins_total * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(dw.p, weight, (size_t)nbins_total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    for (int64_t p0 = 0; p0 < npix; p0 += CH) {
+        const int64_t n = npix - p0 < CH ? npix - p0 : CH;
+        double* out = nullptr;
+        HIPCHK(hipMalloc((void**)&out, (size_t)n * 2 * sizeof(double)));
+        hipError_t e = hipMemcpyAsync(d1.p, bin1 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d2.p, bin2 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dc.p, count + p0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            prof_scope ps(ctx, "select_pixels", 36.0 * n);
+            hipLaunchKernelGGL(k_sel_pixel_values, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)d1.p,
+                               (const int64_t*)d2.p, (const int32_t*)dc.p, (long long)n, weight ? (const double*)dw.p : nullptr,
+                               (long long)nbins_total, out);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the staging buffers are reused
+        if (e != hipSuccess) { (void)hipFree(out); return set_err(ctx, STP_E_HIP, std::string("select append pixels: ") + hipGetErrorString(e)); }
+        s->chunks.push_back(std::make_pair(out, (long long)(2 * n)));
+        s->npos = -1;
+    }
+    return STP_OK;
+}
+
 static unsigned sel_grid(long long n)
 {
     long long g = (n + 256 * 8 - 1) / (256 * 8);

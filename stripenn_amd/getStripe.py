@@ -157,13 +157,8 @@ class getStripe:
             try:
                 if hasattr(self.unbalLib, 'chrom_pixels'):
                     # pixel-table source: the dense symmetric matrix holds every off-diagonal pixel twice
-                    px = self.unbalLib.chrom_pixels(CHROM, with_values=True)
-                    v = px['values']
-                    off = px['bin1'] != px['bin2']
-                    vo = v[off & (v > 0)]
-                    self.backend.select_append(sel, vo)
-                    self.backend.select_append(sel, vo)
-                    self.backend.select_append(sel, v[~off & (v > 0)])
+                    px = self.unbalLib.chrom_pixels(CHROM)
+                    self.backend.select_append_pixels(sel, px['bin1'], px['bin2'], px['count'], px['weight'])
                     nb = 0
                 strip = max(1, int(16e6 // max(nb, 1)))                 # <= 128 MB of float64 per fetch
                 for r0 in range(0, nb, strip):

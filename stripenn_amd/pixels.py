@@ -139,7 +139,8 @@ class PixelSelector:
         self.w = table.weight(balance)
         self.resol = table.binsize
         self.nfetch = 0
-        self._vals = None            # balanced value of every stored pixel, formed on first dense read
+        self._nonneg = None          # no negative count / weight anywhere: row sums are zero iff all pixels are
+        self._pos = None
 
     def _extent(self, region):
         region = str(region)
@@ -155,22 +156,9 @@ class PixelSelector:
             raise ValueError('Genomic region out of bounds: %s' % region)
         return name, s // self.resol, -(-e // self.resol)
 
-    def values(self):
-        """Balanced value of every stored pixel of the table (formed once per selector)."""
-        if self._vals is None:
-            t = self.table
-            self._vals = pixel_values(t.count, self.w, t.bin1_id, t.bin2_id)
-        return self._vals
-
-    def chrom_pixels(self, chrom, with_values=False):
-        t = self.table
-        b1, b2, cn, lo, n = t.chrom_pixels(chrom)
-        out = dict(bin1=b1, bin2=b2, count=cn, weight=self.w, lo=lo, nrows=n)
-        if with_values:                       # the cis pixels are the chromosome's row slice minus trans pixels
-            a, b = t.rows_slice(lo, lo + n)
-            v = self.values()[a:b]
-            out['values'] = v if len(v) == len(b1) else v[t.bin2_id[a:b] < lo + n]
-        return out
+    def chrom_pixels(self, chrom):
+        b1, b2, cn, lo, n = self.table.chrom_pixels(chrom)
+        return dict(bin1=b1, bin2=b2, count=cn, weight=self.w, lo=lo, nrows=n)
 
     def fetch(self, region, region2=None):
         self.nfetch += 1
@@ -181,6 +169,19 @@ class PixelSelector:
         lo, _ = self.table.chrom_bins(n1)
         return self._dense(r0 + lo, r1 + lo, c0 + lo, c1 + lo)
 
+    def _positive(self):
+        """value > 0 for every stored pixel (NaN from a masked bin compares False): one byte per pixel, formed once
+        in 16 M-pixel pieces so that no whole-table float array ever exists on the host."""
+        if self._pos is None:
+            t = self.table
+            n = len(t.count)
+            pos = np.empty(n, dtype=bool)
+            for a in range(0, n, 1 << 24):
+                b = min(a + (1 << 24), n)
+                pos[a:b] = pixel_values(t.count[a:b], self.w, t.bin1_id[a:b], t.bin2_id[a:b]) > 0
+            self._pos = pos
+        return self._pos
+
     def row_nonzero(self, region, region2=None):
         """Which rows of `fetch(region, region2)` have a non-zero sum after NaN -> 0 (what nulldist's pools
         ask of the unit matrix, getStripe.py:329-331), straight from the pixel table.  Returns None when the
@@ -190,22 +191,22 @@ class PixelSelector:
         if n1 != n2:
             raise ValueError('trans fetch is not on the stripenn path')
         t = self.table
-        self.values()
-        if getattr(self, '_nonneg', None) is None:
-            self._nonneg = not bool(np.any(self._vals < 0))
+        if self._nonneg is None:
+            with np.errstate(invalid='ignore'):
+                self._nonneg = bool((len(t.count) == 0 or t.count.min() >= 0) and
+                                    (self.w is None or not np.any(self.w < 0)))
         if not self._nonneg:
             return None
         lo, _ = t.chrom_bins(n1)
         R0, R1, C0, C1 = r0 + lo, r1 + lo, c0 + lo, c1 + lo
         hit = np.zeros(r1 - r0, dtype=bool)
-        a, b = t.rows_slice(R0, R1)                                  # stored pixels: bin1 in rows, bin2 in cols
-        b2 = t.bin2_id[a:b]
-        ok = (b2 >= C0) & (b2 < C1) & (self._vals[a:b] > 0)
-        hit[t.bin1_id[a:b][ok] - R0] = True
-        a, b = t.rows_slice(C0, C1)                                  # mirror images: bin2 in rows, bin1 in cols
-        b2 = t.bin2_id[a:b]
-        ok = (b2 >= R0) & (b2 < R1) & (self._vals[a:b] > 0)
-        hit[b2[ok] - R0] = True
+        for (A0, A1, B0, B1, mirror) in ((R0, R1, C0, C1, False), (C0, C1, R0, R1, True)):
+            a, b = t.rows_slice(A0, A1)       # stored pixels (bin1 in rows, bin2 in cols), then their mirror images
+            b1 = t.bin1_id[a:b]; b2 = t.bin2_id[a:b]
+            keep = (b2 >= B0) & (b2 < B1)
+            b1, b2 = b1[keep], b2[keep]
+            pos = self._positive()[a:b][keep]
+            hit[(b2 if mirror else b1)[pos] - R0] = True
         return hit
 
     def __getitem__(self, key):
@@ -226,7 +227,7 @@ class PixelSelector:
             b1 = t.bin1_id[a:b]; b2 = t.bin2_id[a:b]
             keep = (b2 >= B0) & (b2 < B1)
             b1, b2 = b1[keep], b2[keep]
-            v = self.values()[a:b][keep]
+            v = pixel_values(t.count[a:b][keep], self.w, b1, b2)
             if mirror:
                 out[b2 - R0, b1 - C0] = v
             else:

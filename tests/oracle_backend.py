@@ -129,6 +129,15 @@ class OracleBackend:
     def select_append(self, sel, values):
         sel.append(np.asarray(values, dtype=np.float64).ravel())
 
+    def select_append_pixels(self, sel, bin1, bin2, count, weight):
+        v = np.asarray(count).astype(np.float64)
+        if weight is not None:
+            w = np.asarray(weight, np.float64)
+            v = (v * w[np.asarray(bin1)]) * w[np.asarray(bin2)]
+        off = np.asarray(bin1) != np.asarray(bin2)
+        v = np.concatenate([v, v[off]])
+        sel.append(v[v > 0])
+
     def select_count(self, sel):
         return int(sum(len(v) for v in sel))
 

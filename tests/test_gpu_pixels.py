@@ -85,3 +85,27 @@ def test_compute_from_pixel_table_equals_dense_route(tmp_path, monkeypatch):
         outs.append([open(os.path.join(out, f)).read() for f in ('result_unfiltered.tsv', 'result_filtered.tsv')])
     assert outs[0] == outs[1]
     assert outs[0][0].count('\n') > 10
+
+
+def test_quantile_from_pixel_table_equals_dense_quantile():
+    """stp_select_append_pixels: values formed on the device, off-diagonal pixels counted twice, equals
+    np.quantile over the positive entries of the dense symmetric matrix (getStripe.py:160-176)."""
+    import pandas as pd
+    from stripenn_amd import getStripe as GS
+    names = ['chrA', 'chrB']
+    chroms = {'chrA': synth.SynthChrom(900, 41, nan_frac=0.03), 'chrB': synth.SynthChrom(700, 42, balanced=False)}
+    t = pixels.PixelTable.from_synth(names, chroms, RESOL)
+    qs = [0.5, 0.95, 0.97, 0.999]
+    for balance in ('weight', False):
+        sel = pixels.PixelSelector(t, balance)
+
+        class Info:
+            chromsizes = pd.Series(t.chromsizes, index=names)
+            binsize = RESOL
+        hb = BK.HipBackend(0)
+        obj = GS.getStripe(sel, RESOL, 10, 8, 2.0, names, names, t.chromsizes, t.chromsizes, 1, 3, 1, backend=hb)
+        MP = obj.getQuantile_original(Info, names, qs)
+        hb.close()
+        for nm in names:
+            D = sel.fetch(nm)
+            assert np.array_equal(MP[nm], np.quantile(D[D > 0], qs)), (balance, nm)

@@ -1,0 +1,37 @@
+"""Whole-genome `compute` on one GPU: mm10 chromosome sizes at 5 kb (2 645 frames x 5 levels),
+synthetic pixel table held in memory, the unmodified driver stripenn_amd.stripenn.compute.
+    python tools/probe_genome.py [scale]      # scale < 1 shrinks every chromosome (quick check)"""
+import contextlib, io as _io, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from stripenn_amd import getStripe, io, pixels, stripenn, synth
+
+MM10 = [195471971, 182113224, 160039680, 156508116, 151834684, 149736546, 145441459, 129401213, 124595110, 130694993,
+        122082543, 120129022, 120421639, 124902244, 104043685, 98207768, 94987271, 90702639, 61431566, 171031299]
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+names = ['chr%d' % (i + 1) for i in range(19)] + ['chrX']
+t0 = time.time()
+chroms = {n: synth.SynthChrom(int(-(-s * scale // 5000)), 1 + i) for i, (n, s) in enumerate(zip(names, MM10))}
+table = pixels.PixelTable.from_synth(names, chroms, 5000)
+print('genome: %d bins, %d stored pixels, table built in %.0f s' % (table.chrom_offset[-1], len(table.count), time.time() - t0), flush=True)
+stripenn.open_matrix = lambda cool: io.pixel_matrix(table)
+acc = {}
+for name in ('_band', 'getQuantile_original', 'mpmean', 'nulldist', 'extract', 'RemoveRedundant', 'scoringstripes', 'pvalue', '_search'):
+    f = getattr(getStripe.getStripe, name)
+    def mk(f, name):
+        def w(self, *a, **k):
+            t = time.time(); r = f(self, *a, **k); acc[name] = acc.get(name, 0.0) + time.time() - t; return r
+        return w
+    setattr(getStripe.getStripe, name, mk(f, name))
+os.makedirs('gpurun_out', exist_ok=True)
+t0 = time.time()
+with contextlib.redirect_stdout(_io.StringIO()):
+    stripenn.compute('pixels:in-memory', 'gpurun_out/genome_out', 'weight', 'all', 2.0, 10, 8, '0.95,0.96,0.97,0.98,0.99', 8,
+                     0.1, '0', False, 3, 123456789, force=True)
+total = time.time() - t0
+nfr = sum(-(-c.nbins // 200) for c in chroms.values())
+print('compute: %.1f s for %d frames x 5 levels (%d frame-levels; the reference needs ~0.78 s of one core for each)' % (total, nfr, nfr * 5))
+for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
+    print('  %-22s %.2f s (inclusive)' % (k, v))
+print(open('gpurun_out/genome_out/result_filtered.tsv').read().count('\n') - 1, 'filtered stripes;',
+      open('gpurun_out/genome_out/result_unfiltered.tsv').read().count('\n') - 1, 'unfiltered')
