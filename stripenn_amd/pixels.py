@@ -176,9 +176,19 @@ class PixelSelector:
             t = self.table
             n = len(t.count)
             pos = np.empty(n, dtype=bool)
+            w = self.w
+            # (count * w1) * w2 > 0  <=>  count > 0 and w1 > 0 and w2 > 0, unless the product underflows to 0:
+            # impossible while every positive weight is >= 1e-100 (counts are >= 1); otherwise form the products
+            cheap = w is None or not np.any((w > 0) & (w < 1e-100))
+            wpos = None if w is None else (w > 0)                    # NaN (masked bin) -> False
             for a in range(0, n, 1 << 24):
                 b = min(a + (1 << 24), n)
-                pos[a:b] = pixel_values(t.count[a:b], self.w, t.bin1_id[a:b], t.bin2_id[a:b]) > 0
+                if w is None:
+                    pos[a:b] = t.count[a:b] > 0
+                elif cheap:
+                    pos[a:b] = (t.count[a:b] > 0) & wpos[t.bin1_id[a:b]] & wpos[t.bin2_id[a:b]]
+                else:
+                    pos[a:b] = pixel_values(t.count[a:b], w, t.bin1_id[a:b], t.bin2_id[a:b]) > 0
             self._pos = pos
         return self._pos
 
