@@ -518,6 +518,7 @@ class getStripe:
         listTotal = [0 for _ in range(nrow)]
         chrset = list(set(df['chr']))
         chrcol = np.asarray(df['chr'])
+        col_p = [df[k].tolist() for k in ('pos1', 'pos2', 'pos3', 'pos4')]      # columns read once
         for c in chrset:
             is_mask = is_masking and (mask_chr == c)
             idx = np.where(chrcol == c)[0].tolist()
@@ -526,8 +527,7 @@ class getStripe:
             exval = np.asarray(expecVal[str(c)], dtype=np.float64)
             st = np.zeros(len(idx), dtype=SCORE_STRIPE_DTYPE)
             for k, i in enumerate(idx):
-                xs, xe = df['pos1'].iloc[i], df['pos2'].iloc[i]
-                ys, ye = df['pos3'].iloc[i], df['pos4'].iloc[i]
+                xs, xe, ys, ye = col_p[0][i], col_p[1][i], col_p[2][i], col_p[3][i]
                 x_start_index = int(xs / resol)
                 x_end_index = int(xe / resol)
                 y_start_index = int(ys / resol)
