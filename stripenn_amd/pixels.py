@@ -210,13 +210,17 @@ class PixelSelector:
         lo, _ = t.chrom_bins(n1)
         R0, R1, C0, C1 = r0 + lo, r1 + lo, c0 + lo, c1 + lo
         hit = np.zeros(r1 - r0, dtype=bool)
-        for (A0, A1, B0, B1, mirror) in ((R0, R1, C0, C1, False), (C0, C1, R0, R1, True)):
-            a, b = t.rows_slice(A0, A1)       # stored pixels (bin1 in rows, bin2 in cols), then their mirror images
-            b1 = t.bin1_id[a:b]; b2 = t.bin2_id[a:b]
-            keep = (b2 >= B0) & (b2 < B1)
-            b1, b2 = b1[keep], b2[keep]
-            pos = self._positive()[a:b][keep]
-            hit[(b2 if mirror else b1)[pos] - R0] = True
+        pos = self._positive()
+        a, b = t.rows_slice(R0, R1)                 # stored pixels: bin1 in the rows, bin2 in the columns
+        b2 = t.bin2_id[a:b]
+        ok = pos[a:b] & (b2 < C1)
+        if C0 > R0:                                  # (bin2 >= bin1 >= R0 covers the lower bound otherwise)
+            ok &= b2 >= C0
+        hit[t.bin1_id[a:b][ok] - R0] = True
+        a, b = t.rows_slice(C0, min(C1, R1))        # mirror images: bin2 in the rows, bin1 (<= bin2 < R1) in the columns
+        b2 = t.bin2_id[a:b]
+        ok = pos[a:b] & (b2 >= R0) & (b2 < R1)
+        hit[b2[ok] - R0] = True
         return hit
 
     def __getitem__(self, key):
