@@ -440,8 +440,10 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
         double avg = stp_pw<true>([&](int64_t k) { return diff[k]; }, 0, n, s_stk) / (double)n;
         out_g[blockIdx.x] = med * avg;
         const int nc = nkc[0];
-        out_total[blockIdx.x] = s_tot * (double)nc;
-        out_mean[blockIdx.x] = (s_tot * (double)nc) / ((double)hk * nc * nc);
+        // every centre column deleted (a mask covering the whole stripe width): np.sum over the empty block is 0.0,
+        // np.mean is NaN (getStripe.py:747-748)
+        out_total[blockIdx.x] = (nc == 0) ? 0.0 : s_tot * (double)nc;
+        out_mean[blockIdx.x] = (nc == 0) ? NAN : (s_tot * (double)nc) / ((double)hk * nc * nc);
     }
 }
 

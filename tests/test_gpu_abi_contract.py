@@ -81,3 +81,28 @@ def test_degenerate_frames_and_images(hip_ctx):
     # flat image: Canny finds nothing, so no records from frame 3 at any level
     assert not np.any(recs['frame'] == 3)
     fr.close(); band.close()
+
+
+def test_fully_masked_centre_matches_reference_sums():
+    """A mask that removes every centre column of a stripe: np.sum over the empty block is 0.0, np.mean and the
+    Stripiness are NaN (getStripe.py:709-758) -- found by tools/soak_score.py."""
+    from oracle_backend import OracleBackend
+    from stripenn_amd import backend as BK
+    ch = synth.SynthChrom(1200, 77, nan_frac=0.0)
+    band_h = ch.band(HW)
+    hb, ob = BK.HipBackend(0), OracleBackend()
+    gb, cb = hb.open_chrom(band_h), ob.open_chrom(band_h)
+    EV = 240.0 / (1.0 + np.arange(400)) + 1.0
+    sc = np.zeros(3, dtype=BK.SCORE_STRIPE_DTYPE)
+    for k, (x0, w, h) in enumerate(((300, 1, 60), (500, 2, 40), (700, 1, 25))):
+        x1 = x0 + w - 1; y0 = x0; y1 = y0 + h - 1
+        sc['row0'][k], sc['row1'][k] = y0, y1 + 1
+        sc['col0'][k] = (x0, x0 - 10, x1 + 1); sc['col1'][k] = (x1 + 1, x0, x1 + 11)
+        sc['ex0'][k] = (x0, x0 - 10, x1 + 2); sc['ey0'][k] = y0; sc['mirror'][k] = 0
+        sc['mcol0'][k] = (0, 1, 1); sc['mcol1'][k] = (w - 1, 0, 0)        # the whole centre block
+        sc['mrow0'][k], sc['mrow1'][k] = 1, 0
+    g, m, t = hb.stripiness(gb, EV, sc)
+    go, mo, to = ob.stripiness(cb, EV, sc)
+    assert np.array_equal(t, to) and np.all(t == 0.0)
+    assert np.all(np.isnan(m)) and np.all(np.isnan(mo)) and np.array_equal(g, go, equal_nan=True)
+    gb.close(); hb.close()
