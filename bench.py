@@ -1,18 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the `stripenn compute` hot path on MI355X (contract: see the task's bench.py section).
 
-A "step" = one pass of the GPU hot path over one chromosome-sized batch already resident in HBM:
-frame compaction -> (5 maxpixel levels x 6 brightness levels) image build / Canny / line joining
--> stripe records on the host [-> p-value + Stripiness kernels for the called stripes].
-Workload at N=1: BASELINE.json configs[1] (chr16-size 5 kb chromosome, maxpixel sweep 0.95-0.99),
-realised synthetically (stripenn_amd/synth.py).  N>1: weak scaling, every rank sweeps its own
-chromosome of the same size (chromosome x maxpixel units shard with no collective).
+Workload (default, `--workload genome`): BASELINE.json's metric configuration -- a 5 kb WHOLE GENOME:
+the 20 mm10 chromosome sizes (1-19, X; 526 765 bins, 2 645 frames) x 5 maxpixel levels x 6 brightness
+levels = 79 350 images, 2.1 G contact-px per step, realised synthetically (stripenn_amd/synth.py's pixel
+function, evaluated on the device by stripenn_amd/synth_device.py).  All bands are resident in HBM before
+the timed region.
+
+A "step" = one pass of the GPU hot path over the rank's share of the genome: per chromosome (or frame span
+of one) frame compaction + medpixel -> image build / Canny / line joining for every (frame, level,
+brightness) -> candidate records on the host -> p-value + Stripiness kernels for every candidate.
+
+N > 1 (`--gpus N`): STRONG scaling of the same genome.  The (chromosome x frame) grid is cut into N
+contiguous spans of equal frame count (stripenn_amd.shard.frame_spans; all maxpixel levels of a frame stay
+together), one process per GPU, no collective on the data path; the process group only carries the barrier
+and the max-over-ranks time.  Launch either through torch.distributed.run (RANK / WORLD_SIZE in the
+environment) or plainly as `python bench.py --gpus N`: then this process starts the N ranks itself, as
+children, before it has touched the GPU.
+
+Other workloads (extra lines, not the metric): `--workload chr16` (configs[1]: one chr16-size chromosome,
+the r01 bench line), `--bins N` (one chromosome of N 5 kb-bins, e.g. 248957 for the configs[4]-like band).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,15 +36,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_SIMD = 1024          # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9       # max clock; an FP64 VALU wave-instruction occupies its SIMD for 4 cycles
+MM10 = [195471971, 182113224, 160039680, 156508116, 151834684, 149736546, 145441459, 129401213, 124595110, 130694993,
+        122082543, 120129022, 120421639, 124902244, 104043685, 98207768, 94987271, 90702639, 61431566, 171031299]
+MM10_NAMES = ['chr%d' % (i + 1) for i in range(19)] + ['chrX']
 CHR16_BINS = 19642     # mm10 chr16 (98,207,768 bp) at 5 kb
+RESOL = 5000
 MAXPIXEL = [0.95, 0.96, 0.97, 0.98, 0.99]
 BYTES_PER_IMAGE_PX = {'gray': 12.0, 'canny': 5.0, 'lines': 9.0}  # SURVEY.md 8(d) stages A, B, C-F
 SCORE_KERNELS = ('pvalue', 'stripiness')
-# HBM bytes per launch of the chain kernels for THIS default workload, from rocprofv3 PMC passes
-# (profiles/r01e_pmc.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, KB units, FETCH_SIZE
-# doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read inside this script.
-PMC_TRAFFIC_BYTES = {'canny': (2 * 922851 + 254623) * 1024.0, 'gray': (2 * 331738 + 1850574) * 1024.0,
-                     'lines': (2 * 109698 + 64509) * 1024.0}
+PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_current.json')    # written by tools/summarize_profile.py
 
 
 def frame_table(nbins):
@@ -50,7 +66,6 @@ def _cpu_task(args):
     fi, M = args
     band, hw, st, en = _G['band'], _G['hw'], _G['st'], _G['en']
     s, e = int(st[fi]), int(en[fi])
-    n0 = e - s + 1
     rows = np.arange(s, e + 1)[:, None]
     cols = np.arange(s, e + 1)[None, :]
     D = band[rows, cols - rows + hw].copy()
@@ -78,7 +93,7 @@ def _cpu_worker(args):
     return px, done, t0, t_last
 
 
-def cpu_baseline(band_h, hw, st, en, Ms, wall_budget_s=12.0):
+def cpu_baseline(band_h, hw, st, en, Ms, what, wall_budget_s=12.0):
     """Oracle ("port") on all host cores, time-bounded: every worker walks its share of the units until
     the deadline and returns by itself (no Pool.terminate(), which can dead-lock); the rate is the pixels of
     all completed units over the span from the first start to the last completion."""
@@ -106,23 +121,53 @@ def cpu_baseline(band_h, hw, st, en, Ms, wall_budget_s=12.0):
     px = sum(r[0] for r in res); done = sum(r[1] for r in res)
     dt = max(r[3] for r in res) - min(r[2] for r in res)
     return {'value': round(px / dt / 1e6, 2), 'unit': 'contact-Mpx/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d (frame,maxpixel) units of the same chromosome (%.2fx one step), StripeSearch chain only, '
-                      'oracle/stripe_oracle.c via a fork pool on %d host cores, %.1f s wall'
-                      % (done, done / len(allt), cores, dt)}
+            'sample': '%d (frame,maxpixel) units of %s, StripeSearch chain only (the GPU step also scores every '
+                      'candidate stripe), oracle/stripe_oracle.c via a fork pool on %d host cores, %.1f s wall'
+                      % (done, what, cores, dt)}
+
+
+# ----------------------------------------------------------------------------- rank launcher
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (this process has not
+    touched the GPU and never will), relay rank 0's output, return the worst exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--bins', type=int, default=CHR16_BINS, help='chromosome length in 5 kb bins')
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', choices=('genome', 'chr16'), default='genome')
+    ap.add_argument('--bins', type=int, default=0, help='one chromosome of this many 5 kb bins instead of a named workload')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-score', action='store_true', help='StripeSearch chain only (skips the p-value / Stripiness set-up; for very long chromosomes)')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end `compute` run (quantile -> TSVs) at N = 1')
+    ap.add_argument('--no-score', action='store_true', help='StripeSearch chain only (for very long chromosomes)')
+    ap.add_argument('--allow-stp-lib', action='store_true', help='accept a library named by STP_LIB (profiling builds)')
     args = ap.parse_args()
 
-    # the default run takes about a minute; never hang the driver: dump the stacks and exit after 20 min
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get('STP_LIB') and not args.allow_stp_lib:
+        sys.exit('bench.py: STP_LIB=%s is set; the benchmark measures the product library only '
+                 '(pass --allow-stp-lib for an ablation build)' % os.environ['STP_LIB'])
+
+    # never hang the driver: dump the stacks and exit after 20 min
     import faulthandler
     faulthandler.dump_traceback_later(1200, exit=True)
 
@@ -130,43 +175,74 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # STP_BENCH_REHEARSE=1: every rank on device 0 with gloo (a one-GPU box cannot host an RCCL group of 2)
+    rehearse = os.environ.get('STP_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
     torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    rdev = 'cpu' if rehearse else 'cuda'      # where the timing scalars are reduced
 
-    from stripenn_amd import synth, hip
+    from stripenn_amd import synth_device, hip, shard, getStripe as GS, backend as BK
     hw = 512
-    nb = args.bins
-    chrom = synth.SynthChrom(nb, 16 + rank)
-    band_h = chrom.band(hw)
-    # (HipBackend below raises if the HIP extension / GPU is missing: no CPU fallback; the band is
-    #  resident in HBM before the timed region)
-    st, en = frame_table(nb)
-    # maxpixel quantiles: the reference's getQuantile step stays on the host and is
-    # outside the hot path; on band-limited synthetic data the band holds every positive pixel.
-    Ms = np.quantile(band_h[band_h > 0], MAXPIXEL)
+    bs = int(50000 / RESOL)
+    if args.bins:
+        names, nbins, seeds = ['chr16'], [args.bins], [16]
+        wl = 'configs[4]-like 1kb chr1-size band' if args.bins > 200000 else 'custom chromosome'
+    elif args.workload == 'chr16':
+        names, nbins, seeds = ['chr16'], [CHR16_BINS], [16]
+        wl = 'configs[1]: chr16-size 5kb chromosome'
+    else:
+        names, nbins, seeds = MM10_NAMES, [-(-s // RESOL) for s in MM10], list(range(1, 21))
+        wl = 'configs[2]: mm10-size whole genome at 5kb (20 chromosomes)'
+    sizes = np.array([n * RESOL for n in nbins], dtype=np.int64)
+    nframes = [-(-n // 200) for n in nbins]
+    my_units = shard.frame_spans(nframes, world)[rank]       # (chromosome index, first frame, end frame)
 
-    # score-path inputs (untimed set-up): expected values and background tables of this chromosome,
-    # computed through the same facade the CLI uses
-    from stripenn_amd import getStripe as GS, backend as BK
-    name = 'chr16'
-    sel = synth.SynthSelector({name: chrom}, 5000)
-    size = nb * 5000
-    hb = BK.HipBackend(local_rank)
-    obj = GS.getStripe(sel, 5000, 10, 8, 2.0, [name], [name], np.array([size]), np.array([size]), 2, 3, 123456789,
-                       backend=hb)
-    obj._bands[name] = hb.ctx.band_upload(band_h)
-    sband = obj._bands[name]
+    # ---- untimed set-up: every band in HBM, maxpixel quantiles, expected values, background tables
+    t_setup = time.time()
+    hb = BK.HipBackend(local_rank)       # raises if the HIP extension / GPU is missing: no CPU fallback
+    ctx = hb.ctx
+    chroms, tens, bands = {}, {}, {}
+    need_all = not args.no_score         # the background tables sample every chromosome of the genome
+    for ci, nm in enumerate(names):
+        if not need_all and not any(u[0] == ci for u in my_units):
+            continue
+        chroms[nm] = synth_device.DeviceChrom(nbins[ci], seeds[ci], dev)
+        tens[nm] = chroms[nm].band(hw)
+        torch.cuda.synchronize()
+        bands[nm] = ctx.band_wrap(tens[nm].data_ptr(), nbins[ci], hw, keepalive=tens[nm])
+    Ms = {}
+    for ci in sorted({u[0] for u in my_units}):
+        # the reference's getQuantile step (np.quantile(mat[mat > 0], q)) is outside the timed path; on this
+        # band-limited synthetic data the band holds every positive pixel, so the order statistics of the band's
+        # positive entries are those of the dense matrix (sorted on the device, numpy's interpolation on the host)
+        t = tens[names[ci]]
+        v = torch.sort(t[t > 0]).values
+        Ms[ci] = GS.quantile_linear(lambda ranks: v[torch.as_tensor(ranks, device=dev)].cpu().numpy(), int(v.numel()),
+                                    MAXPIXEL)
+        del v
+    sel = _DeviceSelector(chroms, RESOL)
+    obj = GS.getStripe(sel, RESOL, 10, 8, 2.0, names, names, sizes, sizes, 2, 3, 123456789, backend=hb)
+    for nm in bands:
+        obj._bands[nm] = bands[nm]
+    EV = {}
     if not args.no_score:
-        EV = np.asarray(obj.mpmean()[name])
+        EVall = obj.mpmean()
+        EV = {ci: np.asarray(EVall[names[ci]]) for ci in {u[0] for u in my_units}}
         bg = obj.nulldist()
         hb.set_background(*bg)
-    bs = 10
+    tabs = {ci: frame_table(nbins[ci]) for ci in {u[0] for u in my_units}}
+    setup_s = time.time() - t_setup
 
-    def score_inputs(recs, fr):
+    def score_inputs(recs, fr, st, nb):
         """bin rectangles of every candidate stripe (vectorised host arithmetic)"""
         f = recs['frame']
         base = st[f]
@@ -192,17 +268,20 @@ def main():
         return pv, sc
 
     def step():
-        fr = sband.frames(st, en)
-        recs = fr.stripe_search(Ms)
-        if not args.no_score:
-            pv, sc = score_inputs(recs, fr)
-            p = hb.pvalue(sband, bs, pv)
-            g = hb.stripiness(sband, EV, sc)[0]
-        S = fr.S.copy()
-        fr.close()
-        return recs, S
-
-    ctx = hb.ctx
+        nrec, px = 0, 0.0
+        for ci, f0, f1 in my_units:
+            st, en = tabs[ci]
+            sband = bands[names[ci]]
+            fr = sband.frames(st[f0:f1], en[f0:f1])
+            recs = fr.stripe_search(Ms[ci])
+            if not args.no_score:
+                pv, sc = score_inputs(recs, fr, st[f0:f1], nbins[ci])
+                hb.pvalue(sband, bs, pv)
+                hb.stripiness(sband, EV[ci], sc)
+            nrec += len(recs)
+            px += float((fr.S.astype(np.float64) ** 2).sum())
+            fr.close()
+        return nrec, px * len(MAXPIXEL)
 
     def barrier():
         if world > 1:
@@ -217,62 +296,160 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        recs, S = step()
+        nrec, contact_px = step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_rank = time.perf_counter() - t0
     stats = ctx.stats()
+    dt, total_px, total_rec, rank_ms = dt_rank, contact_px, nrec, [dt_rank / args.steps * 1e3]
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        tmax = torch.tensor([dt_rank], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-
-    contact_px = float((S.astype(np.float64) ** 2).sum()) * len(Ms)   # this rank, per step
-    image_px = contact_px * 6
-    total_px = contact_px                                              # all ranks (each has its own chromosome)
-    if world > 1:
-        tsum = torch.tensor([contact_px], dtype=torch.float64, device='cuda')
+        tsum = torch.tensor([contact_px, float(nrec)], dtype=torch.float64, device=rdev)
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        total_px = float(tsum.item())
+        total_px, total_rec = float(tsum[0].item()), int(tsum[1].item())
+        allt = [torch.zeros(1, dtype=torch.float64, device=rdev) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([dt_rank / args.steps * 1e3], dtype=torch.float64, device=rdev))
+        rank_ms = [float(t.item()) for t in allt]
     value = total_px * args.steps / dt / 1e6
 
-    out = None
     if rank == 0:
+        image_px = contact_px * 6                                   # this rank, per step
         chain_ms = stats['chain_wall']['ms'] if 'chain_wall' in stats else sum(v['ms'] for k, v in stats.items() if k in BYTES_PER_IMAGE_PX)
         dom = max((k for k in stats if k in BYTES_PER_IMAGE_PX or k in SCORE_KERNELS), key=lambda k: stats[k]['ms'])
         d = stats[dom]
-        ach = d['alg_bytes'] / d['launches'] / (d['ms'] / d['launches'] * 1e-3) / 1e9
+        ach = d['alg_bytes'] / (d['ms'] * 1e-3) / 1e9
+        pmc = _load_pmc('genome' if not args.bins and args.workload == 'genome' else
+                        'chr16' if not args.bins else 'bins%d' % args.bins)
+        traffic, valu = None, None
+        if pmc and dom in pmc.get('kernels', {}):
+            k = pmc['kernels'][dom]
+            if k.get('fetch_kb') is not None and k.get('write_kb') is not None:
+                # per launch of the dominant kernel: FETCH_SIZE doubled (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE
+                traffic = (2.0 * k['fetch_kb'] + k['write_kb']) * 1024.0
+            if k.get('valu_insts') is not None and k.get('image_px'):
+                per_px = k['valu_insts'] / k['image_px']
+                step_insts = per_px * image_px                      # wave-instructions of this kernel per step
+                valu = {'kernel': 'k_' + dom, 'wave_insts_per_image_px': round(per_px, 1),
+                        'cycles_per_inst': 4, 'peak_wave_insts_per_s': N_SIMD * CLOCK_HZ / 4,
+                        'achieved_wave_insts_per_s': round(step_insts / (d['ms'] / args.steps * 1e-3), 0),
+                        'frac': round(step_insts / (d['ms'] / args.steps * 1e-3) / (N_SIMD * CLOCK_HZ / 4), 4),
+                        'source': pmc.get('tag')}
         roof = {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(ach / HBM_PEAK_GBS, 4),
-                'traffic': (PMC_TRAFFIC_BYTES.get(dom) if nb == CHR16_BINS else None),
-                'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+                'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                'traffic_source': (pmc.get('tag') if traffic is not None else None),
+                'avg_launch_ms': round(d['ms'] / d['launches'], 4), 'launches_per_step': d['launches'] / args.steps,
                 'alg_bytes_per_launch': d['alg_bytes'] / d['launches'],
+                'fp64_valu': valu,
                 'chain': {'kernels_ms_per_step': {k: round(v['ms'] / args.steps, 4) for k, v in stats.items()},
                           'alg_bytes_per_image_px': 26.0,
                           'achieved_GBs': round(26.0 * image_px * args.steps / (chain_ms * 1e-3) / 1e9, 1),
                           'frac': round(26.0 * image_px * args.steps / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
         out = {'metric': 'contact-matrix Mpixels/s through compute path', 'value': round(value, 2),
                'unit': 'contact-Mpx/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-               'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-               'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-               'config': {'workload': '%s (%d bins, %d frames), maxpixel sweep 0.95-0.99 x 6 brightness levels: frame '
-                                      'compaction + StripeSearch chain%s'
-                                      % ('configs[1]: chr16-size 5kb chromosome' if nb == CHR16_BINS else
-                                         'configs[4]-like 1kb chr1-size band' if nb > 200000 else 'custom chromosome',
-                                         nb, len(st),
+               'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+               'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+               'config': {'workload': '%s: %d bins, %d frames x %d maxpixel levels (0.95-0.99) x 6 brightness levels; step = frame '
+                                      'compaction + medpixel + StripeSearch chain%s, bands resident in HBM'
+                                      % (wl, sum(nbins), sum(nframes), len(MAXPIXEL),
                                          '' if args.no_score else ' + p-value and Stripiness of every candidate stripe'),
-                          'frames': int(len(st)), 'levels': len(Ms), 'images_per_step': int(len(st) * len(Ms) * 6),
-                          'contact_px_per_step': total_px, 'stripe_records': int(len(recs)),
-                          'sharding': 'one chromosome per rank, no collective'},
+                          'chromosomes': len(names), 'frames': int(sum(nframes)), 'levels': len(MAXPIXEL),
+                          'images_per_step': int(sum(nframes) * len(MAXPIXEL) * 6),
+                          'contact_px_per_step': total_px, 'stripe_records_per_step': int(total_rec),
+                          'sharding': 'contiguous (chromosome x frame) spans of equal frame count, one process per GPU, '
+                                      'no collective on the data path',
+                          'rank_ms_per_step': [round(t, 3) for t in rank_ms], 'setup_s': round(setup_s, 1),
+                          'library': hip.LIB_PATH},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(band_h, hw, st, en, [float(m) for m in Ms])
+            ci = min({u[0] for u in my_units}, key=lambda c: nbins[c])        # the smallest chromosome held here
+            band_h = bands[names[ci]].download()
+            st, en = tabs[ci]
+            out['cpu_baseline'] = cpu_baseline(band_h, hw, st, en, [float(m) for m in Ms[ci]],
+                                               '%s (%d bins, %d frames) of the same genome' % (names[ci], nbins[ci], len(st)))
+            del band_h
         else:
             out['cpu_baseline'] = None
+        if world == 1 and not args.no_e2e and not args.no_score:
+            out['e2e_compute'] = e2e_compute(names, chroms, total_px, hb)
         print(json.dumps(out), flush=True)
     hb.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class _DeviceSelector:
+    """`matrix(balance=...)`-like selector over device-generated chromosomes (set-up of the background tables):
+    fetch() evaluates the block on the GPU and copies it to the host; row_nonzero() answers the pools' only
+    question (which rows of the block have a non-zero sum after NaN -> 0; all values are >= 0) without the copy."""
+
+    def __init__(self, chroms, resol):
+        self.chroms, self.resol = chroms, int(resol)
+
+    def _extent(self, region):
+        region = str(region)
+        if ':' not in region:
+            return region, 0, self.chroms[region].nbins
+        name, rng = region.rsplit(':', 1)
+        s, e = rng.replace(',', '').split('-')
+        s, e = int(s), int(e)
+        if s < 0 or e > self.chroms[name].nbins * self.resol or s > e:
+            raise ValueError('Genomic region out of bounds: %s' % region)
+        return name, s // self.resol, -(-e // self.resol)
+
+    def _block(self, region, region2):
+        import torch
+        n1, r0, r1 = self._extent(region)
+        n2, c0, c1 = (n1, r0, r1) if region2 is None else self._extent(region2)
+        ch = self.chroms[n1]
+        r = torch.arange(r0, r1, device=ch.device, dtype=torch.int64)[:, None].expand(r1 - r0, c1 - c0)
+        c = torch.arange(c0, c1, device=ch.device, dtype=torch.int64)[None, :].expand(r1 - r0, c1 - c0)
+        val = (ch._counts(r, c) * ch.w[r]) * ch.w[c]
+        return torch.where(ch.nanflag[r] | ch.nanflag[c], torch.full_like(val, float('nan')), val)
+
+    def fetch(self, region, region2=None):
+        return self._block(region, region2).cpu().numpy()
+
+    def row_nonzero(self, region, region2=None):
+        return (self._block(region, region2) > 0).any(dim=1).cpu().numpy()
+
+
+def _load_pmc(workload):
+    try:
+        with open(PMC_FILE) as f:
+            return json.load(f).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
+def e2e_compute(names, chroms, contact_px, hb):
+    """The whole `stripenn compute` driver (quantiles -> expected values -> background -> candidates -> p-values ->
+    redundancy filter -> Stripiness -> TSVs) on the same genome handed over as cooler's pixel table in host
+    memory; reported beside the kernel-path figure, never as `value`."""
+    import contextlib
+    import io as _io
+    import tempfile
+    from stripenn_amd import io, stripenn, synth_device
+    t0 = time.time()
+    table = synth_device.pixel_table(names, chroms, RESOL)
+    t_table = time.time() - t0
+    orig = stripenn.open_matrix
+    stripenn.open_matrix = lambda cool: io.pixel_matrix(table)
+    out = tempfile.mkdtemp(prefix='stp_e2e_')
+    try:
+        t0 = time.time()
+        with contextlib.redirect_stdout(_io.StringIO()):
+            stripenn.compute('pixels:in-memory', out, 'weight', 'all', 2.0, 10, 8, ','.join(str(m) for m in MAXPIXEL), 8, 0.1,
+                             '0', False, 3, 123456789, force=True, backend=hb)
+        dt = time.time() - t0
+        nu = open(os.path.join(out, 'result_unfiltered.tsv')).read().count('\n') - 1
+        nf = open(os.path.join(out, 'result_filtered.tsv')).read().count('\n') - 1
+    finally:
+        stripenn.open_matrix = orig
+    return {'seconds': round(dt, 2), 'contact_Mpx_s': round(contact_px / dt / 1e6, 1), 'stored_pixels': int(len(table.count)),
+            'stripes_unfiltered': nu, 'stripes_filtered': nf, 'pixel_table_build_s': round(t_table, 1),
+            'what': 'stripenn_amd.stripenn.compute on the same genome as an in-memory pixel table (quantile -> TSVs), 1 GPU'}
 
 
 if __name__ == '__main__':
