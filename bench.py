@@ -242,31 +242,6 @@ def main():
     tabs = {ci: frame_table(nbins[ci]) for ci in {u[0] for u in my_units}}
     setup_s = time.time() - t_setup
 
-    def score_inputs(recs, fr, st, nb):
-        """bin rectangles of every candidate stripe (vectorised host arithmetic)"""
-        f = recs['frame']
-        base = st[f]
-        nzr = fr.nz.ravel(); fo = f * fr.nz.shape[1]
-        x0 = base + nzr.take(fo + recs['x']); x1 = base + nzr.take(fo + recs['x'] + recs['w'] - 1)
-        y0 = base + nzr.take(fo + recs['y']); y1 = base + nzr.take(fo + recs['y'] + recs['h'] - 1)
-        n = len(recs)
-        pv = np.zeros(n, dtype=BK.PV_STRIPE_DTYPE)
-        pv['row0'], pv['row1'] = y0, y1 + 1
-        pv['col0'], pv['col1'] = np.maximum(x0 - bs, 0), np.minimum(x1 + 1 + bs, nb)
-        pv['mode'] = np.where(x0 == y0, 0, 1)
-        pv['upbase'] = y1 + 1 - y0
-        sc = np.zeros(n, dtype=BK.SCORE_STRIPE_DTYPE)
-        sc['row0'], sc['row1'] = y0, y1 + 1
-        lm = np.minimum(np.maximum(x0 - bs, 1), x0); rm = np.minimum(x1 + 1 + bs, nb - 1)
-        sc['col0'][:, 0], sc['col1'][:, 0] = x0, x1 + 1
-        sc['col0'][:, 1], sc['col1'][:, 1] = lm, x0
-        sc['col0'][:, 2], sc['col1'][:, 2] = x1 + 1, np.maximum(rm, x1 + 1)
-        sc['ex0'][:, 0], sc['ex0'][:, 1], sc['ex0'][:, 2] = x0, lm, x1 + 2
-        sc['ey0'] = y0
-        sc['mirror'] = np.where(x0 == y0, 0, 1)
-        sc['mcol0'], sc['mcol1'], sc['mrow0'], sc['mrow1'] = 1, 0, 1, 0
-        return pv, sc
-
     def step():
         nrec, px = 0, 0.0
         for ci, f0, f1 in my_units:
@@ -275,7 +250,7 @@ def main():
             fr = sband.frames(st[f0:f1], en[f0:f1])
             recs = fr.stripe_search(Ms[ci])
             if not args.no_score:
-                pv, sc = score_inputs(recs, fr, st[f0:f1], nbins[ci])
+                pv, sc = BK.score_inputs(recs, fr.nz, st[f0:f1], nbins[ci], bs)
                 hb.pvalue(sband, bs, pv)
                 hb.stripiness(sband, EV[ci], sc)
             nrec += len(recs)

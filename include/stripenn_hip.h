@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STP_ABI_VERSION 2
+#define STP_ABI_VERSION 3
 #define STP_FRAME_MAX 400   /* frames are at most 400 x 400 (getStripe.py:794-799) */
 #define STP_NDIAG 400       /* diagonals kept for expected values / background (getStripe.py:219,305) */
 
@@ -64,13 +64,23 @@ int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_
 /* Build the band on the device straight from cooler's pixel table (the data format one step before the
  * path; replaces `cooler.Cooler(cool).matrix(balance=norm)` + dense `.fetch`, stripenn.py:80-118):
  *   bin1_id <= bin2_id (global bin ids), count; pixels with either bin outside [bin_lo, bin_lo + nrows) or
- *   with |bin2 - bin1| > halfwidth are skipped; value = (count * weight[bin1]) * weight[bin2] (cooler's
- *   balancing rule; NaN weights give NaN), or (double)count when weight == NULL; each pixel is written at
- *   (i, j) and mirrored at (j, i); cells without a pixel stay 0.  weight has nbins_total entries (global
- *   bin ids).  No dense intermediate exists on either side. */
+ *   with |bin2 - bin1| > halfwidth are skipped; value = count * (bias[bin1] * bias[bin2]) (cooler's dense
+ *   read multiplies the count block by np.outer(bias1, bias2); NaN gives NaN), or (double)count when
+ *   weight == NULL; `weight` is the MULTIPLICATIVE bias: the caller passes 1 / w for cooler's divisive
+ *   columns (KR, VC, SQRT_VC); each pixel is written at (i, j) and mirrored at (j, i); cells without a
+ *   pixel stay 0.  weight has nbins_total entries (global bin ids).  No dense intermediate exists. */
 int stp_band_pack(stp_ctx* ctx, const int64_t* bin1_id, const int64_t* bin2_id, const int32_t* count, int64_t npix,
                   const double* weight, int64_t nbins_total, int64_t bin_lo, int64_t nrows, int32_t halfwidth,
                   stp_band** out);
+/* For a band built by stp_band_pack: the distance from every bin to the nearest stored pixel with a positive
+ * value in its row of the symmetric matrix, to the right (column >= row; 0 = a positive diagonal pixel) and to
+ * the left (column < row); INT32_MAX where there is none.  Every cis pixel handed to stp_band_pack takes part,
+ * also those beyond the halfwidth.  With it the host answers "which rows of this block have a non-zero sum"
+ * (the pools of getStripe.nulldist, getStripe.py:262-273, 329-331: `np.sum(mat, axis=1) != 0` over a dense
+ * fetch) for any block whose columns cover its rows, without fetching anything: row i of the block
+ * rows x [c0, c1) is non-empty iff i + right[i] < c1 or i - left[i] >= c0 (all values being >= 0).
+ * STP_E_UNSUPPORTED for uploaded / wrapped bands. */
+int stp_band_nearest(stp_ctx* ctx, const stp_band* band, int32_t* right_out /* nrows */, int32_t* left_out /* nrows */);
 /* Copy a band back to the host (nrows x 2*halfwidth doubles; parity tests, debugging). */
 int stp_band_download(stp_ctx* ctx, const stp_band* band, double* out_host);
 /* Adopt a band that already lives in device memory (caller keeps ownership of dptr). */
@@ -86,6 +96,12 @@ void stp_band_free(stp_ctx* ctx, stp_band* band);
  * the device, numpy's linear interpolation applied by the library on the host. */
 int stp_frames_create(stp_ctx* ctx, const stp_band* band, const int32_t* start, const int32_t* end,
                       int32_t nframes, stp_frames** out);
+/* flags: STP_FRAMES_KEEP_ALL keeps every column of every frame (no zero-column removal, no "more than 10 columns"
+ * rule): the frame IS the matrix a caller hands to getStripe.StripeSearch (getStripe.py:864), whose columns
+ * search_frame has already compacted. */
+#define STP_FRAMES_KEEP_ALL 1
+int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* start, const int32_t* end,
+                         int32_t nframes, int32_t flags, stp_frames** out);
 int stp_frames_info(stp_ctx* ctx, const stp_frames* fr, int32_t* S_out, int16_t* nz_out /* nframes*400 */,
                     double* medpixel_out /* nframes, may be NULL */);
 void stp_frames_free(stp_ctx* ctx, stp_frames* fr);
@@ -209,8 +225,8 @@ int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rects, i
 typedef struct stp_select stp_select;
 int stp_select_create(stp_ctx* ctx, stp_select** out);
 int stp_select_append(stp_ctx* ctx, stp_select* sel, const double* values_host, int64_t n);
-/* Append the balanced values of cooler pixels (bin1_id <= bin2_id, count; value = (count * w[bin1]) * w[bin2], or
- * (double)count when weight == NULL) as the dense symmetric matrix would hold them: an off-diagonal pixel counts
+/* Append the balanced values of cooler pixels (bin1_id <= bin2_id, count; value = count * (bias[bin1] * bias[bin2]), or
+ * (double)count when weight == NULL; `weight` is the multiplicative bias as in stp_band_pack) as the dense symmetric matrix would hold them: an off-diagonal pixel counts
  * twice (getStripe.py:160-176 takes the quantile over the full square matrix).  The values are formed on the
  * device from the table columns; nothing dense and no host-side product array exists. */
 int stp_select_append_pixels(stp_ctx* ctx, stp_select* sel, const int64_t* bin1_id, const int64_t* bin2_id,

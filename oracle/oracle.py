@@ -317,14 +317,15 @@ def medpixel(D):
 # ------------------------------------------------------------------ band from cooler's pixel table
 def band_from_pixels(bin1, bin2, count, weight, lo, nrows, hw):
     """CPU restatement of stp_band_pack: what `cooler.Cooler(cool).matrix(balance=...)` + dense fetch
-    (stripenn.py:80-118, getStripe.py:808) would put into the diagonal band.  value = (count * w[bin1]) *
-    w[bin2] (cooler's balancing rule; raw counts when weight is None), written at (i, j) and mirrored at
+    (stripenn.py:80-118, getStripe.py:808) would put into the diagonal band.  value = count * (b[bin1] *
+    b[bin2]) (cooler's dense branch: count block times np.outer(bias1, bias2); `weight` here is that multiplicative
+    bias, 1 / w for the divisive columns; raw counts when weight is None), written at (i, j) and mirrored at
     (j, i); cells no stored pixel names are 0.  cooler itself is absent here: parity unpinned for this reader."""
     bin1 = np.asarray(bin1, np.int64); bin2 = np.asarray(bin2, np.int64)
     v = np.asarray(count).astype(np.float64)
     if weight is not None:
         w = np.asarray(weight, np.float64)
-        v = (v * w[bin1]) * w[bin2]
+        v = v * (w[bin1] * w[bin2])
     i = bin1 - lo; j = bin2 - lo
     ok = (i >= 0) & (j >= 0) & (i < nrows) & (j < nrows)
     i, j, v = i[ok], j[ok], v[ok]
@@ -335,3 +336,26 @@ def band_from_pixels(bin1, bin2, count, weight, lo, nrows, hw):
     m = (-d >= -hw) & (-d < hw)
     band[j[m], hw - d[m]] = v[m]
     return band
+
+
+def nearest_from_pixels(bin1, bin2, count, weight, lo, nrows):
+    """CPU restatement of stp_band_nearest: per bin of [lo, lo + nrows) the distance to the nearest stored pixel
+    with a positive balanced value in its row of the symmetric matrix, to the right (column >= row) and to the
+    left (column < row); INT32_MAX where there is none.  What getStripe.nulldist's pools ask of a dense fetch
+    (`np.sum(mat, axis=1) != 0`, getStripe.py:262-273, 329-331) reduces to these two numbers per row."""
+    bin1 = np.asarray(bin1, np.int64); bin2 = np.asarray(bin2, np.int64)
+    v = np.asarray(count).astype(np.float64)
+    if weight is not None:
+        w = np.asarray(weight, np.float64)
+        v = v * (w[bin1] * w[bin2])
+    i = bin1 - lo; j = bin2 - lo
+    ok = (i >= 0) & (j >= 0) & (i < nrows) & (j < nrows) & (v > 0)
+    i, j = i[ok], j[ok]
+    i, j = np.minimum(i, j), np.maximum(i, j)
+    big = np.iinfo(np.int32).max
+    right = np.full(int(nrows), big, np.int64)
+    left = np.full(int(nrows), big, np.int64)
+    np.minimum.at(right, i, j - i)
+    off = j > i
+    np.minimum.at(left, j[off], (j - i)[off])
+    return right, left

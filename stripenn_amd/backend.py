@@ -25,6 +25,35 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def score_inputs(recs, nz, starts, nbins, bs):
+    """Bin rectangles of raw stripe records (hip.REC_DTYPE; `nz` / `starts`: compaction map and first bin of the
+    frames they index) in the two layouts the score kernels take -- the arithmetic of getStripe.pvalue
+    (getStripe.py:552-563, 583-597) and scoringstripes (:668-697) for stripes that sit on whole bins, vectorised.
+    Used where candidates go straight from the search to the score kernels (bench.py, tests)."""
+    f = recs['frame']
+    base = np.asarray(starts)[f]
+    nzr = nz.ravel(); fo = f * nz.shape[1]
+    x0 = base + nzr.take(fo + recs['x']); x1 = base + nzr.take(fo + recs['x'] + recs['w'] - 1)
+    y0 = base + nzr.take(fo + recs['y']); y1 = base + nzr.take(fo + recs['y'] + recs['h'] - 1)
+    n = len(recs)
+    pv = np.zeros(n, dtype=PV_STRIPE_DTYPE)
+    pv['row0'], pv['row1'] = y0, y1 + 1
+    pv['col0'], pv['col1'] = np.maximum(x0 - bs, 0), np.minimum(x1 + 1 + bs, nbins)
+    pv['mode'] = np.where(x0 == y0, 0, 1)
+    pv['upbase'] = y1 + 1 - y0
+    sc = np.zeros(n, dtype=SCORE_STRIPE_DTYPE)
+    sc['row0'], sc['row1'] = y0, y1 + 1
+    lm = np.minimum(np.maximum(x0 - bs, 1), x0); rm = np.minimum(x1 + 1 + bs, nbins - 1)
+    sc['col0'][:, 0], sc['col1'][:, 0] = x0, x1 + 1
+    sc['col0'][:, 1], sc['col1'][:, 1] = lm, x0
+    sc['col0'][:, 2], sc['col1'][:, 2] = x1 + 1, np.maximum(rm, x1 + 1)
+    sc['ex0'][:, 0], sc['ex0'][:, 1], sc['ex0'][:, 2] = x0, lm, x1 + 2
+    sc['ey0'] = y0
+    sc['mirror'] = np.where(x0 == y0, 0, 1)
+    sc['mcol0'], sc['mcol1'], sc['mrow0'], sc['mrow1'] = 1, 0, 1, 0
+    return pv, sc
+
+
 class HipBackend:
     name = 'hip'
 
@@ -62,8 +91,18 @@ class HipBackend:
     def close_chrom(self, band):
         band.close()
 
-    def frames(self, band, starts, ends):
-        return band.frames(starts, ends)
+    def frames(self, band, starts, ends, keep_all=False):
+        return band.frames(starts, ends, keep_all)
+
+    def band_nearest(self, band):
+        """(right, left) nearest-positive-pixel distances of a packed band as int64 arrays, None for other bands."""
+        try:
+            r, l = band.nearest()
+        except hip.StripennHipError as e:
+            if e.code == hip.STP_E_UNSUPPORTED:
+                return None
+            raise
+        return r.astype(np.int64), l.astype(np.int64)
 
     def stripe_search(self, frames, M_levels, sigma, minH, maxW, bfilter):
         return frames.stripe_search(M_levels, sigma=sigma, minH=minH, maxW=maxW, bfilter=bfilter)

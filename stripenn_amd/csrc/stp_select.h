@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_sel_pixel_values(const int64_t* __restr
     for (long long p = blockIdx.x * 256ll + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
         const long long i = b1[p], j = b2[p];
         double v = (double)cnt[p];
-        if (w) v = (i >= 0 && j >= 0 && i < nbins && j < nbins) ? (v * w[i]) * w[j] : 0.0;
+        if (w) v = (i >= 0 && j >= 0 && i < nbins && j < nbins) ? v * (w[i] * w[j]) : 0.0;
         out[2 * p] = v;
         out[2 * p + 1] = (i != j) ? v : 0.0;
     }

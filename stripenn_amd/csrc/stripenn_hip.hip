@@ -25,7 +25,7 @@ __global__ __launch_bounds__(512) void k_frame_compact(const double* __restrict_
                                                         const int32_t* __restrict__ fstart,
                                                         const int32_t* __restrict__ fn0, int32_t* __restrict__ S_out,
                                                         int16_t* __restrict__ nz_out,
-                                                        unsigned long long* __restrict__ fstat)
+                                                        unsigned long long* __restrict__ fstat, int keep_all)
 {
     __shared__ int s_wave[8];
     __shared__ unsigned long long s_n, s_mn, s_mx;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(512) void k_frame_compact(const double* __restrict_
             }
         }
     }
-    const bool flag = (c < n0) && (sum != 0.0);
+    const bool flag = (c < n0) && (keep_all || sum != 0.0);
     const unsigned long long bal = __ballot(flag);
     const int lane = c & 63, wv = c >> 6;
     for (int o = 32; o > 0; o >>= 1) {
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(512) void k_frame_compact(const double* __restrict_
     if (flag) nz_out[f * STP_FRAME_MAX + pos] = (int16_t)c;
     __syncthreads();
     if (c == 0) {
-        S_out[f] = (total > 10) ? total : 0;   // getStripe.py:818
+        S_out[f] = (keep_all || total > 10) ? total : 0;   // getStripe.py:818
         fstat[f * 3] = s_n; fstat[f * 3 + 1] = s_mn; fstat[f * 3 + 2] = s_mx;
     }
 }
@@ -711,20 +711,30 @@ __global__ __launch_bounds__(1024) void k_compact_recs(const stp_drec* __restric
 
 // Band packer: one lane per stored pixel of cooler's upper-triangular table; every pixel lands in two band
 // cells (itself and its mirror image).  The band was zeroed first; cells no pixel names stay 0.
+// value = count * (b[bin1] * b[bin2]): cooler's dense read multiplies the count matrix by np.outer(bias1, bias2).
+// near[0..nrows) / near[nrows..2 nrows): distance from each bin to the nearest stored pixel with a positive value
+// in its row of the symmetric matrix, to the right (column >= row) / to the left (column < row) -- every cis pixel
+// takes part, also those beyond the band's halfwidth.
 __global__ __launch_bounds__(256) void k_band_pack(const int64_t* __restrict__ bin1, const int64_t* __restrict__ bin2,
                                                     const int32_t* __restrict__ count, int64_t npix,
-                                                    const double* __restrict__ wloc /* weights of [lo, lo+nrows) or null */,
-                                                    int64_t lo, int64_t nrows, int W, int hw, double* __restrict__ band)
+                                                    const double* __restrict__ wloc /* bias of [lo, lo+nrows) or null */,
+                                                    int64_t lo, int64_t nrows, int W, int hw, double* __restrict__ band,
+                                                    int32_t* __restrict__ near)
 {
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = bin1[p] - lo, j = bin2[p] - lo;
+        int64_t i = bin1[p] - lo, j = bin2[p] - lo;
         if (i < 0 || j < 0 || i >= nrows || j >= nrows) continue;
+        if (j < i) { const int64_t t = i; i = j; j = t; }
         const int64_t d = j - i;
-        if (d > hw || d < -hw) continue;
         double v = (double)count[p];
-        if (wloc) v = (v * wloc[i]) * wloc[j];
-        if (d >= -hw && d < hw) band[i * (int64_t)W + (d + hw)] = v;
-        if (-d >= -hw && -d < hw) band[j * (int64_t)W + (hw - d)] = v;
+        if (wloc) v = v * (wloc[i] * wloc[j]);
+        if (v > 0.0) {
+            atomicMin(&near[i], (int32_t)d);                       // row i holds a positive pixel d columns to the right
+            if (d > 0) atomicMin(&near[nrows + j], (int32_t)d);    // row j holds its mirror image d columns to the left
+        }
+        if (d > hw) continue;
+        if (d < hw) band[i * (int64_t)W + (d + hw)] = v;
+        band[j * (int64_t)W + (hw - d)] = v;
     }
 }
 
@@ -764,6 +774,7 @@ struct stp_ctx {
     bool profiling = false;
     std::vector<stp_kstat> stats;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<std::vector<double>, stp_fastdiv>> fd_cache;   // verified interior bleed-over divisions
 };
 
 struct stp_band {
@@ -771,6 +782,7 @@ struct stp_band {
     int64_t nrows = 0;
     int hw = 0, W = 0;
     bool owned = false;
+    int32_t* near = nullptr;   // 2 x nrows nearest-positive-pixel distances (bands built by stp_band_pack only)
 };
 
 struct stp_frames {
@@ -1014,6 +1026,7 @@ void stp_band_free(stp_ctx* ctx, stp_band* b)
     if (!b) return;
     if (ctx) (void)hipSetDevice(ctx->device);
     if (b->owned && b->d) (void)hipFree((void*)b->d);
+    if (b->near) (void)hipFree(b->near);
     delete b;
 }
 
@@ -1033,7 +1046,14 @@ void stp_frames_free(stp_ctx* ctx, stp_frames* fr)
 int stp_frames_create(stp_ctx* ctx, const stp_band* band, const int32_t* start, const int32_t* end, int32_t n,
                       stp_frames** out)
 {
+    return stp_frames_create_ex(ctx, band, start, end, n, 0, out);
+}
+
+int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* start, const int32_t* end, int32_t n,
+                         int32_t flags, stp_frames** out)
+{
     if (!ctx || !band || !start || !end || !out || n <= 0) return STP_E_ARG;
+    if (flags & ~STP_FRAMES_KEEP_ALL) return set_err(ctx, STP_E_ARG, "stp_frames_create_ex: unknown flag");
     for (int i = 0; i < n; i++) {
         int n0 = end[i] - start[i] + 1;
         if (start[i] < 0 || end[i] >= band->nrows || n0 < 1 || n0 > STP_FRAME_MAX)
@@ -1070,7 +1090,7 @@ int stp_frames_create(stp_ctx* ctx, const stp_band* band, const int32_t* start, 
         for (int i = 0; i < n; i++) bytes += 8.0 * fr->h_n0[i] * fr->h_n0[i];
         prof_scope ps(ctx, "frame_compact", bytes);
         hipLaunchKernelGGL(k_frame_compact, dim3(n), dim3(512), 0, ctx->stream, band->d, band->W, band->hw, fr->d_start,
-                           fr->d_n0, fr->d_S, fr->d_nz, d_fstat);
+                           fr->d_n0, fr->d_S, fr->d_nz, d_fstat, (flags & STP_FRAMES_KEEP_ALL) ? 1 : 0);
     }
     FRCHK(hipGetLastError());
     {
@@ -1148,7 +1168,13 @@ int stp_band_pack(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2, const 
     const int64_t CH = (int64_t)1 << 23;                 // pixels per staged chunk (160 MB of table columns)
     const int64_t nch = npix < CH ? npix : CH;
     dev_buf b1, b2, bc, bw;
+    int32_t* near = nullptr;
+    if (hipMalloc((void**)&near, (size_t)nrows * 2 * sizeof(int32_t)) != hipSuccess) {
+        (void)hipFree(d); delete b;
+        return set_err(ctx, STP_E_NOMEM, "hipMalloc(band nearest-pixel table) failed");
+    }
     hipError_t e = hipMemsetAsync(d, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)near, 0x7FFFFFFF, (size_t)nrows * 2, ctx->stream);
     if (e == hipSuccess && nch) e = b1.alloc(ctx, (size_t)nch * sizeof(int64_t));
     if (e == hipSuccess && nch) e = b2.alloc(ctx, (size_t)nch * sizeof(int64_t));
     if (e == hipSuccess && nch) e = bc.alloc(ctx, (size_t)nch * sizeof(int32_t));
@@ -1165,18 +1191,32 @@ int stp_band_pack(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2, const 
             prof_scope ps(ctx, "band_pack", (double)n * 36.0);    // 20 B of table read + two 8 B cells written
             const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 64);
             hipLaunchKernelGGL(k_band_pack, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)b1.p, (const int64_t*)b2.p,
-                               (const int32_t*)bc.p, n, weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d);
+                               (const int32_t*)bc.p, n, weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d, near);
         }
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the staging buffers are reused
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
-        (void)hipFree(d); delete b;
+        (void)hipFree(d); (void)hipFree(near); delete b;
         return set_err(ctx, e == hipErrorOutOfMemory ? STP_E_NOMEM : STP_E_HIP, std::string("band pack: ") + hipGetErrorString(e));
     }
     b->d = d;
+    b->near = near;
     *out = b;
+    return STP_OK;
+}
+
+int stp_band_nearest(stp_ctx* ctx, const stp_band* band, int32_t* right_out, int32_t* left_out)
+{
+    if (!ctx || !band || !right_out || !left_out) return STP_E_ARG;
+    if (!band->near)
+        return set_err(ctx, STP_E_UNSUPPORTED, "nearest-pixel table: only bands built by stp_band_pack carry one");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(right_out, band->near, (size_t)band->nrows * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(left_out, band->near + band->nrows, (size_t)band->nrows * sizeof(int32_t), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return STP_OK;
 }
 
@@ -1191,11 +1231,12 @@ int stp_band_download(stp_ctx* ctx, const stp_band* band, double* out_host)
 
 // Interior bleed-over constant of the given Gaussian weights and exhaustive verification of the
 // multiply + 2 FMA division by it for every float mantissa (cached per weight vector).
-static stp_fastdiv make_fastdiv(const double* w, int R)
+static stp_fastdiv make_fastdiv(stp_ctx* ctx, const double* w, int R)
 {
-    static std::vector<double> cache_w;
-    static stp_fastdiv cache_fd = {0.0, 0.0, 0};
-    if ((int)cache_w.size() == 2 * R + 1 && memcmp(cache_w.data(), w, (2 * R + 1) * sizeof(double)) == 0) return cache_fd;
+    // cached per context (contexts may be driven from different host threads) and per weight vector: a few
+    // vectors are kept so that alternating sigmas do not re-run the 8 M-iteration verification
+    for (auto& e : ctx->fd_cache)
+        if ((int)e.first.size() == 2 * R + 1 && memcmp(e.first.data(), w, (2 * R + 1) * sizeof(double)) == 0) return e.second;
     stp_fastdiv fd;
     const int S = 4 * R + 8;                                       // any size with an interior pixel
     const double V = stp_bleed_v(2 * R + 2, S, R, w);
@@ -1209,8 +1250,8 @@ static stp_fastdiv make_fastdiv(const double* w, int R)
         const double q = stp_div_const((double)f, fd.c, fd.rc), t = (double)f / fd.c;
         if (memcmp(&q, &t, 8) != 0) fd.ok = 0;
     }
-    cache_w.assign(w, w + 2 * R + 1);
-    cache_fd = fd;
+    if (ctx->fd_cache.size() >= 8) ctx->fd_cache.erase(ctx->fd_cache.begin());
+    ctx->fd_cache.push_back(std::make_pair(std::vector<double>(w, w + 2 * R + 1), fd));
     return fd;
 }
 
@@ -1252,7 +1293,7 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         prof_scope ps(ctx, "canny", ipx * 5.0);          // stage B: 4 B read + 1 B written
         const int tiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
         const dim3 cg(tiles, (unsigned)nimg);
-        const stp_fastdiv fd = make_fastdiv(prm->gauss_w, R);
+        const stp_fastdiv fd = make_fastdiv(ctx, prm->gauss_w, R);
         const unsigned pgrid = (unsigned)(((nf * nlev + 7) / 8) * 8 * tiles);
         if (R == 8)
             hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES, ctx->stream, d_gray,

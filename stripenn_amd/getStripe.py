@@ -69,8 +69,11 @@ def quantile_linear(order_stats, n, q):
 
 class getStripe:
     def __init__(self, unbalLib, resol, minH, maxW, canny, all_chromnames, chromnames, all_chromsizes, chromsizes, core,
-                 bfilter, seed, backend=None, device=0, halfwidth=HALFWIDTH):
-        """Reference signature (getStripe.py:18) + optional backend/device/halfwidth keywords."""
+                 bfilter, seed, backend=None, device=0, halfwidth=None, frame_span=None):
+        """Reference signature (getStripe.py:18) + optional keywords (not in the reference): backend / device;
+        halfwidth of the resident band (default: 512, or more when 448 + 2 * (50000 / resol) needs it, i.e. below
+        1 kb); frame_span = {chromosome: (first frame, one past the last)} restricts extract() to those frames
+        of a chromosome (multi-GPU driver, stripenn_amd/shard.py) -- only the band rows they need are built."""
         self.unbalLib = unbalLib
         self.resol = int(resol)
         self.minH = minH
@@ -87,9 +90,15 @@ class getStripe:
         self.chromnames2sizes = {}
         for i in range(len(self.all_chromnames)):
             self.chromnames2sizes[self.all_chromnames[i]] = self.all_chromsizes[i]
+        if halfwidth is None:
+            need = 448 + 2 * int(50000 / self.resol)              # frame 400 + flank + windows (include/stripenn_hip.h)
+            halfwidth = max(HALFWIDTH, -(-need // 64) * 64)
         self.halfwidth = int(halfwidth)
+        self.frame_span = {str(k): (int(v[0]), int(v[1])) for k, v in (frame_span or {}).items()}
         self.backend = backend if backend is not None else HipBackend(device)   # raises without a GPU
         self._bands = {}
+        self._partial = set()           # chromosomes whose resident band holds only the rows of their frame span
+        self._near = {}
         self._frames = {}
         self._search_cache = {}
         self.timing = {}
@@ -98,25 +107,41 @@ class getStripe:
     def _nbins(self, chrom):
         return int(math.ceil(int(self.chromnames2sizes[str(chrom)]) / self.resol))
 
-    def _band(self, chrom):
-        """Resident band of one chromosome; built from row strips fetched through the selector."""
+    def _band(self, chrom, whole=True):
+        """Resident band of one chromosome; built from row strips fetched through the selector, or packed on the
+        device from the pixel table.  whole=False (extract and the per-stripe kernels) accepts a band that holds
+        only the rows of the chromosome's frame span; the whole-chromosome steps (expected values, background)
+        ask for all rows."""
         chrom = str(chrom)
-        if chrom in self._bands:
+        if chrom in self._bands and not (whole and chrom in self._partial):
             return self._bands[chrom]
+        if chrom in self._bands:                                   # a partial band has to become a whole one
+            self.release(chrom)
         t0 = time.time()
         nb = self._nbins(chrom)
         size = int(self.chromnames2sizes[chrom])
         hw = self.halfwidth
+        # rows the frames of this chromosome's span can touch (+ one halfwidth of margin), or all of them
+        ra, rb = 0, nb
+        if not whole and chrom in self.frame_span:
+            fa, fb = self.frame_span[chrom]
+            ra, rb = max(0, fa * 200 - 100 - hw), min(nb, fb * 200 + 100 + hw)
+            if (ra, rb) != (0, nb):
+                self._partial.add(chrom)
         if hasattr(self.unbalLib, 'chrom_pixels') and hasattr(self.backend, 'pack_chrom'):
             # the source IS cooler's pixel table: the device builds the band from it, no dense fetch at all
-            self._bands[chrom] = self.backend.pack_chrom(self.unbalLib.chrom_pixels(chrom), hw)
+            px = self.unbalLib.chrom_pixels(chrom)
+            if (ra, rb) != (0, nb):                                # stored pixels (i <= j) that land in rows [ra, rb)
+                a, b = np.searchsorted(px['bin1'], [px['lo'] + ra - hw, px['lo'] + rb], side='left')
+                px = dict(px, bin1=px['bin1'][a:b], bin2=px['bin2'][a:b], count=px['count'][a:b])
+            self._bands[chrom] = self.backend.pack_chrom(px, hw)
             self.timing['band_build_s'] = self.timing.get('band_build_s', 0.0) + time.time() - t0
             return self._bands[chrom]
         band = np.zeros((nb, 2 * hw), dtype=np.float64)
         strip = 2048
         dd = np.arange(-hw, hw)[None, :]
-        for r0 in range(0, nb, strip):
-            r1 = min(r0 + strip, nb)
+        for r0 in range(ra, rb, strip):
+            r1 = min(r0 + strip, rb)
             c0, c1 = max(r0 - hw, 0), min(r1 + hw, nb)
             rows = '%s:%d-%d' % (chrom, r0 * self.resol + 1, min(r1 * self.resol, size))
             cols = '%s:%d-%d' % (chrom, c0 * self.resol + 1, min(c1 * self.resol, size))
@@ -136,6 +161,8 @@ class getStripe:
             fr = self._frames.pop(c, None)
             if fr is not None and hasattr(fr[0], 'close'):
                 fr[0].close()
+            self._partial.discard(c)
+            self._near.pop(c, None)
             b = self._bands.pop(c, None)
             if b is not None:
                 self.backend.close_chrom(b)
@@ -279,14 +306,38 @@ class getStripe:
             if a > b:
                 a, b = b, a
             pos = '%s:%d-%d' % (chrom, a, b)
-            live = self._rows_nonzero(pos, pos)[0]
+            live = self._rows_nonzero(pos, pos, chrom)[0]
             poolsum += int(np.count_nonzero(live))
         return poolsum
 
-    def _rows_nonzero(self, p1, p2):
-        """(rows whose sum over the fetched block is non-zero after NaN -> 0, the block or None).  A selector that
-        can answer from its own tables (PixelSelector.row_nonzero) spares the dense block; it is then fetched
-        only by the caller that really needs its pixels."""
+    def _nearest(self, chrom):
+        """(right, left) nearest-positive-pixel distances of a chromosome whose band was packed on the device from
+        ALL its cis pixels (stp_band_nearest), or None: dense-fetch sources, partial bands, tables with negative
+        values (there a zero row sum does not mean an empty row)."""
+        if chrom in self._near:
+            return self._near[chrom]
+        near = None
+        ok = getattr(self.unbalLib, 'nonnegative', None)
+        if ok is not None and ok() and hasattr(self.backend, 'band_nearest'):
+            band = self._band(chrom)
+            if chrom not in self._partial:
+                near = self.backend.band_nearest(band)
+        self._near[chrom] = near
+        return near
+
+    def _rows_nonzero(self, p1, p2, chrom=None):
+        """(rows whose sum over the fetched block is non-zero after NaN -> 0, the block or None).  Answered without
+        a dense block when possible: from the nearest-positive-pixel table the device filled while packing the band
+        (row i of rows x [c0, c1), c0 <= rows < c1, is non-empty iff i + right[i] < c1 or i - left[i] >= c0), else
+        from the selector's own tables (PixelSelector.row_nonzero); the block is then fetched only by the caller
+        that really needs its pixels."""
+        if chrom is not None:
+            near = self._nearest(chrom)
+            if near is not None:
+                (r0, r1), (c0, c1) = self._region_bins(p1), self._region_bins(p2)
+                if c0 <= r0 and c1 >= r1:
+                    i = np.arange(r0, r1, dtype=np.int64)
+                    return (i + near[0][r0:r1] < c1) | (i - near[1][r0:r1] >= c0), None
         fast = getattr(self.unbalLib, 'row_nonzero', None)
         if fast is not None:
             live = fast(p1, p2)
@@ -294,6 +345,11 @@ class getStripe:
                 return live, None
         mat = nantozero(np.array(self.unbalLib.fetch(p1, p2), dtype=np.float64))
         return np.sum(mat, axis=1) != 0, mat
+
+    def _region_bins(self, region):
+        name, rng = str(region).rsplit(':', 1)
+        a, b = rng.split('-')
+        return _extent(int(a), int(b), self.resol)
 
     def null_samplesizes(self, chromnames2, n_available_col):
         """:278-283 (the sample-size array keeps its unfiltered indexing, as in the reference)"""
@@ -306,8 +362,26 @@ class getStripe:
             samplesize[0] = np.uint64(int(samplesize[0]) + dif)
         return chromnames2, samplesize
 
-    def null_tables(self, chrom, chromnames2, samplesize):
-        """main_null_calc (:285-479) for one chromosome -> four 400 x ss tables"""
+    def null_pools(self, chrom):
+        """The sampling pools of one chromosome's units (:329-335): per unit the rows with a non-zero sum that keep
+        the 20-row margin (`base`, what the top-up branch draws from, :436-438) and the pool of the unit loop
+        (`pool`: unit 0 also drops x <= 410).  Plain lists: they travel between ranks in the multi-GPU driver."""
+        chrom = str(chrom)
+        chrsize, itera, unitsize = self._unit_geometry(chrom)
+        out = []
+        for it in range(itera):
+            p1, p2, r0, r1, c0, c1 = self._unit_regions(chrom, it, chrsize, unitsize)
+            live = self._rows_nonzero(p1, p2, chrom)[0]
+            x = np.nonzero(live)[0]
+            base = x[(x > 20) & (x < (unitsize - 20))]
+            pool = base[(base > 410) & (base < (c1 - c0))] if it == 0 else base
+            out.append((base.tolist(), pool.tolist()))
+        return out
+
+    def null_tables(self, chrom, chromnames2, samplesize, pools=None, windows=True):
+        """main_null_calc (:285-479) for one chromosome -> four 400 x ss tables.  `pools` (null_pools) may come
+        from another rank; windows=False only draws the samples (the PRNG stream of numcores == 1 runs on across
+        chromosomes, so every rank replays the draws of the chromosomes it does not own) and returns None."""
         resol = self.resol
         bs = int(50000 / resol)
         tabs = [[], [], [], []]
@@ -317,7 +391,9 @@ class getStripe:
             c = chromnames2.index(chrom)
             ss = samplesize[c]                                     # (index into the unfiltered array, :295-298)
             chrsize, itera, unitsize = self._unit_geometry(chrom)
-            band = self._band(chrom)
+            if pools is None:
+                pools = self.null_pools(chrom)
+            band = self._band(chrom) if windows else None
             self._null_pending = []
             n_pool = []
             collected = 0
@@ -325,28 +401,26 @@ class getStripe:
             last_it = -1
             for it in range(itera):
                 last_it = it
-                p1, p2, r0, r1, c0, c1 = self._unit_regions(chrom, it, chrsize, unitsize)
-                live, mat = self._rows_nonzero(p1, p2)
-                pool = np.nonzero(live)[0].tolist()
-                pool = [x for x in pool if x > 20 and x < (unitsize - 20)]
-                if it == 0:
-                    pool = [x for x in pool if x > 410 and x < (c1 - c0)]
+                pool = pools[it][1]
                 n_pool.append(len(pool))
                 if len(pool) == 0:
                     continue
                 k = len(pool) if len(pool) < sss else sss
                 randval = prng.choices(pool, k=k)
-                collected += self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if it > 0 else 0, bs, mat, (p1, p2))
+                collected += len(randval)
+                if windows:
+                    p1, p2, r0, r1, c0, c1 = self._unit_regions(chrom, it, chrsize, unitsize)
+                    self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if it > 0 else 0, bs, None, (p1, p2))
             depl = int(ss) - collected                             # :416-477
             if depl > 0:
                 rich = int(np.argmax(n_pool))
-                p1, p2, r0, r1, c0, c1 = self._unit_regions(chrom, rich, chrsize, unitsize)
-                live, mat = self._rows_nonzero(p1, p2)
-                pool = np.nonzero(live)[0].tolist()
-                pool = [x for x in pool if x > 20 and x < (unitsize - 20)]
-                randval = prng.choices(pool, k=depl)
-                # the reference tests the loop variable `it` left over from the unit loop (:458)
-                self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if last_it > 0 else 0, bs, mat, (p1, p2))
+                randval = prng.choices(pools[rich][0], k=depl)
+                if windows:
+                    p1, p2, r0, r1, c0, c1 = self._unit_regions(chrom, rich, chrsize, unitsize)
+                    # the reference tests the loop variable `it` left over from the unit loop (:458)
+                    self._null_batch(band, tabs, randval, r0, r1, c0, c1, 400 if last_it > 0 else 0, bs, None, (p1, p2))
+            if not windows:
+                return None
             self._null_flush(band, tabs, bs)
         return [np.column_stack([np.zeros((400, 0))] + t) for t in tabs]
 
@@ -403,87 +477,89 @@ class getStripe:
                 t[pos] = a[:, o:o + n]
             o += n
 
+    # ------------------------------------------------------------------ table columns as arrays
+    @staticmethod
+    def _icol(df, k):
+        """A position column as int64 (the reference converts each value with int(float(v)))."""
+        a = np.asarray(df[k])
+        if a.dtype.kind in 'iu':
+            return a.astype(np.int64)
+        return np.trunc(np.asarray(a, dtype=np.float64)).astype(np.int64)
+
+    @staticmethod
+    def _tdiv(a, r):
+        """int(a / r) of the reference: division truncated towards zero."""
+        return np.where(a >= 0, a // r, -((-a) // r))
+
+    @staticmethod
+    def _groups(df):
+        """[(chromosome, row indices in table order)], chromosomes in order of first appearance."""
+        names = [str(c) for c in df['chr'].tolist()]
+        codes = {}
+        code = np.fromiter((codes.setdefault(c, len(codes)) for c in names), dtype=np.int64, count=len(names))
+        return [(c, np.nonzero(code == k)[0]) for c, k in codes.items()]
+
     # ------------------------------------------------------------------ observed mean (score only)
     def getMean(self, df, mask='0'):
         """getStripe.py:501-534 (K: k_stripe_mean)."""
         n = len(df)
         listM = [0 for _ in range(n)]
         listS = [0 for _ in range(n)]
-        by_chr = {}
-        for i in range(n):
-            by_chr.setdefault(str(df['chr'].iloc[i]), []).append(i)
-        for chrom, idx in by_chr.items():
-            rects = np.zeros(len(idx), dtype=RECT_DTYPE)
-            for k, i in enumerate(idx):
-                xs, xe = int(df['pos1'].iloc[i]), int(df['pos2'].iloc[i])
-                ys, ye = int(df['pos3'].iloc[i]), int(df['pos4'].iloc[i])
-                rects['row0'][k], rects['row1'][k] = _extent(ys, ye, self.resol)
-                rects['col0'][k], rects['col1'][k] = _extent(xs, xe, self.resol)
-            m, s = self.backend.stripe_mean(self._band(chrom), rects)
-            for k, i in enumerate(idx):
-                listM[i] = m[k]
-                listS[i] = s[k]
-        return listM, listS
+        if n == 0:
+            return listM, listS
+        r = self.resol
+        xs, xe, ys, ye = (self._icol(df, k) for k in ('pos1', 'pos2', 'pos3', 'pos4'))
+        rects = np.zeros(n, dtype=RECT_DTYPE)
+        rects['row0'], rects['row1'] = ys // r, -(-ye // r)           # cooler's extent of 'chr:start-end'
+        rects['col0'], rects['col1'] = xs // r, -(-xe // r)
+        M, S = np.zeros(n), np.zeros(n)
+        for chrom, idx in self._groups(df):
+            M[idx], S[idx] = self.backend.stripe_mean(self._band(chrom, whole=False), rects[idx])
+        return list(M), list(S)
 
     # ------------------------------------------------------------------ p-value
     def pvalue(self, bgleft_up, bgright_up, bgleft_down, bgright_down, df):
         """getStripe.py:536-606 (K: k_pvalue).  The direction of every stripe -- including the
         background rows a stripe INHERITS from its predecessor when it touches neither end of the
-        diagonal (:584-597) -- is decided here exactly like the reference's loop."""
+        diagonal (:584-597) -- is decided here exactly like the reference's loop, on whole columns."""
         bs = int(50000 / self.resol)
+        resol = self.resol
         n = len(df)
         if n == 0:
             return []
         self.backend.set_background(bgleft_up, bgright_up, bgleft_down, bgright_down)
+        groups = self._groups(df)
+        pos1, pos2, pos3, pos4 = (self._icol(df, k) for k in ('pos1', 'pos2', 'pos3', 'pos4'))
+        chrlen = np.zeros(n, dtype=np.int64)
+        for chrom, idx in groups:
+            chrlen[idx] = int(self.chromnames2sizes[chrom])
+        leftmost = np.maximum(pos1 - bs * resol, 1)                    # :552-559
+        rightmost = np.minimum(pos2 + bs * resol, chrlen)
         stripes = np.zeros(n, dtype=PV_STRIPE_DTYPE)
-        chroms = []
-        have_prev = False
-        prev_row, prev_tab = 0, 0
-        col_chr = [str(c) for c in df['chr'].tolist()]            # columns read once (not 5 .iloc calls per row)
-        col_p = [df[k].tolist() for k in ('pos1', 'pos2', 'pos3', 'pos4')]
-        for i in range(n):
-            chrom = col_chr[i]
-            chrLen = self.chromnames2sizes[chrom]
-            pos1, pos2, pos3, pos4 = col_p[0][i], col_p[1][i], col_p[2][i], col_p[3][i]
-            leftmost = pos1 - bs * self.resol
-            rightmost = pos2 + bs * self.resol
-            if leftmost < 1:
-                leftmost = 1
-            if rightmost > chrLen:
-                rightmost = chrLen
-            c0, c1 = _extent(int(float(leftmost)), int(float(rightmost)), self.resol)
-            r0, r1 = _extent(int(float(pos3)), int(float(pos4)), self.resol)
-            x1 = int((pos1 - 1) / self.resol)
-            x2 = int(pos2 / self.resol)
-            y1 = int((pos3 - 1) / self.resol)
-            y2 = int(pos4 / self.resol)
-            h = r1 - r0
-            s = stripes[i]
-            s['row0'], s['row1'], s['col0'], s['col1'] = r0, r1, c0, c1
-            s['upbase'] = y2 - y1
-            if x1 == y1:
-                s['mode'] = 0
-                if h > 0:
-                    have_prev, prev_row, prev_tab = True, min(h - 1, 399), 1
-            elif x2 == y2:
-                s['mode'] = 1
-                if h > 0:
-                    d = (y2 - y1) - (h - 1) - 1
-                    have_prev, prev_row, prev_tab = True, (399 if d >= 400 else d), 0
-            else:
-                if not have_prev:
-                    raise UnboundLocalError("local variable 'bleft' referenced before assignment")  # as the reference
-                s['mode'], s['fixed_row'], s['fixed_tab'] = 2, prev_row % 400, prev_tab
-            chroms.append(chrom)
-        PVAL = [0.0] * n
-        order = {}
-        for i, c in enumerate(chroms):
-            order.setdefault(c, []).append(i)
-        for chrom, idx in order.items():
-            p = self.backend.pvalue(self._band(chrom), bs, stripes[idx])
-            for k, i in enumerate(idx):
-                PVAL[i] = p[k]
-        return PVAL
+        stripes['col0'], stripes['col1'] = leftmost // resol, -(-rightmost // resol)
+        stripes['row0'], stripes['row1'] = pos3 // resol, -(-pos4 // resol)
+        x1, x2 = self._tdiv(pos1 - 1, resol), self._tdiv(pos2, resol)
+        y1, y2 = self._tdiv(pos3 - 1, resol), self._tdiv(pos4, resol)
+        h = stripes['row1'].astype(np.int64) - stripes['row0']
+        stripes['upbase'] = y2 - y1
+        mode = np.where(x1 == y1, 0, np.where(x2 == y2, 1, 2))
+        stripes['mode'] = mode
+        need = mode == 2
+        if need.any():
+            # `bleft` / `bright` keep the rows the last stripe that set them left behind (:584-597)
+            src = np.where((mode != 2) & (h > 0), np.arange(n), -1)
+            last = np.maximum.accumulate(src)
+            if (last[need] < 0).any():
+                raise UnboundLocalError("local variable 'bleft' referenced before assignment")  # as the reference
+            j = last[need]
+            d_up = (y2[j] - y1[j]) - (h[j] - 1) - 1
+            prev_row = np.where(mode[j] == 0, np.minimum(h[j] - 1, 399), np.where(d_up >= 400, 399, d_up))
+            stripes['fixed_row'][need] = prev_row % 400
+            stripes['fixed_tab'][need] = np.where(mode[j] == 0, 1, 0)
+        P = np.zeros(n)
+        for chrom, idx in groups:
+            P[idx] = self.backend.pvalue(self._band(chrom, whole=False), bs, stripes[idx])
+        return P.tolist()
 
     # ------------------------------------------------------------------ Stripiness
     def scoringstripes(self, df, expecVal, mask='0'):
@@ -513,66 +589,58 @@ class getStripe:
             return lo, hi
 
         nrow = df.shape[0]
-        listg = [0 for _ in range(nrow)]
-        listMean = [0 for _ in range(nrow)]
-        listTotal = [0 for _ in range(nrow)]
-        chrset = list(set(df['chr']))
-        chrcol = np.asarray(df['chr'])
-        col_p = [df[k].tolist() for k in ('pos1', 'pos2', 'pos3', 'pos4')]      # columns read once
-        for c in chrset:
+        G, CM, CT = np.zeros(nrow), np.zeros(nrow), np.zeros(nrow)
+        if nrow == 0:
+            return [], [], []
+        XS, XE, YS, YE = (self._icol(df, k) for k in ('pos1', 'pos2', 'pos3', 'pos4'))
+        for c, idx in self._groups(df):
             is_mask = is_masking and (mask_chr == c)
-            idx = np.where(chrcol == c)[0].tolist()
             chrom_idx = self.chromnames.index(str(c))
             chrom_bin_size = int(np.ceil(self.chromsizes[chrom_idx] / resol))
             exval = np.asarray(expecVal[str(c)], dtype=np.float64)
+            xs, xe, ys, ye = XS[idx], XE[idx], YS[idx], YE[idx]
+            xsi, xei = self._tdiv(xs, resol), self._tdiv(xe, resol)       # :668-673
+            ysi, yei = self._tdiv(ys, resol), self._tdiv(ye, resol)
+            leftmost = np.maximum(xsi - bs, 1)                            # :675-680
+            rightmost = np.where(xei + bs >= chrom_bin_size, chrom_bin_size - 1, xei + bs)
             st = np.zeros(len(idx), dtype=SCORE_STRIPE_DTYPE)
-            for k, i in enumerate(idx):
-                xs, xe, ys, ye = col_p[0][i], col_p[1][i], col_p[2][i], col_p[3][i]
-                x_start_index = int(xs / resol)
-                x_end_index = int(xe / resol)
-                y_start_index = int(ys / resol)
-                y_end_index = int(ye / resol)
-                leftmost = x_start_index - bs
-                rightmost = x_end_index + bs
-                if leftmost < 1:
-                    leftmost = 1
-                if rightmost >= chrom_bin_size:
-                    rightmost = chrom_bin_size - 1
-                s = st[k]
-                s['row0'], s['row1'] = _extent(int(ys), int(ye), resol)
-                s['col0'][0], s['col1'][0] = _extent(int(xs), int(xe), resol)
-                s['col0'][1], s['col1'][1] = _extent(int(leftmost * resol), int(x_start_index * resol), resol)
-                s['col0'][2], s['col1'][2] = _extent(int(x_end_index * resol), int(rightmost * resol), resol)
-                s['ex0'] = (x_start_index, leftmost, x_end_index + 1)
-                s['ey0'] = y_start_index
-                s['mirror'] = 0 if xs == ys else 1
-                # np.divide(obs, exp) needs equal shapes (:687,693,699); the reference raises otherwise
-                ex_w = (x_end_index - x_start_index, x_start_index - leftmost, rightmost - x_end_index)
-                ex_h = y_end_index - y_start_index
-                for b in range(3):
-                    ow, oh = int(s['col1'][b] - s['col0'][b]), int(s['row1'] - s['row0'])
-                    if (oh, ow) != (ex_h, ex_w[b]):
-                        raise ValueError('operands could not be broadcast together with shapes (%d,%d) (%d,%d) '
-                                         % (oh, ow, ex_h, ex_w[b]))
-                s['mcol0'], s['mcol1'] = (1, 1, 1), (0, 0, 0)
-                s['mrow0'], s['mrow1'] = 1, 0
-                if is_mask and mask_start > np.min([xs - 50000, ys]) and mask_start < np.max([xe + 50000, ye]):
+            st['row0'], st['row1'] = ys // resol, -(-ye // resol)         # the three fetches (:682-696) as bin extents
+            st['col0'][:, 0], st['col1'][:, 0] = xs // resol, -(-xe // resol)
+            st['col0'][:, 1], st['col1'][:, 1] = leftmost, xsi
+            st['col0'][:, 2], st['col1'][:, 2] = xei, rightmost
+            st['ex0'][:, 0], st['ex0'][:, 1], st['ex0'][:, 2] = xsi, leftmost, xei + 1
+            st['ey0'] = ysi
+            st['mirror'] = np.where(xs == ys, 0, 1)
+            # np.divide(obs, exp) needs equal shapes (:687,693,699); the reference raises otherwise
+            ex_w = np.stack([xei - xsi, xsi - leftmost, rightmost - xei], axis=1)
+            ex_h = yei - ysi
+            ow = st['col1'].astype(np.int64) - st['col0']
+            oh = st['row1'].astype(np.int64) - st['row0']
+            bad = (oh[:, None] != ex_h[:, None]) | (ow != ex_w)
+            if bad.any():
+                k, b = np.argwhere(bad)[0]
+                raise ValueError('operands could not be broadcast together with shapes (%d,%d) (%d,%d) '
+                                 % (oh[k], ow[k, b], ex_h[k], ex_w[k, b]))
+            st['mcol0'], st['mcol1'] = 1, 0
+            st['mrow0'], st['mrow1'] = 1, 0
+            if is_mask:
+                hit = (mask_start > np.minimum(xs - 50000, ys)) & (mask_start < np.maximum(xe + 50000, ye))
+                for k in np.nonzero(hit)[0].tolist():
+                    s = st[k]
                     h = int(s['row1'] - s['row0'])
-                    starts = (x_start_index, leftmost, x_end_index + 1)
-                    ends = (x_end_index, x_start_index, rightmost)
+                    starts = (int(xsi[k]), int(leftmost[k]), int(xei[k]) + 1)
+                    ends = (int(xei[k]), int(xsi[k]), int(rightmost[k]))
                     for b in range(3):
                         lo, hi = mask_range(starts[b], ends[b], int(s['col1'][b] - s['col0'][b]), 1)
                         s['mcol0'][b], s['mcol1'][b] = lo, hi
-                    s['mrow0'], s['mrow1'] = mask_range(y_start_index, y_end_index, h, 0)
-            g, cm, ct = self.backend.stripiness(self._band(str(c)), exval, st)
-            for k, i in enumerate(idx):
-                listg[i] = float(g[k])
-                listMean[i] = cm[k]
-                listTotal[i] = ct[k]
-        return listg, listMean, listTotal
+                    s['mrow0'], s['mrow1'] = mask_range(int(ysi[k]), int(yei[k]), h, 0)
+            G[idx], CM[idx], CT[idx] = self.backend.stripiness(self._band(str(c), whole=False), exval, st)
+        return G.tolist(), list(CM), list(CT)
 
     # ------------------------------------------------------------------ stripe search
     def _chrom_frames(self, chrom, chridx):
+        """(frames handle, starts, ends, number of the first frame) of a chromosome -- all its frames, or those
+        of its frame span."""
         if chrom in self._frames:
             return self._frames[chrom]
         rowsize = int(np.ceil(self.chromsizes[chridx] / self.resol))
@@ -587,8 +655,11 @@ class getStripe:
                 start = 0
             starts.append(start)
             ends.append(end)
-        fr = self.backend.frames(self._band(chrom), np.array(starts, np.int32), np.array(ends, np.int32))
-        self._frames[chrom] = (fr, starts, ends)
+        fa, fb = self.frame_span.get(str(chrom), (0, nframes))
+        fa, fb = max(0, fa), min(nframes, fb)
+        starts, ends = starts[fa:fb], ends[fa:fb]
+        fr = self.backend.frames(self._band(chrom, whole=False), np.array(starts, np.int32), np.array(ends, np.int32))
+        self._frames[chrom] = (fr, starts, ends, fa)
         return self._frames[chrom]
 
     def _search(self, chrom, chridx, M_levels):
@@ -596,7 +667,7 @@ class getStripe:
         re-runs every frame per level (stripenn.py:134-138); the kernels share the band reads."""
         key = (chrom, tuple(float(m) for m in M_levels))
         if key not in self._search_cache:
-            fr, starts, ends = self._chrom_frames(chrom, chridx)
+            fr = self._chrom_frames(chrom, chridx)[0]
             t0 = time.time()
             recs = self.backend.stripe_search(fr, np.asarray(M_levels, dtype=np.float64), self.canny, self.minH,
                                               self.maxW, int(self.bfilter))
@@ -606,36 +677,41 @@ class getStripe:
 
     def extract(self, MP, index, perc, bgleft_up, bgright_up, bgleft_down, bgright_down):
         """getStripe.py:790-862: candidate stripes of one maxpixel level, all chromosomes."""
-        tables = [pd.DataFrame(columns=EXTRACT_COLUMNS)]
+        parts = []
         for chridx in range(len(self.chromnames)):
             chrom = self.chromnames[chridx]
             print('Chromosome: ' + str(chrom) + " / Maximum pixel: " + str(round(perc * 100, 3)) + "%")
             recs = self._search(chrom, chridx, MP[chrom])
             recs = recs[recs['level'] == index]
-            fr, starts, ends = self._chrom_frames(chrom, chridx)
-            tables.append(self._chrom_table(chrom, int(self.chromsizes[chridx]), starts, ends, fr, recs, perc))
-        result = pd.concat(tables)
+            fr, starts, ends, f0 = self._chrom_frames(chrom, chridx)
+            parts.append(self._chrom_rows(chrom, int(self.chromsizes[chridx]), starts, ends, f0, fr, recs, perc))
+        if sum(len(p['x']) for p in parts) == 0:
+            result = pd.DataFrame(columns=EXTRACT_COLUMNS)
+        else:                                                            # one table for the level, built once
+            result = pd.DataFrame({k: np.concatenate([p[k] for p in parts]) for k in EXTRACT_COLUMNS},
+                                  columns=EXTRACT_COLUMNS)
         # StripeSearch ends with RemoveRedundant over the rows of ONE frame (getStripe.py:1112): same filter,
         # all frames in one device call, pairs restricted to equal frame numbers
         result = self._filter_redundant(result, 'size', same_frame_only=True)
         res = self.RemoveRedundant(result, 'size')                       # :852
         res = res.reset_index(drop=True)
         p = self.pvalue(bgleft_up, bgright_up, bgleft_down, bgright_down, res)
-        res = res.assign(pvalue=pd.Series(p))
+        res = res.assign(pvalue=pd.Series(p, dtype=np.float64))
         return res
 
-    def _chrom_table(self, chrom, chromsize, starts, ends, fr, recs, perc):
-        """Rows of all frames of one chromosome as StripeSearch builds them (getStripe.py:1081-1110),
-        vectorised: bp coordinates through the compaction map, frame order then record order."""
+    def _chrom_rows(self, chrom, chromsize, starts, ends, f0, fr, recs, perc):
+        """Columns of all frames of one chromosome as StripeSearch builds them (getStripe.py:1081-1110),
+        vectorised: bp coordinates through the compaction map, frame order then record order.  `f0` is the
+        number of the first frame in `starts` (the `num` column counts frames from the chromosome's start)."""
         n = len(recs)
         f = recs['frame'].astype(np.int64)
-        st = np.asarray(starts, dtype=np.int64)[f]
-        en = np.asarray(ends, dtype=np.int64)[f]
+        st = np.asarray(starts, dtype=np.int64)[f] if n else np.zeros(0, np.int64)
+        en = np.asarray(ends, dtype=np.int64)[f] if n else np.zeros(0, np.int64)
         x = recs['x'].astype(np.int64)
         y = recs['y'].astype(np.int64)
         w = recs['w'].astype(np.int64)
         h = recs['h'].astype(np.int64)
-        nz = fr.nz.astype(np.int64)
+        nz = fr.nz
 
         def start_bp(idx):
             return (st + nz[f, idx]) * self.resol + 1
@@ -647,15 +723,57 @@ class getStripe:
         pos1, pos2 = start_bp(x), end_bp(x + w - 1)
         pos3, pos4 = start_bp(y), end_bp(y + h - 1)
         total = recs['total']
-        return pd.DataFrame({'chr': [chrom] * n, 'pos1': pos1, 'pos2': pos2, 'chr2': [chrom] * n, 'pos3': pos3, 'pos4': pos4,
-                             'length': pos4 - pos3 + 1, 'width': pos2 - pos1 + 1, 'total': total, 'Mean': total / h / w,
-                             'maxpixel': [str(perc * 100) + '%'] * n, 'num': f, 'start': st, 'end': en, 'x': x, 'y': y,
-                             'h': h, 'w': w, 'medpixel': fr.medpixel[f].astype(np.float64)})
+        name = np.empty(n, dtype=object)
+        name[:] = chrom
+        label = np.empty(n, dtype=object)
+        label[:] = str(perc * 100) + '%'
+        with np.errstate(divide='ignore', invalid='ignore'):
+            mean = total / h / w
+        return {'chr': name, 'pos1': pos1, 'pos2': pos2, 'chr2': name, 'pos3': pos3, 'pos4': pos4,
+                'length': pos4 - pos3 + 1, 'width': pos2 - pos1 + 1, 'total': total, 'Mean': mean,
+                'maxpixel': label, 'num': f + f0, 'start': st, 'end': en, 'x': x, 'y': y,
+                'h': h, 'w': w, 'medpixel': fr.medpixel[f].astype(np.float64) if n else np.zeros(0)}
 
     def StripeSearch(self, submat, num, start, end, M, perc, chr, framesize, start_array, end_array):
-        """Not supported as a dense-matrix call: frames are gathered from the resident band on the
-        device (use extract).  Kept so that callers get a clear error rather than a silent CPU path."""
-        raise NotImplementedError('stripenn_amd runs StripeSearch on the device from the resident band; use extract()')
+        """getStripe.py:864-1114 on one dense frame matrix, as search_frame calls it (`submat` after its zero-column
+        removal, at most 400 x 400): the matrix is laid out as a one-frame diagonal band, uploaded, and sent through
+        the same device chain as extract() -- with the frame's columns kept as they are (no second zero-column
+        removal, no more-than-10-columns rule: those belong to search_frame, :812-821)."""
+        submat = np.asarray(submat, dtype=np.float64)
+        S = submat.shape[0]
+        if submat.ndim != 2 or submat.shape[1] != S or S < 1 or S > 400:
+            raise ValueError('StripeSearch: submat must be square and at most 400 x 400 (got %r)' % (submat.shape,))
+        hw = self.halfwidth
+        band = np.zeros((S, 2 * hw), dtype=np.float64)
+        rr = np.arange(S)[:, None]
+        cc = rr + np.arange(-hw, hw)[None, :]
+        ok = (cc >= 0) & (cc < S)
+        band[ok] = submat[np.broadcast_to(rr, cc.shape)[ok], cc[ok]]
+        hb = self.backend.open_chrom(band)
+        try:
+            fr = self.backend.frames(hb, np.array([0], np.int32), np.array([S - 1], np.int32), keep_all=True)
+            try:
+                recs = self.backend.stripe_search(fr, np.array([float(M)]), self.canny, self.minH, self.maxW,
+                                                  int(self.bfilter))
+                medpixel = float(fr.medpixel[0])
+            finally:
+                fr.close()
+        finally:
+            self.backend.close_chrom(hb)
+        sa, ea = np.asarray(start_array), np.asarray(end_array)
+        n = len(recs)
+        x, y = recs['x'].astype(np.int64), recs['y'].astype(np.int64)
+        w, h = recs['w'].astype(np.int64), recs['h'].astype(np.int64)
+        total = recs['total']
+        with np.errstate(divide='ignore', invalid='ignore'):
+            mean = total / h / w
+        result = pd.DataFrame({'chr': [chr] * n, 'pos1': sa[x], 'pos2': ea[x + w - 1], 'chr2': [chr] * n, 'pos3': sa[y],
+                               'pos4': ea[y + h - 1], 'length': ea[y + h - 1] - sa[y] + 1,
+                               'width': ea[x + w - 1] - sa[x] + 1, 'total': total, 'Mean': mean,
+                               'maxpixel': [str(perc * 100) + '%'] * n, 'num': [num] * n, 'start': [start] * n,
+                               'end': [end] * n, 'x': x, 'y': y, 'h': h, 'w': w, 'medpixel': [medpixel] * n},
+                              columns=EXTRACT_COLUMNS)
+        return self.RemoveRedundant(result, 'size')
 
     # ------------------------------------------------------------------ redundancy filter
     def RemoveRedundant(self, df, by):

@@ -16,8 +16,8 @@ _ERRNAMES = {-1: 'STP_E_ARG', -2: 'STP_E_CAPACITY', -3: 'STP_E_HIP', -4: 'STP_E_
 
 EXPORTS = [
     'stp_version', 'stp_ctx_create', 'stp_ctx_destroy', 'stp_last_error', 'stp_ctx_set_stream',
-    'stp_ctx_synchronize', 'stp_band_upload', 'stp_band_pack', 'stp_band_download', 'stp_band_wrap_device', 'stp_band_free',
-    'stp_frames_create', 'stp_frames_info', 'stp_frames_free', 'stp_stripe_search', 'stp_dbg_stages',
+    'stp_ctx_synchronize', 'stp_band_upload', 'stp_band_pack', 'stp_band_nearest', 'stp_band_download', 'stp_band_wrap_device', 'stp_band_free',
+    'stp_frames_create', 'stp_frames_create_ex', 'stp_frames_info', 'stp_frames_free', 'stp_stripe_search', 'stp_dbg_stages',
     'stp_set_profiling', 'stp_get_stats', 'stp_reset_stats',
 ]
 
@@ -70,9 +70,11 @@ def load():
     L.stp_band_wrap_device.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.stp_band_pack.argtypes = [vp, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.stp_band_download.argtypes = [vp, vp, vp]
+    L.stp_band_nearest.argtypes = [vp, vp, vp, vp]
     L.stp_band_free.argtypes = [vp, vp]
     L.stp_band_free.restype = None
     L.stp_frames_create.argtypes = [vp, vp, vp, vp, C.c_int32, C.POINTER(vp)]
+    L.stp_frames_create_ex.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.stp_frames_info.argtypes = [vp, vp, vp, vp, vp]
     L.stp_frames_free.argtypes = [vp, vp]
     L.stp_frames_free.restype = None
@@ -85,12 +87,32 @@ def load():
     return L
 
 
+# Half-kernels (outermost tap first, centre last) of the two sigmas the reference's drivers use (compute: --canny 2.0,
+# stripenn.py / cli.py:13; score: canny 2.5, score.py:46), exactly as scipy 1.7.1's _gaussian_kernel1d produces them under
+# numpy 1.26.4 -- the environment that pins the oracle and generated tests/golden (gw_2p0 / gw_2p5).  numpy's exp
+# changed its last-bit rounding between 1.26 and 2.2 (four taps of each kernel move by 1-2 ulp), which is enough to
+# flip a float rounding in the smoothed image, so these two are constants; any other sigma is computed below with
+# the numpy in use, as scipy would.
+_PINNED_HALF = {
+    2.0: ['0x1.18aad19e4159bp-14', '0x1.c98b8c5d0dda5p-12', '0x1.227362b5fc92ep-9', '0x1.1f30504e20207p-7',
+          '0x1.ba4d4125ffd29p-6', '0x1.0941b71ceef37p-4', '0x1.ef9093fc46e5ap-4', '0x1.68856f9ab1982p-3',
+          '0x1.98862a07ae7b4p-3'],
+    2.5: ['0x1.c11200a02c7e7p-15', '0x1.00a8053ff8116p-12', '0x1.f3fdc844de712p-11', '0x1.9f01e699060cep-9',
+          '0x1.2589592bde2b1p-7', '0x1.61d7f2f8c51c0p-6', '0x1.6b795631f5881p-5', '0x1.3e29751c76d89p-4',
+          '0x1.daa44ff00cffdp-4', '0x1.2db1ab5af48bbp-3', '0x1.46d23c3645548p-3'],
+}
+
+
 def gauss_weights(sigma, truncate=4.0):
-    """Weights scipy.ndimage.gaussian_filter1d builds for skimage's canny(sigma): the host computes
-    them with numpy exactly as scipy does (same calls, same order) and hands them to the kernels, so
-    the numpy build in use decides their last bit just as it does for the reference."""
+    """Weights scipy.ndimage.gaussian_filter1d builds for skimage's canny(sigma) (scipy _gaussian_kernel1d, called
+    from getStripe.py:917 through skimage): pinned constants for sigma 2.0 / 2.5 (see _PINNED_HALF); otherwise the
+    host computes them with numpy exactly as scipy does (same calls, same order), so the numpy build in use decides
+    their last bit just as it would for the reference."""
     sd = float(sigma)
     lw = int(truncate * sd + 0.5)
+    if truncate == 4.0 and sd in _PINNED_HALF:
+        half = [float.fromhex(h) for h in _PINNED_HALF[sd]]
+        return np.ascontiguousarray(np.array(half + half[-2::-1], dtype=np.float64)), lw
     x = np.arange(-lw, lw + 1)
     phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
     phi = phi / phi.sum()
@@ -196,6 +218,14 @@ class Band:
         self.ctx._chk(self.ctx.L.stp_band_download(self.ctx.h, self.h, _ptr(out)))
         return out
 
+    def nearest(self):
+        """(right, left) int32 arrays of a packed band: distance to the nearest positive stored pixel of each row
+        (stp_band_nearest); raises StripennHipError(STP_E_UNSUPPORTED) for uploaded / wrapped bands."""
+        r = np.empty(self.nrows, np.int32)
+        l = np.empty(self.nrows, np.int32)
+        self.ctx._chk(self.ctx.L.stp_band_nearest(self.ctx.h, self.h, _ptr(r), _ptr(l)))
+        return r, l
+
     def close(self):
         if getattr(self, 'h', None) and self.ctx.h:
             self.ctx.L.stp_band_free(self.ctx.h, self.h)
@@ -207,18 +237,19 @@ class Band:
         except Exception:
             pass
 
-    def frames(self, start, end):
-        return Frames(self, start, end)
+    def frames(self, start, end, keep_all=False):
+        return Frames(self, start, end, keep_all)
 
 
 class Frames:
-    def __init__(self, band, start, end):
+    def __init__(self, band, start, end, keep_all=False):
         self.band, self.ctx = band, band.ctx
         self.start = np.ascontiguousarray(start, dtype=np.int32)
         self.end = np.ascontiguousarray(end, dtype=np.int32)
         self.n = len(self.start)
         h = C.c_void_p()
-        self.ctx._chk(self.ctx.L.stp_frames_create(self.ctx.h, band.h, _ptr(self.start), _ptr(self.end), self.n, C.byref(h)))
+        self.ctx._chk(self.ctx.L.stp_frames_create_ex(self.ctx.h, band.h, _ptr(self.start), _ptr(self.end), self.n,
+                                                      1 if keep_all else 0, C.byref(h)))
         self.h = h
         self.S = np.zeros(self.n, np.int32)
         self.nz = np.zeros((self.n, STP_FRAME_MAX), np.int16)

@@ -4,16 +4,37 @@ A .cool file is three tables (cooler schema v3): ``bins`` (chrom, start, end, on
 vector), ``pixels`` (bin1_id <= bin2_id, count; sorted by (bin1_id, bin2_id)) and ``indexes``
 (chrom_offset).  ``cooler.Cooler(...).matrix(balance=name).fetch(...)`` -- the only way the reference
 reads it (stripenn.py:80-118, getStripe.py .fetch sites) -- turns a rectangle of that table into a dense
-array: value = count * w[bin1] * w[bin2] (NaN where a weight is NaN), mirrored below the diagonal, 0 where
-no pixel is stored.  ``PixelTable`` holds the same arrays; ``PixelSelector.fetch`` is that dense read
+array: the count block times np.outer(bias1, bias2), i.e. value = count * (b[bin1] * b[bin2]) with b = w for a
+multiplicative column ("weight") and b = 1 / w for the divisive ones cooler knows by name (KR, VC, SQRT_VC:
+the columns hic2cool writes; `--norm KR` is the reference CLI's default), NaN where a weight is NaN, mirrored
+below the diagonal, 0 where no pixel is stored.  ``PixelTable`` holds the same arrays; ``PixelSelector.fetch`` is that dense read
 on the host, and ``chrom_pixels`` hands the cis pixels of one chromosome to the HIP band packer
 (``stp_band_pack``), which builds the resident diagonal band without any dense intermediate.
 
 cooler is absent from the build image (parity of this reader against cooler itself is unpinned); the
-arithmetic above is cooler's documented balancing rule.  Tables travel as .npz (``save`` / ``load``); a
+arithmetic above restates cooler's `matrix()` dense branch (`arr * np.outer(bias1, bias2)`, `bias = 1 / bias`
+under `divisive_weights`, which defaults to `balance in {"KR", "VC", "SQRT_VC"}`).  Tables travel as .npz (``save`` / ``load``); a
 .cool / .mcool group is read through h5py when it is importable.
 """
 import numpy as np
+
+DIVISIVE_WEIGHTS = ('KR', 'VC', 'SQRT_VC')       # cooler's _4DN_DIVISIVE_WEIGHTS
+
+
+def _int32_counts(count):
+    """pixels/count as the int32 column the C ABI takes.  Float or wide-integer columns are accepted when every
+    value is an integer that fits; anything else (cooler files written with --count-as-float, merged or scaled
+    coolers) is refused rather than silently truncated."""
+    c = np.asarray(count)
+    if c.dtype == np.int32:
+        return np.ascontiguousarray(c)
+    if c.size:
+        if c.dtype.kind == 'f' and not np.all(np.isfinite(c) & (c == np.floor(c))):
+            raise ValueError('pixels/count holds non-integer values (a float-count cooler); this build packs int32 '
+                             'counts only -- refusing to truncate them')
+        if c.min() < -2**31 or c.max() > 2**31 - 1:
+            raise ValueError('pixels/count does not fit int32 (max %r)' % c.max())
+    return np.ascontiguousarray(c, dtype=np.int32)
 
 
 class PixelTable:
@@ -24,7 +45,7 @@ class PixelTable:
         self.chrom_offset = np.asarray(chrom_offset, dtype=np.int64)          # len(chromnames) + 1
         self.bin1_id = np.ascontiguousarray(bin1_id, dtype=np.int64)
         self.bin2_id = np.ascontiguousarray(bin2_id, dtype=np.int64)
-        self.count = np.ascontiguousarray(count, dtype=np.int32)
+        self.count = _int32_counts(count)
         self.weights = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in (weights or {}).items()}
         if len(self.chrom_offset) != len(self.chromnames) + 1:
             raise ValueError('chrom_offset must have one entry per chromosome plus one')
@@ -41,14 +62,22 @@ class PixelTable:
         k = self.chrom_index(chrom)
         return int(self.chrom_offset[k]), int(self.chrom_offset[k + 1])
 
-    def weight(self, balance):
-        """balance: False / None / 'NONE' -> raw counts; True -> 'weight'; a name -> that column."""
+    def weight(self, balance, divisive=None):
+        """The multiplicative bias vector of a balancing column.  balance: False / None / 'NONE' -> None (raw
+        counts); True -> 'weight'; a name -> that column.  divisive: None -> cooler's rule (KR, VC, SQRT_VC are
+        divisive: bias = 1 / w); True / False overrides it."""
         if balance in (False, None, 'NONE'):
             return None
         name = 'weight' if balance is True else str(balance)
         if name not in self.weights:
             raise ValueError('no balancing column %r in the pixel table' % name)
-        return self.weights[name]
+        if divisive is None:
+            divisive = name in DIVISIVE_WEIGHTS
+        w = self.weights[name]
+        if divisive:
+            with np.errstate(divide='ignore', invalid='ignore'):
+                return 1.0 / w
+        return w
 
     def rows_slice(self, g0, g1):
         """Index range of the pixels whose bin1_id lies in [g0, g1) (global bin ids)."""
@@ -122,10 +151,11 @@ class PixelTable:
 
 
 def pixel_values(count, weight, bin1, bin2):
-    """cooler's balanced value of each stored pixel: (count * w[bin1]) * w[bin2]; raw counts when weight is None."""
+    """cooler's balanced value of each stored pixel: count * (b[bin1] * b[bin2]) (`arr * np.outer(bias1, bias2)`),
+    b being the multiplicative bias (PixelTable.weight); raw counts when weight is None."""
     v = count.astype(np.float64)
     if weight is not None:
-        v = (v * weight[bin1]) * weight[bin2]
+        v = v * (weight[bin1] * weight[bin2])
     return v
 
 
@@ -133,10 +163,10 @@ class PixelSelector:
     """``cooler.Cooler(...).matrix(balance=...)`` over a PixelTable: ``fetch(region[, region2])`` with cooler's
     extent rule (0-based half-open bp intervals; bins lo = start // binsize, hi = ceil(end / binsize))."""
 
-    def __init__(self, table, balance=True):
+    def __init__(self, table, balance=True, divisive=None):
         self.table = table
         self.balance = balance
-        self.w = table.weight(balance)
+        self.w = table.weight(balance, divisive)         # multiplicative bias (1 / w for KR, VC, SQRT_VC)
         self.resol = table.binsize
         self.nfetch = 0
         self._nonneg = None          # no negative count / weight anywhere: row sums are zero iff all pixels are
@@ -168,6 +198,15 @@ class PixelSelector:
             raise ValueError('trans fetch is not on the stripenn path')
         lo, _ = self.table.chrom_bins(n1)
         return self._dense(r0 + lo, r1 + lo, c0 + lo, c1 + lo)
+
+    def nonnegative(self):
+        """No negative count / bias anywhere: a row's sum is zero iff it holds no positive pixel."""
+        if self._nonneg is None:
+            t = self.table
+            with np.errstate(invalid='ignore'):
+                self._nonneg = bool((len(t.count) == 0 or t.count.min() >= 0) and
+                                    (self.w is None or not np.any(self.w < 0)))
+        return self._nonneg
 
     def _positive(self):
         """value > 0 for every stored pixel (NaN from a masked bin compares False): one byte per pixel, formed once
@@ -201,11 +240,7 @@ class PixelSelector:
         if n1 != n2:
             raise ValueError('trans fetch is not on the stripenn path')
         t = self.table
-        if self._nonneg is None:
-            with np.errstate(invalid='ignore'):
-                self._nonneg = bool((len(t.count) == 0 or t.count.min() >= 0) and
-                                    (self.w is None or not np.any(self.w < 0)))
-        if not self._nonneg:
+        if not self.nonnegative():
             return None
         lo, _ = t.chrom_bins(n1)
         R0, R1, C0, C1 = r0 + lo, r1 + lo, c0 + lo, c1 + lo

@@ -9,7 +9,21 @@ from .io import open_matrix
 from .stripenn import resolve_norm
 
 
-def getScore(cool, coordinates, norm, numcores, seed, out, mask='0', device=0, backend=None):
+def _halfwidth_for(table, resol):
+    """Band halfwidth that holds every pixel the p-value / Stripiness / mean kernels read for these stripes: a
+    stripe's rows against its columns widened by the 50 kb flanks (user tables may hold stripes far longer than
+    the 400-bin frames `compute` produces).  None: the default is enough."""
+    if len(table) == 0:
+        return None
+    bs = int(50000 / resol)
+    p = [np.trunc(np.asarray(table[k], dtype=np.float64)).astype(np.int64) // resol for k in ('pos1', 'pos2', 'pos3', 'pos4')]
+    reach = int(max(np.abs(p[1] + bs + 1 - p[2]).max(), np.abs(p[3] + 1 - (p[0] - bs)).max(),
+                    np.abs(p[0] - bs - p[2]).max(), np.abs(p[3] - p[1] - bs).max()))
+    need = -(-(reach + 2 * bs + 2) // 64) * 64
+    return need if need > getStripe.HALFWIDTH else None
+
+
+def getScore(cool, coordinates, norm, numcores, seed, out, mask='0', device=0, backend=None, halfwidth=None):
     bfilter = 1
     print('Run score function')
     table = pd.read_csv(coordinates, header=None, sep='\t')
@@ -30,8 +44,10 @@ def getScore(cool, coordinates, norm, numcores, seed, out, mask='0', device=0, b
     all_chromsizes = all_chromsizes[big]
     unbalLib = Lib.matrix(balance=norm)
     resol = Lib._info['bin-size']
+    if halfwidth is None:
+        halfwidth = _halfwidth_for(table, resol)
     obj = getStripe.getStripe(unbalLib, resol, 10, 8, 2.5, all_chromnames, all_chromnames, all_chromsizes,
-                              all_chromsizes, numcores, bfilter, seed, backend=backend, device=device)
+                              all_chromsizes, numcores, bfilter, seed, backend=backend, device=device, halfwidth=halfwidth)
     EV = obj.mpmean()
     bg = obj.nulldist()
     pval = obj.pvalue(*bg, table)

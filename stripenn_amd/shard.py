@@ -79,9 +79,23 @@ class _Comm:
             dist.barrier()
 
 
+HALO = 2   # frames searched beyond each end of a rank's span (see sharded_compute)
+
+
 def sharded_compute(rank, world, cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, slow,
-                    bfilter, seed, force=True, backend_factory=None, write=True):
-    """Body of one rank.  Returns (result_table, res_filter) on rank 0, (None, None) elsewhere."""
+                    bfilter, seed, force=True, backend_factory=None, write=True, prepared=False):
+    """Body of one rank.  Returns (result_table, res_filter) on rank 0, (None, None) elsewhere.
+
+    Two static work queues, no collective on the data path (host objects only):
+      A. whole-chromosome steps -- maxpixel quantiles (stripenn.py:126-131), expected values (:132), background
+         pools / windows (:133) -- by LPT over chromosomes; their small results are all-gathered;
+      B. the (chromosome x frame) grid of step 4 / 5 (:134-147) in contiguous spans of equal frame count
+         (frame_spans).  RemoveRedundant only ever compares rows of frames n and n + 1 and collects deletions
+         without applying them (getStripe.py:1116-1161), and the path runs it three times in a row (per frame,
+         per chromosome 'size', whole table 'pvalue'), so a rank searches HALO = 2 extra frames on each side of
+         its span: the verdict on every row of its own frames then equals the single-process one, and the halo
+         rows are dropped before Stripiness.
+    prepared=True: the output directory and log were written by the launcher (launch_compute)."""
     from . import getStripe
     from .io import open_matrix
     from .stripenn import (RESULT_COLUMNS, addlog, finish_tables, makeOutDir, resolve_norm, select_chromosomes)
@@ -89,52 +103,92 @@ def sharded_compute(rank, world, cool, out, norm, chrom, canny, minL, maxW, maxp
     comm = _Comm(rank, world)
     if out[-1] != '/':
         out += '/'
-    if rank == 0 and write:
+    if rank == 0 and write and not prepared:
         makeOutDir(out, force)
         addlog(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, bfilter)
     levels = list(map(float, maxpixel.split(',')))
     Lib = open_matrix(cool)
     normv = resolve_norm(Lib, norm)
     all_names, all_sizes, names, sizes = select_chromosomes(Lib, chrom)
+    names = [str(n) for n in names]
     resol = Lib.binsize
-    mine = lpt_assign(chrom_costs(sizes, resol), world)[rank]
-    my_names = [names[i] for i in mine]
-    my_sizes = np.asarray(sizes)[mine] if len(mine) else np.zeros(0, dtype=np.int64)
+    sel = Lib.matrix(balance=normv)
     backend = backend_factory(rank) if backend_factory is not None else None
-    obj = getStripe.getStripe(Lib.matrix(balance=normv), resol, minL, maxW, canny, all_names, my_names, all_sizes,
-                              my_sizes, numcores, bfilter, seed, backend=backend, device=rank)
     t0 = time.time()
-    MP = (obj.getQuantile_slow if slow else obj.getQuantile_original)(Lib, my_names, levels) if my_names else {}
-    EV = obj.mpmean()
-    # --- background tables: per-chromosome parts are independent when numcores > 1 (the PRNG restarts
-    # per chromosome); with numcores == 1 the stream runs on across chromosomes, so rank 0 does them all.
-    if numcores == 1:
-        bg = obj.nulldist() if rank == 0 else None
-        bg = comm.allgather(bg)[0]
-    else:
-        cand = obj.null_candidates()
-        share = [i for i in range(len(cand)) if i % world == rank]
-        avail = dict(sum(comm.allgather([(i, obj.null_available_cols(cand[i])) for i in share]), []))
-        cand2, samplesize = obj.null_samplesizes(cand, [avail[i] for i in range(len(cand))])
-        share2 = [c for k, c in enumerate(cand2) if k % world == rank]
-        parts = dict(sum(comm.allgather([(c, obj.null_tables(c, cand2, samplesize)) for c in share2]), []))
-        bg = obj.null_concat([parts[c] for c in cand2])
-    # --- candidate stripes, p-values, Stripiness of this rank's chromosomes
+
+    # ---- A: whole-chromosome steps
+    mineA = lpt_assign(chrom_costs(sizes, resol), world)[rank]
+    namesA = [names[i] for i in mineA]
+    sizesA = np.asarray(sizes)[mineA] if len(mineA) else np.zeros(0, dtype=np.int64)
+    objA = getStripe.getStripe(sel, resol, minL, maxW, canny, all_names, namesA, all_sizes, sizesA, numcores, bfilter, seed,
+                               backend=backend, device=rank)
+    MPa = (objA.getQuantile_slow if slow else objA.getQuantile_original)(Lib, namesA, levels) if namesA else {}
+    EVa = objA.mpmean()
+    MP, EV = {}, {}
+    for mp_part, ev_part in comm.allgather((MPa, EVa)):
+        MP.update(mp_part)
+        EV.update(ev_part)
+    # background: sample sizes need every candidate chromosome's pools; a chromosome's pools and windows are
+    # computed where its band lives.  numcores > 1: the PRNG restarts per chromosome (loky pickles `self`);
+    # numcores == 1: one stream runs on across chromosomes, so every rank replays all draws (a few thousand
+    # random() calls) and forms the windows of its own chromosomes only.
+    cand = objA.null_candidates()
+    owner = {names[i]: r for r, part in enumerate(lpt_assign(chrom_costs(sizes, resol), world)) for i in part}
+    extra = [c for c in cand if c not in owner]                   # sampled, but not among the --chrom selection
+    owner.update({c: k % world for k, c in enumerate(extra)})
+    share = [c for c in cand if owner[c] == rank]
+    avail = {}
+    for part in comm.allgather({c: objA.null_available_cols(c) for c in share}):
+        avail.update(part)
+    cand2, samplesize = objA.null_samplesizes(cand, [avail[c] for c in cand])
+    pools = {}
+    for part in comm.allgather({c: objA.null_pools(c) for c in share if c in cand2} if numcores == 1 else {}):
+        pools.update(part)
+    parts = {}
+    for c in cand2:
+        mine = c in share
+        if numcores == 1 or mine:
+            r = objA.null_tables(c, cand2, samplesize, pools=pools.get(c), windows=mine)
+            if mine:
+                parts[c] = r
+    allparts = {}
+    for part in comm.allgather(parts):
+        allparts.update(part)
+    bg = objA.null_concat([allparts[c] for c in cand2])
+
+    # ---- B: candidate stripes, p-values, redundancy filters, Stripiness of this rank's frame span
+    nfr = chrom_nframes(sizes, resol)
+    spans = frame_spans(nfr, world)[rank]
+    own = {names[ci]: (lo, hi) for ci, lo, hi in spans}
+    search = {names[ci]: (max(0, lo - HALO), min(nfr[ci], hi + HALO)) for ci, lo, hi in spans}
+    namesB = [names[ci] for ci, _, _ in spans]
+    sizesB = np.asarray(sizes)[[ci for ci, _, _ in spans]] if spans else np.zeros(0, dtype=np.int64)
+    objB = getStripe.getStripe(sel, resol, minL, maxW, canny, all_names, namesB, all_sizes, sizesB, numcores, bfilter, seed,
+                               backend=objA.backend, frame_span=search)
+    for c in list(objA._bands):                  # whole bands phase A built are reused; the others are freed
+        if c in search and c not in objA._partial:
+            objB._bands[c] = objA._bands.pop(c)
+    objA.release()
     table = pd.DataFrame(columns=RESULT_COLUMNS)
-    if my_names:
-        for i, perc in enumerate(levels):
-            table = pd.concat([table, obj.extract(MP, i, perc, *bg)])
-        table = obj.RemoveRedundant(df=table, by='pvalue')
-        s = obj.scoringstripes(table, EV, mask)[0]
-    else:
-        s = []
+    s = []
+    if namesB:
+        tabs = [objB.extract(MP, i, perc, *bg) for i, perc in enumerate(levels)]
+        tabs = [t for t in tabs if len(t)]
+        if tabs:
+            table = pd.concat(tabs)
+            table = objB.RemoveRedundant(df=table, by='pvalue')
+            lo = np.array([own[str(c)][0] for c in table['chr']], dtype=np.int64)
+            hi = np.array([own[str(c)][1] for c in table['chr']], dtype=np.int64)
+            num = np.asarray(table['num'], dtype=np.int64)
+            table = table.iloc[np.nonzero((num >= lo) & (num < hi))[0]]          # drop the halo frames
+            s = objB.scoringstripes(table, EV, mask)[0]
     table = table.copy()
     table.insert(table.shape[1], '_stripiness', list(s), True)
     elapsed = time.time() - t0
     gathered = comm.allgather((rank, table, elapsed))
     result = (None, None)
     if rank == 0:
-        merged = pd.concat([g[1] for g in sorted(gathered, key=lambda g: g[0])])
+        merged = pd.concat([g[1] for g in sorted(gathered, key=lambda g: g[0]) if len(g[1])] or [gathered[0][1]])
         lev_idx = {str(p * 100) + '%': i for i, p in enumerate(levels)}
         chr_idx = {str(n): i for i, n in enumerate(names)}
         key = [lev_idx[str(m)] * (len(names) + 1) + chr_idx[str(c)] for m, c in zip(merged['maxpixel'], merged['chr'])]
@@ -151,7 +205,7 @@ def sharded_compute(rank, world, cool, out, norm, chrom, canny, minL, maxW, maxp
                     f.write('rank %d: %.2f s\n' % (g[0], g[2]))
         result = (result_table, res_filter)
     if backend is None:
-        obj.backend.close()
+        objB.backend.close()
     comm.barrier()
     return result
 
@@ -163,19 +217,26 @@ def _worker(rank, world, port, args):
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     dist.init_process_group('gloo', rank=rank, world_size=world)   # host objects only
     try:
-        sharded_compute(rank, world, *args)
+        sharded_compute(rank, world, *args, prepared=True)
     finally:
         dist.destroy_process_group()
 
 
 def launch_compute(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, slow, bfilter, seed, force,
                    gpus):
-    """One process per GPU (torch.multiprocessing spawn); rank r drives HIP device r."""
+    """One process per GPU (torch.multiprocessing spawn); rank r drives HIP device r.  The output directory is
+    prepared HERE, in the parent, before any process is spawned: the reference's overwrite prompt
+    (stripenn.py:12-42) needs the terminal's stdin, which spawned ranks do not have."""
     import socket
     import torch.multiprocessing as mp
+    from .stripenn import addlog, makeOutDir
+    if out[-1] != '/':
+        out += '/'
+    makeOutDir(out, force)
+    addlog(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, bfilter)
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    args = (cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, slow, bfilter, seed, force)
+    args = (cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, slow, bfilter, seed, True)
     mp.spawn(_worker, args=(gpus, port, args), nprocs=gpus, join=True)
     return 0

@@ -130,6 +130,8 @@ def compute(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalu
     if out[-1] != '/':
         out += '/'
     if gpus > 1:
+        if device not in (0, None):
+            raise ValueError('--device selects the GPU of a single-GPU run; with --gpus %d rank r drives device r' % gpus)
         from . import shard
         return shard.launch_compute(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, slow,
                                     bfilter, seed, force, gpus)
@@ -157,11 +159,12 @@ def compute(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalu
     print('3. Background distribution estimation ...')
     bgleft_up, bgright_up, bgleft_down, bgright_down = obj.nulldist()
     print('4. Finding candidate stripes from each chromosome ...')
-    result_table = pd.DataFrame(columns=RESULT_COLUMNS)
+    levels = []
     for i in range(len(maxpixel)):
         perc = maxpixel[i]
-        result = obj.extract(MP, i, perc, bgleft_up, bgright_up, bgleft_down, bgright_down)
-        result_table = pd.concat([result_table, result])
+        levels.append(obj.extract(MP, i, perc, bgleft_up, bgright_up, bgleft_down, bgright_down))
+    levels = [t for t in levels if len(t)]                    # (one concat; empty levels carry no dtypes)
+    result_table = pd.concat(levels) if levels else pd.DataFrame(columns=RESULT_COLUMNS)
     result_table = obj.RemoveRedundant(df=result_table, by='pvalue')
     print('5. Stripiness calculation ...')
     s = obj.scoringstripes(result_table, EV, mask)[0]

@@ -25,7 +25,7 @@ class _Band:
 
 
 class _Frames:
-    def __init__(self, band, starts, ends):
+    def __init__(self, band, starts, ends, keep_all=False):
         self.band = band
         self.n = len(starts)
         self.S = np.zeros(self.n, np.int32)
@@ -34,7 +34,9 @@ class _Frames:
         self.D = []
         for f in range(self.n):
             D, nz = O.frame_dense(band.block, int(starts[f]), int(ends[f]))
-            if len(nz) > 10:
+            if keep_all:
+                nz = np.arange(D.shape[0])
+            if keep_all or len(nz) > 10:
                 self.S[f] = len(nz)
                 self.nz[f, :len(nz)] = nz
                 Dc = np.ascontiguousarray(D[np.ix_(nz, nz)])
@@ -58,13 +60,18 @@ class OracleBackend:
         return _Band(band_host)
 
     def pack_chrom(self, px, hw):
-        return _Band(O.band_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], hw))
+        b = _Band(O.band_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], hw))
+        b.near = O.nearest_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'])
+        return b
 
     def close_chrom(self, band):
         pass
 
-    def frames(self, band, starts, ends):
-        return _Frames(band, starts, ends)
+    def frames(self, band, starts, ends, keep_all=False):
+        return _Frames(band, starts, ends, keep_all)
+
+    def band_nearest(self, band):
+        return getattr(band, 'near', None)
 
     def stripe_search(self, frames, M_levels, sigma, minH, maxW, bfilter):
         out = []
@@ -133,7 +140,7 @@ class OracleBackend:
         v = np.asarray(count).astype(np.float64)
         if weight is not None:
             w = np.asarray(weight, np.float64)
-            v = (v * w[np.asarray(bin1)]) * w[np.asarray(bin2)]
+            v = v * (w[np.asarray(bin1)] * w[np.asarray(bin2)])
         off = np.asarray(bin1) != np.asarray(bin2)
         v = np.concatenate([v, v[off]])
         sel.append(v[v > 0])

@@ -20,7 +20,7 @@ def _factory(rank):
     return OracleBackend()
 
 
-def run(rank, world, port, outdir):
+def run(rank, world, port, outdir, numcores=2):
     warnings.filterwarnings('ignore')
     import torch.distributed as dist
     from stripenn_amd import shard
@@ -28,9 +28,9 @@ def run(rank, world, port, outdir):
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(port)
         dist.init_process_group('gloo', rank=rank, world_size=world)
-    a = ARGS
+    a = dict(ARGS, numcores=numcores)
     sys.stdout = open(os.devnull, 'w')
-    res = shard.sharded_compute(rank, world, COOL, os.path.join(outdir, 'w%d' % world), a['norm'], a['chrom'], a['canny'],
+    res = shard.sharded_compute(rank, world, COOL, os.path.join(outdir, 'w%d_c%d' % (world, numcores)), a['norm'], a['chrom'], a['canny'],
                                 a['minL'], a['maxW'], a['maxpixel'], a['numcores'], a['pvalue'], a['mask'], a['slow'],
                                 a['bfilter'], a['seed'], force=True, backend_factory=_factory, write=True)
     if world > 1:

@@ -16,7 +16,7 @@ def test_exports_match_header():
     assert len(declared) >= 20
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, 'declared in the header but not exported: %s' % missing
-    assert L.stp_version() == 2
+    assert L.stp_version() == 3
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -40,3 +40,16 @@ def test_product_never_imports_oracle():
             if f.endswith(('.py', '.hip', '.h', '.cpp')):
                 src = open(os.path.join(dp, f)).read()
                 assert 'oracle' not in src.replace('oracle backend', '').replace('the oracle', '').replace('oracle)', ''), f
+
+
+def test_product_gauss_weights_are_the_references(golden_stages):
+    """hip.gauss_weights() -- what the product hands to the kernels -- equals scipy 1.7.1's _gaussian_kernel1d
+    tables stored with the goldens (numpy 1.26.4) for the reference's two sigmas, whatever numpy runs here
+    (numpy 2.2's exp moves four taps of each kernel by 1-2 ulp; the two kernels are pinned constants)."""
+    import numpy as np
+    from stripenn_amd import hip
+    for sigma, key, r in ((2.0, 'gw_2p0', 8), (2.5, 'gw_2p5', 10)):
+        w, rad = hip.gauss_weights(sigma)
+        assert rad == r and w.dtype == np.float64 and np.array_equal(w, golden_stages[key])
+    w, rad = hip.gauss_weights(3.0)                     # other sigmas: scipy's recipe with the numpy in use
+    assert rad == 12 and len(w) == 25 and abs(w.sum() - 1.0) < 1e-15 and np.array_equal(w, w[::-1])

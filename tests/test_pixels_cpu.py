@@ -146,3 +146,46 @@ def test_row_nonzero_equals_dense_row_sums():
     # a table with a negative value cannot answer without the dense sum
     neg = pixels.PixelTable(['c'], [20 * RESOL], RESOL, [0, 20], [1, 2], [3, 4], [5, -5])
     assert pixels.PixelSelector(neg, False).row_nonzero('c') is None
+
+
+def test_divisive_and_multiplicative_columns_follow_coolers_rule():
+    """cooler's matrix(balance=name): bias = weights[name], `1 / bias` for the divisive columns it knows by name
+    (KR, VC, SQRT_VC -- what hic2cool writes; --norm KR is the reference CLI's default), then
+    `arr * np.outer(bias1, bias2)`.  Hand-computed on a 5-bin table with weights that are NOT exactly
+    representable products, so the multiplication order is visible in the last bit."""
+    rng = np.random.default_rng(3)
+    w = rng.uniform(0.3, 3.0, 5)
+    w[3] = np.nan
+    b1 = np.array([0, 0, 1, 1, 2, 3, 4]); b2 = np.array([0, 2, 1, 4, 2, 4, 4])
+    cn = np.array([7, 3, 11, 5, 2, 9, 13], dtype=np.int32)
+    t = pixels.PixelTable(['c'], [5 * RESOL], RESOL, [0, 5], b1, b2, cn, {'weight': w, 'KR': w, 'VC': w, 'SQRT_VC': w, 'VC_SQRT': w})
+    cnt = np.zeros((5, 5)); cnt[b1, b2] = cn; cnt[b2, b1] = cn
+    with np.errstate(invalid='ignore'):
+        mult = cnt * np.outer(w, w)
+        div = cnt * np.outer(1.0 / w, 1.0 / w)
+    mult[cnt == 0] = 0.0; div[cnt == 0] = 0.0
+    assert np.array_equal(pixels.PixelSelector(t, True).fetch('c'), mult, equal_nan=True)
+    assert np.array_equal(pixels.PixelSelector(t, 'weight').fetch('c'), mult, equal_nan=True)
+    assert np.array_equal(pixels.PixelSelector(t, 'VC_SQRT').fetch('c'), mult, equal_nan=True)    # not in cooler's divisive set
+    for name in ('KR', 'VC', 'SQRT_VC'):
+        got = pixels.PixelSelector(t, name).fetch('c')
+        assert np.array_equal(got, div, equal_nan=True), name
+        assert got[0, 2] == 3 * ((1.0 / w[0]) * (1.0 / w[2]))
+    assert np.array_equal(pixels.PixelSelector(t, 'KR', divisive=False).fetch('c'), mult, equal_nan=True)
+    # the band restatement and the selector agree on the divisive column too
+    sel = pixels.PixelSelector(t, 'KR')
+    px = sel.chrom_pixels('c')
+    band = O.band_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], 0, 5, 512)
+    for i in range(5):
+        for j in range(5):
+            assert (band[i, j - i + 512] == div[i, j]) or (np.isnan(div[i, j]) and np.isnan(band[i, j - i + 512]))
+
+
+def test_float_counts_are_refused_not_truncated():
+    b = np.array([0, 0, 1]); c = np.array([0, 1, 1])
+    ok = pixels.PixelTable(['c'], [2 * RESOL], RESOL, [0, 2], b, c, np.array([2.0, 5.0, 1.0]))
+    assert ok.count.dtype == np.int32 and ok.count.tolist() == [2, 5, 1]
+    with pytest.raises(ValueError, match='non-integer'):
+        pixels.PixelTable(['c'], [2 * RESOL], RESOL, [0, 2], b, c, np.array([2.0, 0.5, 1.0]))
+    with pytest.raises(ValueError, match='int32'):
+        pixels.PixelTable(['c'], [2 * RESOL], RESOL, [0, 2], b, c, np.array([2, 2**40, 1], dtype=np.int64))

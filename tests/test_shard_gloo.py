@@ -26,20 +26,68 @@ def test_lpt_balance_mm10():
         assert max(loads) / (sum(loads) / n) < 1.15     # whole-chromosome units: 1.14 at 8 GPUs (7.0x ideal speed-up)
 
 
-def test_world2_equals_world1(tmp_path):
+def test_frame_spans_balance_mm10():
+    """(chromosome x frame) work queue: contiguous spans, every frame exactly once, imbalance of one frame."""
+    mm10 = [195471971, 182113224, 160039680, 156508116, 151834684, 149736546, 145441459, 129401213, 124595110,
+            130694993, 122082543, 120129022, 120421639, 124902244, 104043685, 98207768, 94987271, 90702639, 61431566,
+            171031299]
+    nfr = shard.chrom_nframes(mm10, 5000)
+    assert sum(nfr) == 2645
+    for n in (1, 2, 3, 4, 8):
+        spans = shard.frame_spans(nfr, n)
+        seen = [[0] * k for k in nfr]
+        for sp in spans:
+            for ci, lo, hi in sp:
+                assert 0 <= lo < hi <= nfr[ci]
+                for f in range(lo, hi):
+                    seen[ci][f] += 1
+        assert all(v == 1 for row in seen for v in row)
+        loads = [sum(hi - lo for _, lo, hi in sp) for sp in spans]
+        assert max(loads) - min(loads) <= 1 and max(loads) / (sum(loads) / n) < 1.03
+
+
+def _spawn(world, out, numcores):
     import torch.multiprocessing as mp
     import shard_worker
-    out = str(tmp_path)
-    shard_worker.run(0, 1, 0, out)
-    sys.stdout = sys.__stdout__
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    mp.spawn(shard_worker.run, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(shard_worker.run, args=(world, port, out, numcores), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize('numcores,worlds', [(2, (2, 3)), (1, (2,))])
+def test_sharded_equals_single_process(tmp_path, numcores, worlds):
+    """world_size 2 / 3 over gloo (frame spans cut chr1 / chr2 in the middle: 7 + 5 + 4 frames) write the TSVs of
+    the single-process run byte for byte, in both PRNG modes of the background step (numcores 2: one stream per
+    chromosome; numcores 1: one stream across chromosomes, replayed by every rank)."""
+    import shard_worker
+    out = str(tmp_path)
+    shard_worker.run(0, 1, 0, out, numcores)
+    sys.stdout = sys.__stdout__
+    for world in worlds:
+        _spawn(world, out, numcores)
+        for name in ('result_unfiltered.tsv', 'result_filtered.tsv'):
+            a = open(os.path.join(out, 'w1_c%d' % numcores, name)).read()
+            b = open(os.path.join(out, 'w%d_c%d' % (world, numcores), name)).read()
+            assert len(a.splitlines()) > 10
+            assert a == b, (name, world)
+        log = open(os.path.join(out, 'w%d_c%d' % (world, numcores), 'stripenn.log')).read()
+        assert 'gpus: %d' % world in log and 'rank 1' in log
+
+
+def test_sharded_world1_equals_unsharded_driver(tmp_path):
+    """sharded_compute(world=1) and stripenn.compute are the same computation."""
+    import shard_worker
+    from oracle_backend import OracleBackend
+    from stripenn_amd import stripenn
+    out = str(tmp_path)
+    shard_worker.run(0, 1, 0, out, 2)
+    sys.stdout = sys.__stdout__
+    a = shard_worker.ARGS
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        stripenn.compute(shard_worker.COOL, os.path.join(out, 'plain'), a['norm'], a['chrom'], a['canny'], a['minL'], a['maxW'],
+                         a['maxpixel'], 2, a['pvalue'], a['mask'], a['slow'], a['bfilter'], a['seed'], force=True,
+                         backend=OracleBackend())
     for name in ('result_unfiltered.tsv', 'result_filtered.tsv'):
-        a = open(os.path.join(out, 'w1', name)).read()
-        b = open(os.path.join(out, 'w2', name)).read()
-        assert len(a.splitlines()) > 10
-        assert a == b, name
-    log = open(os.path.join(out, 'w2', 'stripenn.log')).read()
-    assert 'gpus: 2' in log and 'rank 1' in log
+        assert open(os.path.join(out, 'w1_c2', name)).read() == open(os.path.join(out, 'plain', name)).read()

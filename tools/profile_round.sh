@@ -25,3 +25,5 @@ timeout 400 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VAL
 timeout 400 rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY -d $OUT/${TAG}_pmc_SQ2 -o pmc -- python3 $B --steps $PSTEPS --warmup 0 --no-cpu-baseline --no-e2e > $OUT/${TAG}_pmc_SQ2.log 2>&1 || exit 1
 cd $R
 python3 tools/summarize_profile.py $TAG $WL
+# the raw traces are large (gpurun copies back at most 64 MiB): keep the summaries only
+rm -rf $OUT/${TAG}_kt $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_SQ $OUT/${TAG}_pmc_SQ2
