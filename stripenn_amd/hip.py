@@ -5,6 +5,8 @@ library is missing or no gfx950 device is usable, every entry point raises Strip
 """
 import ctypes as C
 import os
+import sys
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -132,6 +134,15 @@ class Context:
 
     def __init__(self, device=0):
         self.L = load()
+        # torch ships its own HIP runtime, which cannot initialise once ROCm's (ours) has opened the device:
+        # when the host program has torch loaded, let it initialise first (a no-op without torch)
+        t = sys.modules.get('torch')
+        if t is not None:
+            try:
+                if t.cuda.device_count() > 0:
+                    t.cuda.init()
+            except Exception:      # noqa: BLE001
+                pass
         h = C.c_void_p()
         rc = self.L.stp_ctx_create(int(device), C.byref(h))
         if rc != STP_OK:

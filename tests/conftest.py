@@ -8,6 +8,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_sessionstart(session):
+    """A GPU test process holds two HIP runtimes: ROCm's (linked by libstripenn_hip.so) and the one bundled with
+    torch (used for device-generated test data and torch.distributed).  torch's refuses to initialise after the
+    other one has opened the device, so it goes first.  (device_count() does not touch the GPU; on the CPU-only
+    build box it is 0 and nothing is initialised.)"""
+    try:
+        import torch
+        if torch.cuda.device_count() > 0:
+            torch.cuda.init()
+    except Exception:      # noqa: BLE001 -- CPU-only box, or torch absent: the CPU suite does not need it
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with gpurun / by the driver at round end)')
 
