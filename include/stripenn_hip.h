@@ -136,6 +136,11 @@ int stp_stripe_search(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
                       const double* M_levels /* nframes_levels: M for [level] */, int32_t n_levels,
                       stp_stripe_rec* out, int64_t out_capacity, int64_t* out_count);
 
+/* Parity tests: the sweep grants every image 128 record slots and re-runs a chunk of images with 400 slots (one
+ * per possible column pair) when some image needs more -- which no contact map has been seen to do.  This shrinks
+ * the first pass to `slots` (1..128) so that the re-run path executes on ordinary data; results must not change. */
+int stp_dbg_set_sweep_slots(stp_ctx* ctx, int32_t slots);
+
 /* ---- stage-level entry points (parity tests; same kernels as stp_stripe_search) ----------
  * All operate on ONE image: frame `f` of `fr`, level value M, brightness index bi.
  * Buffers are S x S row-major (S = S[f]).  Any output pointer may be NULL. */

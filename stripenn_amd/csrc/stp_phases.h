@@ -24,7 +24,8 @@ typedef unsigned long long stp_u64;
 
 #define STP_PITCH 400 /* pixel pitch of per-image buffers */
 #define STP_NW 7      /* u64 words per bit-row (448 >= 400) */
-#define STP_RCAP 128  /* record slots per image */
+#define STP_RCAP 128  /* record slots per image in the sweep */
+#define STP_RCAP_MAX 400  /* slots of the re-run: neighbouring X values pair at most once per direction -> < 400 records */
 
 // ---------------------------------------------------------------------------------------------
 // tile geometry

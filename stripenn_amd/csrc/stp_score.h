@@ -11,8 +11,8 @@
 #include "../../include/stripenn_hip.h"
 #include "stp_phases.h"
 
-#define STP_SCORE_MAXROWS 1024
-#define STP_SCORE_MAXCOLS 256
+#define STP_SCORE_MAXROWS 3072   /* LDS-bound: 4 x 8 B per row (k_pvalue), ~40 B per row (k_stripiness); 15 Mb at 5 kb */
+#define STP_SCORE_MAXCOLS 1024
 
 struct stp_bandref {
     const double* d;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(448) void k_diag_sums(stp_bandref B, double* __rest
 
 // ---------------------------------------------------------------------------------------------
 // getStripe.nulldist window means (getStripe.py:347-378).  mat = M[row0:row0+nrow, col0:col0+ncol]
-// with NaN -> 0; python slice semantics on mat's extents; np.mean order (needs bs*bs <= 8192).
+// with NaN -> 0; python slice semantics on mat's extents; np.mean order (8192-element buffers).
 
 // `dense` (may be null): the unit matrix itself, nrow x ncol row-major, NaN preserved.  It is supplied
 // by the host for batches in which a Python slice wraps around (negative start) and therefore reads
@@ -129,16 +129,21 @@ __device__ double null_block_mean(const stp_bandref& B, const double* __restrict
     const int64_t cnt = (rh - rl) * (ch - cl);
     double acc = 0.0;
     if (cnt > 0) {
-        // numpy buffers the strided slice (<= 8192 elements) and runs one pairwise loop over the
-        // row-major flattened block
+        // numpy buffers the strided slice 8192 elements at a time and runs one pairwise loop over each buffer of
+        // the row-major flattened block; the partial sums of a block larger than that (bs > 90) add up in order
         const int64_t w = ch - cl;
-        if (dense) {
-            const double* base = dense + rl * (int64_t)s.ncol + cl;
-            const int64_t nc = s.ncol;
-            acc = stp_pw<BIG>([&](int64_t k) { double v = base[(k / w) * nc + (k % w)]; return (v != v) ? 0.0 : v; }, 0, cnt, stk);
-        } else {
-            const int64_t gr0 = s.row0 + rl, gc0 = s.col0 + cl;
-            acc = stp_pw<BIG>([&](int64_t k) { return band_at0(B, gr0 + k / w, gc0 + k % w); }, 0, cnt, stk);
+        for (int64_t o = 0; o < cnt; o += 8192) {
+            const int64_t nn = cnt - o < 8192 ? cnt - o : 8192;
+            double part;
+            if (dense) {
+                const double* base = dense + rl * (int64_t)s.ncol + cl;
+                const int64_t nc = s.ncol;
+                part = stp_pw<BIG>([&](int64_t k) { double v = base[(k / w) * nc + (k % w)]; return (v != v) ? 0.0 : v; }, o, nn, stk);
+            } else {
+                const int64_t gr0 = s.row0 + rl, gc0 = s.col0 + cl;
+                part = stp_pw<BIG>([&](int64_t k) { return band_at0(B, gr0 + k / w, gc0 + k % w); }, o, nn, stk);
+            }
+            acc = (o == 0) ? part : acc + part;
         }
     }
     return acc / (double)cnt;

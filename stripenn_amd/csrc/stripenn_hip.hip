@@ -512,7 +512,8 @@ __device__ int lines_group_pairs_wave(int lane, int S, int ud, int maxW, int nro
 // testmat): after verticalLine the edge map is parked in global memory (escr, L2-resident) and re-read
 // one row per lane during refinement; the 3-column OR of `block` is formed on the fly.  53 KB of LDS
 // -> three workgroups per CU (this kernel is latency bound: serial scans, one-lane grouping).
-__global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ low, const stp_u64* __restrict__ high,
+template <int RCAP>   // record slots per image: STP_RCAP for the sweep, STP_RCAP_MAX (every possible pair) for the rare re-run
+__global__ __launch_bounds__(512, RCAP == STP_RCAP ? 6 : 4) void k_lines(const stp_u64* __restrict__ low, const stp_u64* __restrict__ high,
                                                 const double* __restrict__ band, int W, int hw,
                                                 const int32_t* __restrict__ fstart, const int32_t* __restrict__ fS,
                                                 const int16_t* __restrict__ fnz, int f0, int imgs_per_frame,
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
     __shared__ int16_t colEnd[STP_FRAME_MAX], colUd[STP_FRAME_MAX];
     __shared__ int16_t cnt[STP_FRAME_MAX], minr[STP_FRAME_MAX], maxr[STP_FRAME_MAX];
     __shared__ int16_t cidx[STP_FRAME_MAX], clen[STP_FRAME_MAX], xs[STP_FRAME_MAX + 8];
-    __shared__ stp_lrec lrec[STP_RCAP];
+    __shared__ stp_lrec lrec[RCAP];
     __shared__ int s_nrec, s_nrow, s_wcnt[8];
     __shared__ stp_u64 s_seen[STP_NW];
     int16_t* colT = cidx;                              // block lengths: only copied out for the parity tests
@@ -614,16 +615,16 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
         __syncthreads();
         if (tid < 64 && dbg_stop != 6) {               // wave 0; the serial form only for > 64 candidate columns
             int nr;
-            if (s_nrow <= 64) nr = lines_group_pairs_wave(tid, S, ud, maxW, s_nrow, minr, maxr, cidx, clen, xs, s_seen, lrec, s_nrec, STP_RCAP);
-            else nr = (tid == 0) ? lines_group_pairs(S, ud, maxW, s_nrow, minr, maxr, cidx, clen, xs, lrec, s_nrec, STP_RCAP) : 0;
+            if (s_nrow <= 64) nr = lines_group_pairs_wave(tid, S, ud, maxW, s_nrow, minr, maxr, cidx, clen, xs, s_seen, lrec, s_nrec, RCAP);
+            else nr = (tid == 0) ? lines_group_pairs(S, ud, maxW, s_nrow, minr, maxr, cidx, clen, xs, lrec, s_nrec, RCAP) : 0;
             if (tid == 0) s_nrec = nr;
         }
         __syncthreads();
     }
     if (dbg_stop == 5 || dbg_stop == 6) { if (tid == 0) rec_count[img] = 0; return; }
     const int nrec = s_nrec;
-    const int nst = nrec < STP_RCAP ? nrec : STP_RCAP;
-    stp_drec* out = recs + (size_t)img * STP_RCAP;
+    const int nst = nrec < RCAP ? nrec : RCAP;
+    stp_drec* out = recs + (size_t)img * RCAP;
     const int64_t st = fstart[f];
     {   // totals (getStripe.py:1094): one record per wave at a time -- row sums by the 64 lanes into the wave's
         // own slice of the (now dead) bit matrices, then lane 0 adds the rows in order
@@ -656,7 +657,8 @@ __global__ __launch_bounds__(512, 6) void k_lines(const stp_u64* __restrict__ lo
 #define CR_IPB 64
 __global__ __launch_bounds__(1024) void k_compact_recs(const stp_drec* __restrict__ recs, const int32_t* __restrict__ cnt,
                                                         int nimg, int f0, int nlev, int nb, stp_stripe_rec* __restrict__ out,
-                                                        long long cap, long long* __restrict__ total_overflow)
+                                                        long long cap, long long* __restrict__ total_overflow, int rcap /* slot stride */,
+                                                        int slots /* slots an image may use: <= rcap */)
 {
     __shared__ int s_wsum[16], s_wover[16];
     __shared__ int s_cnt[CR_IPB], s_off[CR_IPB];
@@ -669,14 +671,14 @@ __global__ __launch_bounds__(1024) void k_compact_recs(const stp_drec* __restric
     const int lim = last ? nimg : i0;
     for (int i = tid; i < lim; i += 1024) {
         int c = cnt[i];
-        if (c > STP_RCAP) { c = STP_RCAP; over = 1; }
+        if (c > slots) { c = slots; over = 1; }
         if (i < i0) loc += c;
     }
     for (int o = 32; o > 0; o >>= 1) { loc += __shfl_xor(loc, o); over |= __shfl_xor(over, o); }
     if (lane == 0) { s_wsum[wv] = loc; s_wover[wv] = over; }
     if (tid < CR_IPB) {
         int c = (i0 + tid < nimg) ? cnt[i0 + tid] : 0;
-        s_cnt[tid] = c > STP_RCAP ? STP_RCAP : c;
+        s_cnt[tid] = c > slots ? slots : c;
     }
     __syncthreads();
     if (tid < 64) {                                   // one wave: base + exclusive scan of the 64 counts
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(1024) void k_compact_recs(const stp_drec* __restric
     for (int k = k0; k < c; k += 16) {
         const long long pos = pos0 + k;
         if (pos >= cap) continue;
-        const stp_drec d = recs[(size_t)i * STP_RCAP + k];
+        const stp_drec d = recs[(size_t)i * rcap + k];
         stp_stripe_rec r;
         r.frame = f0 + fl; r.level = lev; r.b_index = bi; r.ud = d.ud;
         r.x = d.x; r.y = d.y; r.w = d.w; r.h = d.h; r.total = d.total;
@@ -775,6 +777,7 @@ struct stp_ctx {
     std::vector<stp_kstat> stats;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<std::vector<double>, stp_fastdiv>> fd_cache;   // verified interior bleed-over divisions
+    int sweep_slots = STP_RCAP;            // record slots per image in the first pass (stp_dbg_set_sweep_slots)
 };
 
 struct stp_band {
@@ -1259,7 +1262,8 @@ static stp_fastdiv make_fastdiv(stp_ctx* ctx, const double* w, int R)
 // [f0, f0+nf) for n_levels levels; buffers sized by the caller.
 static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, int f0, int nf,
                      const double* d_M, int nlev, const double* d_b, const double* d_w, float* d_gray, stp_u64* d_low,
-                     stp_u64* d_high, stp_drec* d_recs, int32_t* d_cnt, int want_dbg, stp_u64* d_dbg, int16_t* d_dbgc)
+                     stp_u64* d_high, stp_drec* d_recs, int32_t* d_cnt, int want_dbg, stp_u64* d_dbg, int16_t* d_dbgc,
+                     int rcap = STP_RCAP)
 {
     void* p_edges = nullptr;     // parked edge maps of k_lines (one bit matrix per image)
     HIPCHK(ws_get(ctx, WS_EDGES, (size_t)nf * nlev * prm->n_bright * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), &p_edges));
@@ -1313,9 +1317,14 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         const int lines_stop = 0;          // the product library has no such switch
 #endif
         prof_scope ps(ctx, "lines", ipx * 9.0);          // stages C-F: 2 + 2 + 1 + 4 B per image px
-        hipLaunchKernelGGL(k_lines, dim3((unsigned)nimg), dim3(512), 0, ctx->stream, d_low, d_high, band->d, band->W,
-                           band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, ipf, prm->minH, prm->maxW, d_recs, d_cnt,
-                           (stp_u64*)p_edges, want_dbg, d_dbg, d_dbgc, lines_stop);
+        if (rcap == STP_RCAP)
+            hipLaunchKernelGGL(k_lines<STP_RCAP>, dim3((unsigned)nimg), dim3(512), 0, ctx->stream, d_low, d_high, band->d, band->W,
+                               band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, ipf, prm->minH, prm->maxW, d_recs, d_cnt,
+                               (stp_u64*)p_edges, want_dbg, d_dbg, d_dbgc, lines_stop);
+        else
+            hipLaunchKernelGGL(k_lines<STP_RCAP_MAX>, dim3((unsigned)nimg), dim3(512), 0, ctx->stream, d_low, d_high, band->d, band->W,
+                               band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, ipf, prm->minH, prm->maxW, d_recs, d_cnt,
+                               (stp_u64*)p_edges, want_dbg, d_dbg, d_dbgc, lines_stop);
     }
     HIPCHK(hipGetLastError());
     return STP_OK;
@@ -1356,45 +1365,65 @@ int stp_stripe_search(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
     long long* h_tot = (long long*)pin;
     stp_stripe_rec* h_out = (stp_stripe_rec*)((char*)pin + 64);
     int64_t total = 0;
-    bool overflow = false;
     for (int f0 = 0; f0 < fr->n; f0 += chunk) {
         const int nf = (fr->n - f0 < chunk) ? fr->n - f0 : chunk;
         const size_t nimg = (size_t)nf * ipf;
-        rc = run_chain(ctx, fr, prm, f0, nf, dM, n_levels, dB, dW, (float*)pGray, (stp_u64*)pLow, (stp_u64*)pHigh,
-                       (stp_drec*)pRecs, (int32_t*)pCnt, 0, nullptr, nullptr);
-        if (rc) return rc;
-        {
-            prof_scope ps(ctx, "compact_recs", (double)nimg * 4.0);
-            hipLaunchKernelGGL(k_compact_recs, dim3((unsigned)((nimg + CR_IPB - 1) / CR_IPB)), dim3(1024), 0, ctx->stream, (const stp_drec*)pRecs,
-                               (const int32_t*)pCnt, (int)nimg, f0, n_levels, nb, (stp_stripe_rec*)pOut, (long long)ocap,
-                               (long long*)pTot);
-        }
-        HIPCHK(hipGetLastError());
-        // one round trip in the common case: the count travels with as many records as the previous
-        // chunk of this context produced (+25 %); only a larger result needs a second copy
-        const size_t guess = std::min(ocap, (size_t)ctx->rec_guess);
-        HIPCHK(hipMemcpyAsync(h_tot, pTot, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-        if (guess) HIPCHK(hipMemcpyAsync(h_out, pOut, guess * sizeof(stp_stripe_rec), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        const long long n = h_tot[0];
-        if (h_tot[1]) overflow = true;
-        if ((size_t)n > ocap) return set_err(ctx, STP_E_CAPACITY, "record compaction overran its buffer");
-        ctx->rec_guess = n + n / 4 + 64;
-        if (n > 0) {
-            if ((size_t)n > guess) {
-                HIPCHK(hipMemcpyAsync(h_out + guess, (stp_stripe_rec*)pOut + guess, ((size_t)n - guess) * sizeof(stp_stripe_rec),
-                                      hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHK(hipStreamSynchronize(ctx->stream));
+        // the sweep gives every image STP_RCAP record slots; a chunk in which some image needs more (never seen on
+        // contact maps: > 128 accepted column pairs in one image) is run again with STP_RCAP_MAX slots -- two
+        // neighbouring X values can pair only once, so no image can fill more
+        for (int rcap = STP_RCAP;; rcap = STP_RCAP_MAX) {
+            const size_t ocap_r = cimg * (size_t)rcap;
+            if (rcap != STP_RCAP) {
+                HIPCHK(ws_get(ctx, WS_RECS, cimg * (size_t)rcap * sizeof(stp_drec), &pRecs));
+                HIPCHK(ws_get(ctx, WS_OUT, ocap_r * sizeof(stp_stripe_rec), &pOut));
+                HIPCHK(pin_get(ctx, ocap_r * sizeof(stp_stripe_rec) + 64, &pin));
+                h_tot = (long long*)pin;
+                h_out = (stp_stripe_rec*)((char*)pin + 64);
             }
-            for (long long k = 0; k < n; k++) {
-                if (total < cap) out[total] = h_out[k];
-                total++;
+            rc = run_chain(ctx, fr, prm, f0, nf, dM, n_levels, dB, dW, (float*)pGray, (stp_u64*)pLow, (stp_u64*)pHigh,
+                           (stp_drec*)pRecs, (int32_t*)pCnt, 0, nullptr, nullptr, rcap);
+            if (rc) return rc;
+            {
+                prof_scope ps(ctx, "compact_recs", (double)nimg * 4.0);
+                hipLaunchKernelGGL(k_compact_recs, dim3((unsigned)((nimg + CR_IPB - 1) / CR_IPB)), dim3(1024), 0, ctx->stream, (const stp_drec*)pRecs,
+                                   (const int32_t*)pCnt, (int)nimg, f0, n_levels, nb, (stp_stripe_rec*)pOut, (long long)ocap_r,
+                                   (long long*)pTot, rcap, rcap == STP_RCAP ? std::min(rcap, ctx->sweep_slots) : rcap);
             }
+            HIPCHK(hipGetLastError());
+            // one round trip in the common case: the count travels with as many records as the previous
+            // chunk of this context produced (+25 %); only a larger result needs a second copy
+            const size_t guess = std::min(ocap_r, (size_t)ctx->rec_guess);
+            HIPCHK(hipMemcpyAsync(h_tot, pTot, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+            if (guess) HIPCHK(hipMemcpyAsync(h_out, pOut, guess * sizeof(stp_stripe_rec), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            const long long n = h_tot[0];
+            if (h_tot[1] && rcap == STP_RCAP) continue;           // some image overflowed its slots: again, with all of them
+            if (h_tot[1]) return set_err(ctx, STP_E_CAPACITY, "an image produced more candidate stripes than pairs of columns exist");
+            if ((size_t)n > ocap_r) return set_err(ctx, STP_E_CAPACITY, "record compaction overran its buffer");
+            ctx->rec_guess = n + n / 4 + 64;
+            if (n > 0) {
+                if ((size_t)n > guess) {
+                    HIPCHK(hipMemcpyAsync(h_out + guess, (stp_stripe_rec*)pOut + guess, ((size_t)n - guess) * sizeof(stp_stripe_rec),
+                                          hipMemcpyDeviceToHost, ctx->stream));
+                    HIPCHK(hipStreamSynchronize(ctx->stream));
+                }
+                for (long long k = 0; k < n; k++) {
+                    if (total < cap) out[total] = h_out[k];
+                    total++;
+                }
+            }
+            break;
         }
     }
     *out_count = total;
-    if (overflow) return set_err(ctx, STP_E_CAPACITY, "an image produced more than 128 candidate stripes");
     if (total > cap) return set_err(ctx, STP_E_CAPACITY, "output capacity too small; out_count holds the needed size");
+    return STP_OK;
+}
+
+int stp_dbg_set_sweep_slots(stp_ctx* ctx, int32_t slots)
+{
+    if (!ctx || slots < 1 || slots > STP_RCAP) return STP_E_ARG;
+    ctx->sweep_slots = slots;
     return STP_OK;
 }
 
@@ -1425,7 +1454,7 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
     float* dGray = (float*)((char*)bGray.p + STP_GRAY_GUARD);
     HIPCHK(bLow.alloc(ctx, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
     HIPCHK(bHigh.alloc(ctx, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
-    HIPCHK(bRecs.alloc(ctx, nimg * STP_RCAP * sizeof(stp_drec)));
+    HIPCHK(bRecs.alloc(ctx, nimg * STP_RCAP_MAX * sizeof(stp_drec)));
     HIPCHK(bCnt.alloc(ctx, nimg * sizeof(int32_t)));
     HIPCHK(bDbg.alloc(ctx, nimg * 4 * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
     HIPCHK(bDbgc.alloc(ctx, nimg * 3 * STP_FRAME_MAX * sizeof(int16_t)));
@@ -1436,7 +1465,7 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
                           ctx->stream));
     rc = run_chain(ctx, fr, prm, f, 1, (const double*)bM.p, 1, (const double*)bB.p, (const double*)bW.p, dGray,
                    (stp_u64*)bLow.p, (stp_u64*)bHigh.p, (stp_drec*)bRecs.p, (int32_t*)bCnt.p, 1, (stp_u64*)bDbg.p,
-                   (int16_t*)bDbgc.p);
+                   (int16_t*)bDbgc.p, STP_RCAP_MAX);
     if (rc) return rc;
     const size_t BW = STP_FRAME_MAX * STP_NW;
     std::vector<float> hg((size_t)STP_PITCH * STP_PITCH);
@@ -1511,7 +1540,7 @@ int stp_null_windows(stp_ctx* ctx, const stp_band* band, const double* unit_matr
             if (samples[i].row0 != samples[0].row0 || samples[i].nrow != samples[0].nrow ||
                 samples[i].col0 != samples[0].col0 || samples[i].ncol != samples[0].ncol)
                 return set_err(ctx, STP_E_ARG, "with a unit matrix all samples of a call must share its geometry");
-    if (bs < 1 || bs * bs > 8192) return set_err(ctx, STP_E_UNSUPPORTED, "background size must satisfy bs*bs <= 8192");
+    if (bs < 1 || bs > 1000) return set_err(ctx, STP_E_ARG, "background window size must be in 1..1000 bins");
     for (int i = 0; i < n; i++) {
         const stp_null_sample& s = samples[i];
         if (s.nrow <= 0 || s.ncol <= 0 || s.row0 < 0 || s.col0 < 0 || s.row0 + s.nrow > band->nrows ||
@@ -1597,7 +1626,8 @@ static int check_rect(stp_ctx* ctx, const stp_band* band, int64_t i, int r0, int
     if (r0 < 0 || c0 < 0 || r1 > band->nrows || c1 > band->nrows || r1 <= r0 || c1 < c0)
         return set_err(ctx, STP_E_ARG, "stripe " + std::to_string(i) + ": region outside the chromosome");
     if (r1 - r0 > maxrows || c1 - c0 > maxcols)
-        return set_err(ctx, STP_E_UNSUPPORTED, "stripe " + std::to_string(i) + ": longer than 1024 bins or wider than 256 bins");
+        return set_err(ctx, STP_E_UNSUPPORTED, "stripe " + std::to_string(i) + ": longer than " + std::to_string(STP_SCORE_MAXROWS) +
+                       " bins or wider than " + std::to_string(STP_SCORE_MAXCOLS) + " bins");
     // every pixel must lie inside the stored band
     if ((int64_t)c1 - 1 - r0 >= band->hw || (int64_t)r1 - 1 - c0 > band->hw)
         return set_err(ctx, STP_E_ARG, "stripe " + std::to_string(i) + ": region leaves the +-halfwidth band; upload a wider band");
@@ -1631,6 +1661,10 @@ int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int
             hmax = std::max(hmax, (int)(st[i].row1 - st[i].row0));
         }
         const size_t lds = 4 * sizeof(double) * (size_t)hmax;
+        if (lds > 48 * 1024) {      // stripes beyond ~1500 rows: more dynamic LDS than the default launch limit
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pvalue<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pvalue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         if (!big)
             hipLaunchKernelGGL(k_pvalue<false>, dim3((unsigned)n), dim3(256), lds, ctx->stream, bref(band), (const double*)bg->sorted,
                                (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p, hmax);
@@ -1680,6 +1714,10 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
         const int HR = (hmax + 3) & ~3, CW = (wmax + 3) & ~3;     // keeps every sub-array 8-byte aligned
         const size_t lds = sizeof(double) * (STP_NDIAG + 3 * (size_t)HR + std::max(HR, 256)) +
                            sizeof(int16_t) * ((size_t)HR + 3 * (size_t)CW) + (size_t)HR;
+        if (lds > 48 * 1024) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stripiness<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stripiness<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
         if (!big)
             hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)n), dim3(128), lds, ctx->stream, bref(band), (const double*)bE.p,
                                (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n), HR, CW);

@@ -19,7 +19,7 @@ _ERRNAMES = {-1: 'STP_E_ARG', -2: 'STP_E_CAPACITY', -3: 'STP_E_HIP', -4: 'STP_E_
 EXPORTS = [
     'stp_version', 'stp_ctx_create', 'stp_ctx_destroy', 'stp_last_error', 'stp_ctx_set_stream',
     'stp_ctx_synchronize', 'stp_band_upload', 'stp_band_pack', 'stp_band_nearest', 'stp_band_download', 'stp_band_wrap_device', 'stp_band_free',
-    'stp_frames_create', 'stp_frames_create_ex', 'stp_frames_info', 'stp_frames_free', 'stp_stripe_search', 'stp_dbg_stages',
+    'stp_frames_create', 'stp_frames_create_ex', 'stp_frames_info', 'stp_frames_free', 'stp_stripe_search', 'stp_dbg_stages', 'stp_dbg_set_sweep_slots',
     'stp_set_profiling', 'stp_get_stats', 'stp_reset_stats',
 ]
 
@@ -82,6 +82,7 @@ def load():
     L.stp_frames_free.restype = None
     L.stp_stripe_search.argtypes = [vp, vp, C.POINTER(SearchParams), vp, C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.stp_dbg_stages.argtypes = [vp, vp, C.POINTER(SearchParams), C.c_int32, C.c_double, C.c_int32] + [vp] * 9
+    L.stp_dbg_set_sweep_slots.argtypes = [vp, C.c_int32]
     L.stp_set_profiling.argtypes = [vp, C.c_int]
     L.stp_get_stats.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
     L.stp_reset_stats.argtypes = [vp]
@@ -194,6 +195,10 @@ class Context:
 
     def band_wrap(self, dptr, nrows, hw, keepalive=None):
         return Band(self, dptr=dptr, nrows=nrows, hw=hw, keepalive=keepalive)
+
+    def dbg_set_sweep_slots(self, slots):
+        """Parity tests: shrink the record slots of the sweep's first pass (stp_dbg_set_sweep_slots)."""
+        self._chk(self.L.stp_dbg_set_sweep_slots(self.h, int(slots)))
 
     # -- profiling
     def set_profiling(self, on):

@@ -69,3 +69,18 @@ def test_block_mean_is_numpy_order():
         for _ in range(100):
             r0 = int(rng.integers(0, 120 - bs)); c0 = int(rng.integers(0, 300 - bs))
             assert float(np.mean(mat[r0:r0 + bs, c0:c0 + bs])) == L.so_block_mean(mat.ctypes.data, 120, 300, r0, r0 + bs, c0, c0 + bs)
+
+
+def test_block_mean_is_numpys_mean():
+    """so_block_mean (the window mean of the background step) against np.mean of the same 2-D slices with THIS
+    numpy -- also above 8192 elements, where numpy's buffered reduction adds up one pairwise sum per 8192-element
+    buffer (the 1.26.4 build of the harness interpreter gives the same bits: tools note in DESIGN.md)."""
+    import ctypes as C
+    L = O._lib_score()
+    rng = np.random.default_rng(5)
+    M = np.ascontiguousarray(rng.random((900, 1100)) * 1e3)
+    for bs in (1, 7, 10, 50, 90, 91, 100, 128, 200):
+        for _ in range(12):
+            r0 = int(rng.integers(0, 900 - bs)); c0 = int(rng.integers(0, 1100 - bs))
+            got = L.so_block_mean(M.ctypes.data_as(C.c_void_p), 900, 1100, r0, r0 + bs, c0, c0 + bs)
+            assert got == np.mean(M[r0:r0 + bs, c0:c0 + bs]), bs
