@@ -327,6 +327,8 @@ STP_HD void canny_p2(int tid, int nt, stp_tile T, int R, const double* w, const 
     }
 }
 
+#include "stp_gauss_fma.h"
+
 // ---- register-blocked Gaussian passes (compile-time radius): each thread produces a run of
 // consecutive outputs along the filter direction from a sliding window held in registers, so an
 // input is loaded and widened to f64 once instead of 2R+1 times.  Same operation order per output.
@@ -372,17 +374,25 @@ STP_HD void canny_p1_blk_g(int tid, int nt, stp_tile T, const double* w, const f
         double win[VRUN + 2 * R];
 #pragma unroll
         for (int k = 0; k < VRUN + 2 * R; k++) win[k] = xin ? (double)raw[k] : 0.0;
+        float outv[VRUN];
+        const unsigned far = stp_gauss_run_fma<R, VRUN>(win, w, outv);       // certified fused sums (stp_gauss_fma.h)
 #pragma unroll
         for (int q = 0; q < VRUN; q++) {
-            double o = win[q + R] * w[R];
-#pragma unroll
-            for (int k = R; k >= 1; k--) o += (win[q + R - k] + win[q + R + k]) * w[R - k];
-            float out = (float)o;
+            float out = outv[q];
             if (!YIN) {
                 const int y = T.ty0 - 2 + yy0 + q;
                 if (!(y >= 0 && y < T.S)) out = 0.0f;
             }
             sVT[xx * CT_VP + yy0 + q] = out;          // columns outside the image give exactly 0 (all-zero window)
+        }
+        if (far == 0 && xin) {                        // some output is near a float rounding boundary: the exact order decides
+#pragma unroll 1
+            for (int q = 0; q < VRUN; q++) {
+                const int y = T.ty0 - 2 + yy0 + q;    // output row; window rows y-R .. y+R (zero outside the image)
+                if (y < 0 || y >= T.S) continue;
+                const int lo = y - R < 0 ? R - y : 0, hi = y + R >= T.S ? R + (T.S - 1 - y) : 2 * R;
+                sVT[xx * CT_VP + yy0 + q] = stp_gauss_exact(gimg + y * STP_PITCH + x, STP_PITCH, R, w, (unsigned)lo, (unsigned)hi);
+            }
         }
     }
 }
@@ -438,6 +448,11 @@ STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const flo
             win[k] = (double)sVT[(xx0 + k) * CT_VP + yy];  // columns >= CT_X+2R+4 (last run only) lie in the
                                                            // buffer's CT_P2_COLS(R) padding and feed only the
                                                            // outputs xx >= SW that are dropped below
+        float fv[HRUN];
+        if (stp_gauss_run_fma<R, HRUN>(win, w, fv) == 0) {    // rare: the run is settled in the exact order (from LDS;
+#pragma unroll                                                // every sVT column of the window exists, 0 outside the image)
+            for (int q = 0; q < HRUN; q++) fv[q] = stp_gauss_exact(sVT + (xx0 + q + R) * CT_VP + yy, CT_VP, R, w, 0u, (unsigned)(2 * R));
+        }
         const double bint = sB[VH + yy] + DBL_EPSILON;
         // interior row and (tile-uniform XIN, or this item's own columns) interior columns: the verified constant
         const int xfirst = T.tx0 - 2 + xx0;
@@ -447,10 +462,7 @@ STP_HD void canny_p2_blk(int tid, int nt, stp_tile T, const double* w, const flo
         for (int q = 0; q < HRUN; q++) {
             const int xx = xx0 + q;
             if (xx >= SW) break;
-            double o = win[q + R] * w[R];
-#pragma unroll
-            for (int k = R; k >= 1; k--) o += (win[q + R - k] + win[q + R + k]) * w[R - k];
-            const float f = (float)o;
+            const float f = fv[q];
             double s;
             if (XIN) {
                 s = fast ? stp_div_const((double)f, fd.c, fd.rc) : (yin ? (double)f / bint : 0.0);

@@ -197,6 +197,39 @@ int emu_lines(const stp_u64* low, const stp_u64* high, const double* band, int W
 
 }  // extern "C"
 
+// Certification of the fused Gaussian sum (stp_gauss_fma.h): over `n` random windows of float values in [lo, 1]
+// the float rounding of the fused sum must equal that of the reference's order whenever the near-boundary test does
+// not flag it.  Returns the number of violations (must be 0); *flagged = how many outputs the test sends to the
+// exact order; *max_ulp_diff = largest distance between the two f64 sums.
+extern "C" long long emu_certify_fma(const double* w, int R, long long n, unsigned long long seed, double lo, long long* flagged,
+                                     double* max_ulp_diff)
+{
+    long long bad = 0, nf = 0;
+    double worst = 0.0;
+    unsigned long long s = seed * 0x9E3779B97F4A7C15ull + 1;
+    std::vector<double> win(2 * R + 1);
+    for (long long it = 0; it < n; it++) {
+        for (int k = 0; k <= 2 * R; k++) {
+            s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+            const float f = (float)(lo + (1.0 - lo) * (double)(s >> 40) / 16777216.0);
+            win[k] = ((s & 0xF00) == 0) ? 0.0 : (double)f;          // some zero taps (image border)
+        }
+        double a = win[R] * w[R], e = win[R] * w[R];
+        for (int k = R; k >= 1; k--) {
+            a = fma(win[R - k] + win[R + k], w[R - k], a);
+            e += (win[R - k] + win[R + k]) * w[R - k];
+        }
+        long long ia, ie;
+        memcpy(&ia, &a, 8); memcpy(&ie, &e, 8);
+        worst = std::max(worst, (double)std::llabs(ia - ie));
+        if (stp_fma_near_word(a) == 0) { nf++; continue; }
+        if ((float)a != (float)e) bad++;
+    }
+    if (flagged) *flagged = nf;
+    if (max_ulp_diff) *max_ulp_diff = worst;
+    return bad;
+}
+
 // whether the multiply + 2 FMA division by the interior bleed-over constant is exact for every float
 extern "C" int emu_fastdiv_ok(const double* w, int R, double* c_out)
 {

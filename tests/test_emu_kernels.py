@@ -146,3 +146,52 @@ def test_generic_radius_path(emu, golden_stages):
     emu.emu_canny2(_p(full), 200, r3, _p(w3), _p(low), _p(high), 0)
     oe, dbg = O.canny(img, w3, r3, debug=True)
     assert np.array_equal(_unpack(low, 200).astype(np.uint8) + _unpack(high, 200), dbg['cls'])
+
+
+# ----------------------------------------------------------------------------- certified FMA (stp_gauss_fma.h)
+@pytest.fixture(scope='module')
+def emu_allnear(emu):
+    """The same replay built with every Gaussian output flagged "near a rounding boundary": only the exact-order
+    fallback of the certified-FMA passes runs."""
+    return C.CDLL(os.path.join(HERE, 'emu', 'libstp_emu_allnear.so'))
+
+
+def _noisy(S, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:S, 0:S]
+    img = 0.299 + 0.701 * np.clip(0.5 + 0.35 * np.sin(xx / 7.0) * np.cos(yy / 11.0) + 0.25 * rng.standard_normal((S, S)), 0, 1)
+    return np.ascontiguousarray(img, dtype=np.float32)
+
+
+@pytest.mark.parametrize('sigma,key', [(2.0, 'gw_2p0'), (2.5, 'gw_2p5')])
+@pytest.mark.parametrize('S', [400, 399, 301, 143, 64, 41, 12])
+def test_canny_sizes_radii_and_exact_fallback(emu, emu_allnear, golden_stages, S, sigma, key):
+    """Image sizes that end inside a tile, both default radii, noisy and plateau images: classes bit-exact vs the
+    oracle -- with the certified-FMA Gaussian passes and with their exact-order fallback alone."""
+    gw = np.ascontiguousarray(golden_stages[key])
+    R = (len(gw) - 1) // 2
+    for k, img in enumerate([_noisy(S, 11 + S)] + (_plateau_images(S)[:3] if S >= 41 else [])):
+        full = np.zeros((400, 400), np.float32)
+        full[:S, :S] = img
+        oe, dbg = O.canny(img, gw, R, debug=True)
+        for lib in (emu, emu_allnear):
+            low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64)
+            lib.emu_canny(_p(full), S, R, _p(gw), _p(low), _p(high))
+            got = _unpack(low, S).astype(np.uint8) + _unpack(high, S)
+            assert np.array_equal(got, dbg['cls']), 'image %d (S=%d, sigma %.1f)' % (k, S, sigma)
+
+
+def test_fma_certification_random_windows(emu, golden_stages):
+    """The claim behind the fused Gaussian sum: whenever the near-boundary test does not flag an output,
+    float(fused sum) == float(sum in the reference's order).  8 M random windows per case (grey-like values, some
+    zero taps); the two f64 sums never differ by more than the R + 1 ulp of the derivation."""
+    emu.emu_certify_fma.restype = C.c_longlong
+    for key, lo in (('gw_2p0', 0.299), ('gw_2p5', 0.299), ('gw_2p0', 1e-3)):
+        gw = np.ascontiguousarray(golden_stages[key])
+        R = (len(gw) - 1) // 2
+        flagged = C.c_longlong(0); worst = C.c_double(0)
+        bad = emu.emu_certify_fma(_p(gw), R, C.c_longlong(8000000), C.c_ulonglong(R * 7 + 1), C.c_double(lo),
+                                  C.byref(flagged), C.byref(worst))
+        assert bad == 0
+        assert worst.value <= R + 1
+        assert flagged.value < 100          # ~64 / 2^29 of the outputs
