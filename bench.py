@@ -242,14 +242,29 @@ def main():
     tabs = {ci: frame_table(nbins[ci]) for ci in {u[0] for u in my_units}}
     setup_s = time.time() - t_setup
 
+    def launch(unit):
+        """frame compaction + medpixel of one unit (small kernels on the context's auxiliary stream) and its whole
+        StripeSearch chain enqueued on the main stream; returns without waiting for the chain"""
+        ci, f0, f1 = unit
+        st, en = tabs[ci]
+        fr = bands[names[ci]].frames(st[f0:f1], en[f0:f1])
+        return unit, fr, fr.stripe_search_begin(Ms[ci])
+
     def step():
+        """Two searches are kept in flight: while the device runs the chain of unit u+1 (and u+2 is queued behind
+        it), the host collects the records of unit u, builds the score inputs and enqueues its p-value /
+        Stripiness kernels -- the single in-order stream never runs dry."""
         nrec, px = 0, 0.0
-        for ci, f0, f1 in my_units:
-            st, en = tabs[ci]
-            sband = bands[names[ci]]
-            fr = sband.frames(st[f0:f1], en[f0:f1])
-            recs = fr.stripe_search(Ms[ci])
+        todo = list(my_units)[::-1]
+        flight = [launch(todo.pop()) for _ in range(min(2, len(todo)))]
+        while flight:
+            (ci, f0, f1), fr, pend = flight.pop(0)
+            recs = pend.wait()
+            if todo:
+                flight.append(launch(todo.pop()))
             if not args.no_score:
+                st = tabs[ci][0]
+                sband = bands[names[ci]]
                 pv, sc = BK.score_inputs(recs, fr.nz, st[f0:f1], nbins[ci], bs)
                 hb.pvalue(sband, bs, pv)
                 hb.stripiness(sband, EV[ci], sc)

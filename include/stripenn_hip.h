@@ -136,6 +136,19 @@ int stp_stripe_search(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
                       const double* M_levels /* nframes_levels: M for [level] */, int32_t n_levels,
                       stp_stripe_rec* out, int64_t out_capacity, int64_t* out_count);
 
+/* The same search without a host round trip per call: `begin` enqueues every kernel of the batch on the ctx stream and
+ * returns at once (the frames, and the band behind them, must stay alive until the search is fetched or cancelled);
+ * `count` blocks until the batch is done and gives the number of records; `fetch` copies them out (capacity >= count)
+ * and releases the search, also on error.  Several searches may be in flight on one context: they run in order on its
+ * stream and share its image workspace, so the host can prepare / consume one batch while the device works on the
+ * next (the reference runs frames strictly one after the other, getStripe.py:829-842). */
+typedef struct stp_search stp_search;
+int stp_stripe_search_begin(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, const double* M_levels,
+                            int32_t n_levels, stp_search** out);
+int stp_stripe_search_count(stp_ctx* ctx, stp_search* search, int64_t* out_count);
+int stp_stripe_search_fetch(stp_ctx* ctx, stp_search* search, stp_stripe_rec* out, int64_t out_capacity);
+void stp_stripe_search_cancel(stp_ctx* ctx, stp_search* search);
+
 /* Parity tests: the sweep grants every image 128 record slots and re-runs a chunk of images with 400 slots (one
  * per possible column pair) when some image needs more -- which no contact map has been seen to do.  This shrinks
  * the first pass to `slots` (1..128) so that the re-run path executes on ordinary data; results must not change. */

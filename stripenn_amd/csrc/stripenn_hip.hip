@@ -657,8 +657,9 @@ __global__ __launch_bounds__(512, RCAP == STP_RCAP ? 6 : 4) void k_lines(const s
 #define CR_IPB 64
 __global__ __launch_bounds__(1024) void k_compact_recs(const stp_drec* __restrict__ recs, const int32_t* __restrict__ cnt,
                                                         int nimg, int f0, int nlev, int nb, stp_stripe_rec* __restrict__ out,
-                                                        long long cap, long long* __restrict__ total_overflow, int rcap /* slot stride */,
-                                                        int slots /* slots an image may use: <= rcap */)
+                                                        long long cap, const long long* __restrict__ tot_in /* records / overflow of the earlier chunks */,
+                                                        long long* __restrict__ tot_out /* ... including this chunk */,
+                                                        int rcap /* slot stride */, int slots /* slots an image may use: <= rcap */)
 {
     __shared__ int s_wsum[16], s_wover[16];
     __shared__ int s_cnt[CR_IPB], s_off[CR_IPB];
@@ -689,8 +690,8 @@ __global__ __launch_bounds__(1024) void k_compact_recs(const stp_drec* __restric
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
         s_off[lane] = incl - c;
         if (lane == 63) {
-            s_base = b;
-            if (last) { total_overflow[0] = (long long)b + incl; total_overflow[1] = ov; }
+            s_base = tot_in[0] + b;                   // the chunks of a search append to one output array
+            if (last) { tot_out[0] = tot_in[0] + (long long)b + incl; tot_out[1] = tot_in[1] | ov; }
         }
     }
     __syncthreads();
@@ -772,12 +773,16 @@ struct stp_ctx {
     size_t pool_bytes = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t aux = nullptr;             // frame compaction / medpixel and the per-stripe score kernels: small kernels
+                                           // with a host round trip each, which must not queue behind (and thereby
+                                           // drain) the searches in flight on `stream`
     std::string err;
     bool profiling = false;
     std::vector<stp_kstat> stats;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<std::vector<double>, stp_fastdiv>> fd_cache;   // verified interior bleed-over divisions
     int sweep_slots = STP_RCAP;            // record slots per image in the first pass (stp_dbg_set_sweep_slots)
+    std::vector<std::pair<size_t, void*>> pin_free;   // pinned staging buffers of finished searches, recycled
 };
 
 struct stp_band {
@@ -881,16 +886,17 @@ struct prof_scope {
     const char* name;
     double bytes;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    prof_scope(stp_ctx* c, const char* n, double b) : ctx(c), name(n), bytes(b)
+    hipStream_t st;
+    prof_scope(stp_ctx* c, const char* n, double b, hipStream_t on = nullptr) : ctx(c), name(n), bytes(b), st(on ? on : c->stream)
     {
         if (!ctx->profiling) return;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
-        (void)hipEventRecord(e0, ctx->stream);
+        (void)hipEventRecord(e0, st);
     }
     ~prof_scope()
     {
         if (!ctx->profiling || !e0) return;
-        (void)hipEventRecord(e1, ctx->stream);
+        (void)hipEventRecord(e1, st);
         stp_pending p;
         p.e0 = e0; p.e1 = e1; p.name = name; p.bytes = bytes;
         ctx->pending.push_back(p);
@@ -941,6 +947,7 @@ int stp_ctx_create(int device_ordinal, stp_ctx** out)
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return STP_E_HIP; }
     ctx->own_stream = true;
+    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return STP_E_HIP; }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
     *out = ctx;
@@ -956,9 +963,11 @@ void stp_ctx_destroy(stp_ctx* ctx)
     for (int i = 0; i < WS_NSLOTS; i++) if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     for (auto& e : ctx->pool_free) (void)hipFree(e.second);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    for (auto& e : ctx->pin_free) (void)hipHostFree(e.second);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
     delete ctx;
 }
 
@@ -1077,9 +1086,9 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
     FRCHK(pool_alloc(ctx, n * sizeof(int32_t), (void**)&fr->d_n0));
     FRCHK(pool_alloc(ctx, n * sizeof(int32_t), (void**)&fr->d_S));
     FRCHK(pool_alloc(ctx, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), (void**)&fr->d_nz));
-    FRCHK(hipMemcpyAsync(fr->d_start, fr->h_start.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    FRCHK(hipMemcpyAsync(fr->d_n0, fr->h_n0.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    FRCHK(hipMemsetAsync(fr->d_nz, 0, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), ctx->stream));
+    FRCHK(hipMemcpyAsync(fr->d_start, fr->h_start.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->aux));
+    FRCHK(hipMemcpyAsync(fr->d_n0, fr->h_n0.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->aux));
+    FRCHK(hipMemsetAsync(fr->d_nz, 0, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), ctx->aux));
     double* d_med = nullptr;
     unsigned long long* d_fstat = nullptr;
     FRCHK(pool_alloc(ctx, (size_t)n * 3 * sizeof(double), (void**)&d_med));
@@ -1091,8 +1100,8 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
     {
         double bytes = 0;
         for (int i = 0; i < n; i++) bytes += 8.0 * fr->h_n0[i] * fr->h_n0[i];
-        prof_scope ps(ctx, "frame_compact", bytes);
-        hipLaunchKernelGGL(k_frame_compact, dim3(n), dim3(512), 0, ctx->stream, band->d, band->W, band->hw, fr->d_start,
+        prof_scope ps(ctx, "frame_compact", bytes, ctx->aux);
+        hipLaunchKernelGGL(k_frame_compact, dim3(n), dim3(512), 0, ctx->aux, band->d, band->W, band->hw, fr->d_start,
                            fr->d_n0, fr->d_S, fr->d_nz, d_fstat, (flags & STP_FRAMES_KEEP_ALL) ? 1 : 0);
     }
     FRCHK(hipGetLastError());
@@ -1100,16 +1109,16 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
         // medpixel: two order statistics per frame by radix select, numpy's lerp on the host
         double bytes = 0;
         for (int i = 0; i < n; i++) bytes += 8.0 * fr->h_n0[i] * fr->h_n0[i];
-        prof_scope ps(ctx, "medpixel", bytes);
+        prof_scope ps(ctx, "medpixel", bytes, ctx->aux);
         stp_bandref B{band->d, band->nrows, band->W, band->hw};
-        hipLaunchKernelGGL(k_medpixel, dim3(n), dim3(1024), 0, ctx->stream, B, fr->d_start, fr->d_n0, d_fstat, d_med);
+        hipLaunchKernelGGL(k_medpixel, dim3(n), dim3(1024), 0, ctx->aux, B, fr->d_start, fr->d_n0, d_fstat, d_med);
     }
     std::vector<double> hm((size_t)n * 3);
-    hipError_t e1 = hipMemcpyAsync(hm.data(), d_med, hm.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e1 == hipSuccess) e1 = hipMemcpyAsync(fr->h_S.data(), fr->d_S, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e1 = hipMemcpyAsync(hm.data(), d_med, hm.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->aux);
+    if (e1 == hipSuccess) e1 = hipMemcpyAsync(fr->h_S.data(), fr->d_S, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->aux);
     if (e1 == hipSuccess) e1 = hipMemcpyAsync(fr->h_nz.data(), fr->d_nz, (size_t)n * STP_FRAME_MAX * sizeof(int16_t),
-                                              hipMemcpyDeviceToHost, ctx->stream);
-    if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+                                              hipMemcpyDeviceToHost, ctx->aux);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->aux);
     pool_release(ctx, d_med, (size_t)n * 3 * sizeof(double));
     pool_release(ctx, d_fstat, (size_t)n * 3 * sizeof(unsigned long long));
     FRCHK(e1);
@@ -1330,94 +1339,212 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     return STP_OK;
 }
 
-int stp_stripe_search(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, const double* M_levels,
-                      int32_t n_levels, stp_stripe_rec* out, int64_t cap, int64_t* out_count)
+// One search in flight: every chunk of the batch is enqueued on the ctx stream without a host round trip; the chunks
+// append their records to ONE device array (k_compact_recs carries the running total from chunk to chunk), and the
+// total travels back together with as many records as the previous search of this context produced (+25 %).
+struct stp_search {
+    const stp_frames* fr = nullptr;
+    std::vector<double> M, bright, gw;
+    stp_search_params prm;
+    int nlev = 0, rcap = STP_RCAP, nchunks = 0;
+    void* d_out = nullptr; size_t out_bytes = 0;
+    long long* d_tot = nullptr; size_t tot_bytes = 0;
+    void* pin = nullptr; size_t pin_bytes = 0, guess = 0;
+    hipEvent_t done = nullptr;
+    long long n = -1;                 // records, once known
+};
+
+static void search_release(stp_ctx* ctx, stp_search* s)
 {
-    if (!ctx || !fr || !M_levels || !out_count || n_levels < 1 || (cap > 0 && !out)) return STP_E_ARG;
-    int rc = check_params(ctx, prm);
-    if (rc) return rc;
-    HIPCHK(hipSetDevice(ctx->device));
-    const int nb = prm->n_bright, ipf = n_levels * nb;
+    if (!s) return;
+    pool_release(ctx, s->d_out, s->out_bytes);
+    pool_release(ctx, s->d_tot, s->tot_bytes);
+    if (s->pin) {
+        if (ctx->pin_free.size() < 8) ctx->pin_free.push_back(std::make_pair(s->pin_bytes, s->pin));
+        else (void)hipHostFree(s->pin);
+    }
+    if (s->done) (void)hipEventDestroy(s->done);
+    delete s;
+}
+
+// enqueue all chunks of the search with s->rcap record slots per image
+static int search_enqueue(stp_ctx* ctx, stp_search* s)
+{
+    const stp_frames* fr = s->fr;
+    const stp_search_params* prm = &s->prm;
+    const int n_levels = s->nlev, nb = prm->n_bright, ipf = n_levels * nb, rcap = s->rcap;
     int chunk = 3072 / ipf;
     if (chunk < 1) chunk = 1;
     if (chunk > fr->n) chunk = fr->n;
     const size_t cimg = (size_t)chunk * ipf;
-    const size_t ocap = cimg * STP_RCAP;                 // dense records per chunk: every image may fill its slots
-    void *pGray, *pLow, *pHigh, *pRecs, *pCnt, *pOut, *pTot, *pPar;
+    s->nchunks = (fr->n + chunk - 1) / chunk;
+    void *pGray, *pLow, *pHigh, *pRecs, *pCnt, *pPar;
     HIPCHK(ws_get(ctx, WS_GRAY, cimg * STP_PITCH * STP_PITCH * sizeof(float) + 2 * STP_GRAY_GUARD, &pGray));
     pGray = (char*)pGray + STP_GRAY_GUARD;            // border tiles of the vertical pass read (and discard) up to R+2 rows outside
     HIPCHK(ws_get(ctx, WS_LOW, cimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), &pLow));
     HIPCHK(ws_get(ctx, WS_HIGH, cimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), &pHigh));
-    HIPCHK(ws_get(ctx, WS_RECS, cimg * STP_RCAP * sizeof(stp_drec), &pRecs));
+    HIPCHK(ws_get(ctx, WS_RECS, cimg * (size_t)rcap * sizeof(stp_drec), &pRecs));
     HIPCHK(ws_get(ctx, WS_CNT, cimg * sizeof(int32_t), &pCnt));
-    HIPCHK(ws_get(ctx, WS_OUT, ocap * sizeof(stp_stripe_rec), &pOut));
-    HIPCHK(ws_get(ctx, WS_TOTAL, 2 * sizeof(long long), &pTot));
     const int nwt = 2 * prm->gauss_radius + 1;
     HIPCHK(ws_get(ctx, WS_PARAMS, (size_t)(n_levels + nb + nwt) * sizeof(double), &pPar));
     double* dM = (double*)pPar;
     double* dB = dM + n_levels;
     double* dW = dB + nb;
-    HIPCHK(hipMemcpyAsync(dM, M_levels, n_levels * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dM, s->M.data(), n_levels * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(dB, prm->bright, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(dW, prm->gauss_w, nwt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    void* pin = nullptr;
-    HIPCHK(pin_get(ctx, ocap * sizeof(stp_stripe_rec) + 64, &pin));
-    long long* h_tot = (long long*)pin;
-    stp_stripe_rec* h_out = (stp_stripe_rec*)((char*)pin + 64);
-    int64_t total = 0;
-    for (int f0 = 0; f0 < fr->n; f0 += chunk) {
+    // output of the whole batch: every image may fill its slots
+    const size_t ocap = (size_t)fr->n * ipf * (size_t)rcap;
+    if (s->out_bytes < ocap * sizeof(stp_stripe_rec)) {
+        pool_release(ctx, s->d_out, s->out_bytes);
+        s->d_out = nullptr; s->out_bytes = 0;
+        HIPCHK(pool_alloc(ctx, ocap * sizeof(stp_stripe_rec), &s->d_out));
+        s->out_bytes = ocap * sizeof(stp_stripe_rec);
+    }
+    const size_t tb = (size_t)(s->nchunks + 1) * 2 * sizeof(long long);
+    if (s->tot_bytes < tb) {
+        pool_release(ctx, s->d_tot, s->tot_bytes);
+        s->d_tot = nullptr; s->tot_bytes = 0;
+        HIPCHK(pool_alloc(ctx, tb, (void**)&s->d_tot));
+        s->tot_bytes = tb;
+    }
+    HIPCHK(hipMemsetAsync(s->d_tot, 0, 2 * sizeof(long long), ctx->stream));
+    for (int c = 0; c < s->nchunks; c++) {
+        const int f0 = c * chunk;
         const int nf = (fr->n - f0 < chunk) ? fr->n - f0 : chunk;
         const size_t nimg = (size_t)nf * ipf;
-        // the sweep gives every image STP_RCAP record slots; a chunk in which some image needs more (never seen on
-        // contact maps: > 128 accepted column pairs in one image) is run again with STP_RCAP_MAX slots -- two
-        // neighbouring X values can pair only once, so no image can fill more
-        for (int rcap = STP_RCAP;; rcap = STP_RCAP_MAX) {
-            const size_t ocap_r = cimg * (size_t)rcap;
-            if (rcap != STP_RCAP) {
-                HIPCHK(ws_get(ctx, WS_RECS, cimg * (size_t)rcap * sizeof(stp_drec), &pRecs));
-                HIPCHK(ws_get(ctx, WS_OUT, ocap_r * sizeof(stp_stripe_rec), &pOut));
-                HIPCHK(pin_get(ctx, ocap_r * sizeof(stp_stripe_rec) + 64, &pin));
-                h_tot = (long long*)pin;
-                h_out = (stp_stripe_rec*)((char*)pin + 64);
-            }
-            rc = run_chain(ctx, fr, prm, f0, nf, dM, n_levels, dB, dW, (float*)pGray, (stp_u64*)pLow, (stp_u64*)pHigh,
+        int rc = run_chain(ctx, fr, prm, f0, nf, dM, n_levels, dB, dW, (float*)pGray, (stp_u64*)pLow, (stp_u64*)pHigh,
                            (stp_drec*)pRecs, (int32_t*)pCnt, 0, nullptr, nullptr, rcap);
-            if (rc) return rc;
-            {
-                prof_scope ps(ctx, "compact_recs", (double)nimg * 4.0);
-                hipLaunchKernelGGL(k_compact_recs, dim3((unsigned)((nimg + CR_IPB - 1) / CR_IPB)), dim3(1024), 0, ctx->stream, (const stp_drec*)pRecs,
-                                   (const int32_t*)pCnt, (int)nimg, f0, n_levels, nb, (stp_stripe_rec*)pOut, (long long)ocap_r,
-                                   (long long*)pTot, rcap, rcap == STP_RCAP ? std::min(rcap, ctx->sweep_slots) : rcap);
+        if (rc) return rc;
+        {
+            prof_scope ps(ctx, "compact_recs", (double)nimg * 4.0);
+            hipLaunchKernelGGL(k_compact_recs, dim3((unsigned)((nimg + CR_IPB - 1) / CR_IPB)), dim3(1024), 0, ctx->stream, (const stp_drec*)pRecs,
+                               (const int32_t*)pCnt, (int)nimg, f0, n_levels, nb, (stp_stripe_rec*)s->d_out, (long long)ocap,
+                               (const long long*)(s->d_tot + 2 * c), s->d_tot + 2 * (c + 1), rcap,
+                               rcap == STP_RCAP ? std::min(rcap, ctx->sweep_slots) : rcap);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    // the count travels with as many records as the previous search of this context produced (+25 %): one round trip
+    // in the common case
+    s->guess = std::min(ocap, (size_t)ctx->rec_guess);
+    const size_t pb = 64 + std::max(s->guess, (size_t)1024) * sizeof(stp_stripe_rec);
+    if (s->pin_bytes < pb) {
+        if (s->pin) (void)hipHostFree(s->pin);
+        s->pin = nullptr; s->pin_bytes = 0;
+        for (size_t i = 0; i < ctx->pin_free.size(); i++)
+            if (ctx->pin_free[i].first >= pb) {
+                s->pin = ctx->pin_free[i].second; s->pin_bytes = ctx->pin_free[i].first;
+                ctx->pin_free[i] = ctx->pin_free.back(); ctx->pin_free.pop_back();
+                break;
             }
-            HIPCHK(hipGetLastError());
-            // one round trip in the common case: the count travels with as many records as the previous
-            // chunk of this context produced (+25 %); only a larger result needs a second copy
-            const size_t guess = std::min(ocap_r, (size_t)ctx->rec_guess);
-            HIPCHK(hipMemcpyAsync(h_tot, pTot, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-            if (guess) HIPCHK(hipMemcpyAsync(h_out, pOut, guess * sizeof(stp_stripe_rec), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            const long long n = h_tot[0];
-            if (h_tot[1] && rcap == STP_RCAP) continue;           // some image overflowed its slots: again, with all of them
-            if (h_tot[1]) return set_err(ctx, STP_E_CAPACITY, "an image produced more candidate stripes than pairs of columns exist");
-            if ((size_t)n > ocap_r) return set_err(ctx, STP_E_CAPACITY, "record compaction overran its buffer");
-            ctx->rec_guess = n + n / 4 + 64;
-            if (n > 0) {
-                if ((size_t)n > guess) {
-                    HIPCHK(hipMemcpyAsync(h_out + guess, (stp_stripe_rec*)pOut + guess, ((size_t)n - guess) * sizeof(stp_stripe_rec),
-                                          hipMemcpyDeviceToHost, ctx->stream));
-                    HIPCHK(hipStreamSynchronize(ctx->stream));
-                }
-                for (long long k = 0; k < n; k++) {
-                    if (total < cap) out[total] = h_out[k];
-                    total++;
-                }
-            }
-            break;
+        if (!s->pin) {
+            HIPCHK(hipHostMalloc(&s->pin, pb, hipHostMallocDefault));
+            s->pin_bytes = pb;
         }
     }
-    *out_count = total;
-    if (total > cap) return set_err(ctx, STP_E_CAPACITY, "output capacity too small; out_count holds the needed size");
+    s->guess = std::min(s->guess, (s->pin_bytes - 64) / sizeof(stp_stripe_rec));
+    HIPCHK(hipMemcpyAsync(s->pin, s->d_tot + 2 * s->nchunks, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+    if (s->guess)
+        HIPCHK(hipMemcpyAsync((char*)s->pin + 64, s->d_out, s->guess * sizeof(stp_stripe_rec), hipMemcpyDeviceToHost, ctx->stream));
+    if (!s->done) HIPCHK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(s->done, ctx->stream));
+    s->n = -1;
     return STP_OK;
+}
+
+int stp_stripe_search_begin(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, const double* M_levels,
+                            int32_t n_levels, stp_search** out)
+{
+    if (!ctx || !fr || !M_levels || !out || n_levels < 1) return STP_E_ARG;
+    *out = nullptr;
+    int rc = check_params(ctx, prm);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    stp_search* s = new (std::nothrow) stp_search();
+    if (!s) return STP_E_NOMEM;
+    s->fr = fr; s->nlev = n_levels;
+    s->M.assign(M_levels, M_levels + n_levels);
+    s->bright.assign(prm->bright, prm->bright + prm->n_bright);
+    s->gw.assign(prm->gauss_w, prm->gauss_w + 2 * prm->gauss_radius + 1);
+    s->prm = *prm; s->prm.bright = s->bright.data(); s->prm.gauss_w = s->gw.data();
+    rc = search_enqueue(ctx, s);
+    if (rc) { search_release(ctx, s); return rc; }
+    *out = s;
+    return STP_OK;
+}
+
+int stp_stripe_search_count(stp_ctx* ctx, stp_search* s, int64_t* out_count)
+{
+    if (!ctx || !s || !out_count) return STP_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (s->n < 0) {
+        for (;;) {
+            HIPCHK(hipEventSynchronize(s->done));
+            const long long* h_tot = (const long long*)s->pin;
+            if (h_tot[1] && s->rcap == STP_RCAP) {
+                // some image needed more than the sweep's record slots (never seen on contact maps): the batch is
+                // searched again with one slot per possible column pair -- neighbouring X values pair at most once
+                s->rcap = STP_RCAP_MAX;
+                int rc = search_enqueue(ctx, s);
+                if (rc) return rc;
+                continue;
+            }
+            if (h_tot[1]) return set_err(ctx, STP_E_CAPACITY, "an image produced more candidate stripes than pairs of columns exist");
+            s->n = h_tot[0];
+            break;
+        }
+        if ((size_t)s->n * sizeof(stp_stripe_rec) > s->out_bytes) return set_err(ctx, STP_E_CAPACITY, "record compaction overran its buffer");
+        ctx->rec_guess = s->n + s->n / 4 + 64;
+    }
+    *out_count = s->n;
+    return STP_OK;
+}
+
+int stp_stripe_search_fetch(stp_ctx* ctx, stp_search* s, stp_stripe_rec* out, int64_t cap)
+{
+    if (!ctx || !s || (cap > 0 && !out)) return STP_E_ARG;
+    int64_t n = 0;
+    int rc = stp_stripe_search_count(ctx, s, &n);
+    if (rc == STP_OK && n > cap) rc = set_err(ctx, STP_E_CAPACITY, "output capacity too small for " + std::to_string(n) + " records");
+    if (rc == STP_OK && n > 0) {
+        const size_t have = std::min((size_t)n, s->guess);
+        memcpy(out, (char*)s->pin + 64, have * sizeof(stp_stripe_rec));
+        if ((size_t)n > have) {
+            hipError_t e = hipMemcpyAsync(out + have, (stp_stripe_rec*)s->d_out + have, ((size_t)n - have) * sizeof(stp_stripe_rec),
+                                          hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = set_err(ctx, STP_E_HIP, std::string("record copy: ") + hipGetErrorString(e));
+        }
+    }
+    search_release(ctx, s);
+    return rc;
+}
+
+void stp_stripe_search_cancel(stp_ctx* ctx, stp_search* s)
+{
+    if (!ctx || !s) return;
+    (void)hipSetDevice(ctx->device);
+    if (s->done) (void)hipEventSynchronize(s->done);
+    search_release(ctx, s);
+}
+
+int stp_stripe_search(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, const double* M_levels,
+                      int32_t n_levels, stp_stripe_rec* out, int64_t cap, int64_t* out_count)
+{
+    if (!ctx || !fr || !M_levels || !out_count || n_levels < 1 || (cap > 0 && !out)) return STP_E_ARG;
+    stp_search* s = nullptr;
+    int rc = stp_stripe_search_begin(ctx, fr, prm, M_levels, n_levels, &s);
+    if (rc) return rc;
+    int64_t n = 0;
+    rc = stp_stripe_search_count(ctx, s, &n);
+    if (rc) { stp_stripe_search_cancel(ctx, s); return rc; }
+    *out_count = n;
+    if (n > cap) {
+        stp_stripe_search_cancel(ctx, s);
+        return set_err(ctx, STP_E_CAPACITY, "output capacity too small; out_count holds the needed size");
+    }
+    return stp_stripe_search_fetch(ctx, s, out, cap);
 }
 
 int stp_dbg_set_sweep_slots(stp_ctx* ctx, int32_t slots)
@@ -1649,11 +1776,11 @@ int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int
     dev_buf bS, bO;
     HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_pv_stripe)));
     HIPCHK(bO.alloc(ctx, (size_t)n * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(bS.p, st, (size_t)n * sizeof(stp_pv_stripe), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(bS.p, st, (size_t)n * sizeof(stp_pv_stripe), hipMemcpyHostToDevice, ctx->aux));
     {
         double bytes = 0;
         for (int64_t i = 0; i < n; i++) bytes += (8.0 * (st[i].col1 - st[i].col0) + 16000.0) * (st[i].row1 - st[i].row0);
-        prof_scope ps(ctx, "pvalue", bytes);
+        prof_scope ps(ctx, "pvalue", bytes, ctx->aux);
         bool big = bs > 128;
         int hmax = 1;
         for (int64_t i = 0; i < n; i++) {
@@ -1666,15 +1793,15 @@ int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pvalue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
         if (!big)
-            hipLaunchKernelGGL(k_pvalue<false>, dim3((unsigned)n), dim3(256), lds, ctx->stream, bref(band), (const double*)bg->sorted,
+            hipLaunchKernelGGL(k_pvalue<false>, dim3((unsigned)n), dim3(256), lds, ctx->aux, bref(band), (const double*)bg->sorted,
                                (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p, hmax);
         else
-            hipLaunchKernelGGL(k_pvalue<true>, dim3((unsigned)n), dim3(256), lds, ctx->stream, bref(band), (const double*)bg->sorted,
+            hipLaunchKernelGGL(k_pvalue<true>, dim3((unsigned)n), dim3(256), lds, ctx->aux, bref(band), (const double*)bg->sorted,
                                (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p, hmax);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_p, bO.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_p, bO.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipStreamSynchronize(ctx->aux));
     return STP_OK;
 }
 
@@ -1694,14 +1821,14 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
     HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_score_stripe)));
     HIPCHK(bE.alloc(ctx, STP_NDIAG * sizeof(double)));
     HIPCHK(bO.alloc(ctx, (size_t)n * 3 * sizeof(double) + (size_t)n * sizeof(int)));
-    HIPCHK(hipMemcpyAsync(bS.p, st, (size_t)n * sizeof(stp_score_stripe), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(bE.p, exval400, STP_NDIAG * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(bS.p, st, (size_t)n * sizeof(stp_score_stripe), hipMemcpyHostToDevice, ctx->aux));
+    HIPCHK(hipMemcpyAsync(bE.p, exval400, STP_NDIAG * sizeof(double), hipMemcpyHostToDevice, ctx->aux));
     double* o = (double*)bO.p;
     {
         double bytes = 0;
         for (int64_t i = 0; i < n; i++)
             for (int b = 0; b < 3; b++) bytes += 8.0 * (st[i].col1[b] - st[i].col0[b]) * (st[i].row1 - st[i].row0);
-        prof_scope ps(ctx, "stripiness", bytes);
+        prof_scope ps(ctx, "stripiness", bytes, ctx->aux);
         bool big = false;
         int hmax = 1, wmax = 1;
         for (int64_t i = 0; i < n; i++) {
@@ -1719,18 +1846,18 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stripiness<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
         if (!big)
-            hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)n), dim3(128), lds, ctx->stream, bref(band), (const double*)bE.p,
+            hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)n), dim3(128), lds, ctx->aux, bref(band), (const double*)bE.p,
                                (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n), HR, CW);
         else
-            hipLaunchKernelGGL(k_stripiness<true>, dim3((unsigned)n), dim3(128), lds, ctx->stream, bref(band), (const double*)bE.p,
+            hipLaunchKernelGGL(k_stripiness<true>, dim3((unsigned)n), dim3(128), lds, ctx->aux, bref(band), (const double*)bE.p,
                                (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n), HR, CW);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_g, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(out_mean, o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(out_total, o + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (out_status) HIPCHK(hipMemcpyAsync(out_status, o + 3 * n, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_g, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipMemcpyAsync(out_mean, o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipMemcpyAsync(out_total, o + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
+    if (out_status) HIPCHK(hipMemcpyAsync(out_status, o + 3 * n, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipStreamSynchronize(ctx->aux));
     return STP_OK;
 }
 
@@ -1746,18 +1873,18 @@ int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rc, int6
     dev_buf bS, bO;
     HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_rect)));
     HIPCHK(bO.alloc(ctx, (size_t)n * 2 * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(bS.p, rc, (size_t)n * sizeof(stp_rect), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(bS.p, rc, (size_t)n * sizeof(stp_rect), hipMemcpyHostToDevice, ctx->aux));
     double* o = (double*)bO.p;
     {
         double bytes = 0;
         for (int64_t i = 0; i < n; i++) bytes += 8.0 * (rc[i].col1 - rc[i].col0) * (rc[i].row1 - rc[i].row0);
-        prof_scope ps(ctx, "stripe_mean", bytes);
-        hipLaunchKernelGGL(k_stripe_mean, dim3((unsigned)n), dim3(256), 0, ctx->stream, bref(band), (const stp_rect*)bS.p, o, o + n);
+        prof_scope ps(ctx, "stripe_mean", bytes, ctx->aux);
+        hipLaunchKernelGGL(k_stripe_mean, dim3((unsigned)n), dim3(256), 0, ctx->aux, bref(band), (const stp_rect*)bS.p, o, o + n);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_mean, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(out_sum, o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpyAsync(out_mean, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipMemcpyAsync(out_sum, o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipStreamSynchronize(ctx->aux));
     return STP_OK;
 }
 

@@ -19,7 +19,8 @@ _ERRNAMES = {-1: 'STP_E_ARG', -2: 'STP_E_CAPACITY', -3: 'STP_E_HIP', -4: 'STP_E_
 EXPORTS = [
     'stp_version', 'stp_ctx_create', 'stp_ctx_destroy', 'stp_last_error', 'stp_ctx_set_stream',
     'stp_ctx_synchronize', 'stp_band_upload', 'stp_band_pack', 'stp_band_nearest', 'stp_band_download', 'stp_band_wrap_device', 'stp_band_free',
-    'stp_frames_create', 'stp_frames_create_ex', 'stp_frames_info', 'stp_frames_free', 'stp_stripe_search', 'stp_dbg_stages', 'stp_dbg_set_sweep_slots',
+    'stp_frames_create', 'stp_frames_create_ex', 'stp_frames_info', 'stp_frames_free', 'stp_stripe_search', 'stp_stripe_search_begin', 'stp_stripe_search_count', 'stp_stripe_search_fetch',
+    'stp_stripe_search_cancel', 'stp_dbg_stages', 'stp_dbg_set_sweep_slots',
     'stp_set_profiling', 'stp_get_stats', 'stp_reset_stats',
 ]
 
@@ -82,6 +83,11 @@ def load():
     L.stp_frames_free.restype = None
     L.stp_stripe_search.argtypes = [vp, vp, C.POINTER(SearchParams), vp, C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.stp_dbg_stages.argtypes = [vp, vp, C.POINTER(SearchParams), C.c_int32, C.c_double, C.c_int32] + [vp] * 9
+    L.stp_stripe_search_begin.argtypes = [vp, vp, C.POINTER(SearchParams), vp, C.c_int32, C.POINTER(vp)]
+    L.stp_stripe_search_count.argtypes = [vp, vp, C.POINTER(C.c_int64)]
+    L.stp_stripe_search_fetch.argtypes = [vp, vp, vp, C.c_int64]
+    L.stp_stripe_search_cancel.argtypes = [vp, vp]
+    L.stp_stripe_search_cancel.restype = None
     L.stp_dbg_set_sweep_slots.argtypes = [vp, C.c_int32]
     L.stp_set_profiling.argtypes = [vp, C.c_int]
     L.stp_get_stats.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
@@ -257,6 +263,34 @@ class Band:
         return Frames(self, start, end, keep_all)
 
 
+class PendingSearch:
+    """A stripe search in flight (stp_search): wait() blocks until the device is done and returns the records."""
+
+    def __init__(self, frames, handle):
+        self.frames, self.ctx, self.h = frames, frames.ctx, handle
+
+    def wait(self):
+        if self.h is None:
+            raise RuntimeError('this search has already been fetched')
+        h, self.h = self.h, None
+        n = C.c_int64()
+        rc = self.ctx.L.stp_stripe_search_count(self.ctx.h, h, C.byref(n))
+        if rc != STP_OK:
+            self.ctx.L.stp_stripe_search_cancel(self.ctx.h, h)
+            self.ctx._chk(rc)
+        out = np.zeros(max(int(n.value), 1), dtype=REC_DTYPE)
+        self.ctx._chk(self.ctx.L.stp_stripe_search_fetch(self.ctx.h, h, _ptr(out), len(out)))
+        return out[:n.value]
+
+    def __del__(self):
+        try:
+            if self.h is not None and self.ctx.h:
+                self.ctx.L.stp_stripe_search_cancel(self.ctx.h, self.h)
+                self.h = None
+        except Exception:      # noqa: BLE001
+            pass
+
+
 class Frames:
     def __init__(self, band, start, end, keep_all=False):
         self.band, self.ctx = band, band.ctx
@@ -291,8 +325,9 @@ class Frames:
                          int(gr), gw.ctypes.data_as(C.POINTER(C.c_double)))
         return p, (bright, gw)
 
-    def stripe_search(self, M_levels, sigma=2.0, minH=10, maxW=8, bfilter=3, bright=None, gauss_w=None, capacity=None):
-        """Candidate stripes of every frame x level x brightness, as a structured array (REC_DTYPE)."""
+    def stripe_search_begin(self, M_levels, sigma=2.0, minH=10, maxW=8, bfilter=3, bright=None, gauss_w=None):
+        """Enqueue the search of every frame x level x brightness and return at once (stp_stripe_search_begin);
+        `.wait()` on the result gives the records.  Several searches may be in flight on one context."""
         M_levels = np.ascontiguousarray(M_levels, dtype=np.float64)
         if bright is None:
             bright = brightness_levels()
@@ -301,17 +336,13 @@ class Frames:
         else:
             gr = (len(gauss_w) - 1) // 2
         p, keep = self._params(minH, maxW, bfilter, bright, gauss_w, gr)
-        cap = capacity or max(1024, 64 * self.n * len(M_levels))
-        while True:
-            out = np.zeros(cap, dtype=REC_DTYPE)
-            cnt = C.c_int64()
-            rc = self.ctx.L.stp_stripe_search(self.ctx.h, self.h, C.byref(p), _ptr(M_levels), len(M_levels), _ptr(out),
-                                              cap, C.byref(cnt))
-            if rc == STP_E_CAPACITY and cnt.value > cap:
-                cap = int(cnt.value)
-                continue
-            self.ctx._chk(rc)
-            return out[:cnt.value]
+        h = C.c_void_p()
+        self.ctx._chk(self.ctx.L.stp_stripe_search_begin(self.ctx.h, self.h, C.byref(p), _ptr(M_levels), len(M_levels), C.byref(h)))
+        return PendingSearch(self, h)
+
+    def stripe_search(self, M_levels, sigma=2.0, minH=10, maxW=8, bfilter=3, bright=None, gauss_w=None, capacity=None):
+        """Candidate stripes of every frame x level x brightness, as a structured array (REC_DTYPE)."""
+        return self.stripe_search_begin(M_levels, sigma, minH, maxW, bfilter, bright, gauss_w).wait()
 
     def dbg_stages(self, f, M, bi, sigma=2.0, minH=10, maxW=8, bfilter=3, bright=None, gauss_w=None):
         """Per-stage arrays of one image (parity tests)."""
