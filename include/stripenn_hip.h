@@ -234,6 +234,13 @@ typedef struct {
 int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rects, int64_t n, double* out_mean,
                     double* out_sum);
 
+/* ---- heat-map plane of a window: seeimage (seeimage.py:74-85) -----------------------------------
+ * out[r * ncols + c] = clip((255 * (M - A[r][c]) / M) / 255, 0, 1) for the window A = M[row0:row0+nrows, col0:col0+ncols]
+ * of the resident band -- the image-build arithmetic of StripeSearch (getStripe.py:889-895) -- NaN pixels stay NaN.
+ * The caller stacks it as the green and blue channels under a constant red 1.  The window must lie inside the band. */
+int stp_window_plane(stp_ctx* ctx, const stp_band* band, int64_t row0, int32_t nrows, int64_t col0, int32_t ncols, double M,
+                     double* out);
+
 /* ---- order statistics of the positive pixels: getStripe.getQuantile_original ------------------
  * (getStripe.py:160-176: `np.quantile(mat[mat > 0], quantile)` over the whole chromosome.)
  * The host streams the chromosome in row strips (`stp_select_append`; non-positive and NaN entries

@@ -69,6 +69,7 @@ class HipBackend:
         L.stp_pvalue.argtypes = [vp, vp, vp, C.c_int32, vp, C.c_int64, vp]
         L.stp_stripiness.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
         L.stp_stripe_mean.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
+        L.stp_window_plane.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_double, vp]
         L.stp_remove_redundant.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
         L.stp_select_create.argtypes = [vp, C.POINTER(vp)]
         L.stp_select_append.argtypes = [vp, vp, vp, C.c_int64]
@@ -173,6 +174,12 @@ class HipBackend:
         if n:
             self.ctx._chk(self.ctx.L.stp_stripe_mean(self.ctx.h, band.h, _p(rects), n, _p(m), _p(s)))
         return m, s
+
+    def window_plane(self, band, row0, nrows, col0, ncols, M):
+        """Green = blue plane of seeimage's heat map of a window of the resident band (stp_window_plane)."""
+        out = np.empty((int(nrows), int(ncols)), np.float64)
+        self.ctx._chk(self.ctx.L.stp_window_plane(self.ctx.h, band.h, int(row0), int(nrows), int(col0), int(ncols), float(M), _p(out)))
+        return out
 
     # ---- redundancy filter
     def remove_redundant(self, p1, p2, p3, p4, h, w, key, by, order, b0, b1, b2):

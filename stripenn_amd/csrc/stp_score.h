@@ -453,6 +453,19 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
 }
 
 // ---------------------------------------------------------------------------------------------
+// seeimage.py:78-85 -- the green = blue plane of the heat map of one window, with StripeSearch's image arithmetic
+// (stp_gplane_px, getStripe.py:889-895): clip((255 * (M - A) / M) / 255, 0, 1); a NaN pixel stays NaN (the
+// reference's np.where / np.clip leave it alone; imshow draws it blank).  One lane per pixel, rows coalesced.
+__global__ __launch_bounds__(256) void k_window_plane(stp_bandref B, int64_t row0, int nrows, int64_t col0, int ncols, double M,
+                                                       double* __restrict__ out)
+{
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < (int64_t)nrows * ncols; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / ncols, c = i - r * ncols;
+        out[i] = stp_gplane_px(band_at(B, row0 + r, col0 + c), M);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // getStripe.getMean (getStripe.py:518-521): nanmean / nansum of the observed stripe pixels
 
 __global__ __launch_bounds__(256) void k_stripe_mean(stp_bandref B, const stp_rect* __restrict__ rc, double* __restrict__ out_mean,

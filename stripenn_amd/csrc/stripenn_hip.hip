@@ -1889,6 +1889,29 @@ int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rc, int6
 }
 
 
+int stp_window_plane(stp_ctx* ctx, const stp_band* band, int64_t row0, int32_t nrows, int64_t col0, int32_t ncols, double M,
+                     double* out)
+{
+    if (!ctx || !band || !out || nrows <= 0 || ncols <= 0) return STP_E_ARG;
+    if (row0 < 0 || col0 < 0 || row0 + nrows > band->nrows || col0 + ncols > band->nrows)
+        return set_err(ctx, STP_E_ARG, "window outside the chromosome");
+    if (col0 + ncols - 1 - row0 >= band->hw || row0 + nrows - 1 - col0 > band->hw)
+        return set_err(ctx, STP_E_ARG, "window leaves the +-halfwidth band; build a wider band");
+    HIPCHK(hipSetDevice(ctx->device));
+    dev_buf bO;
+    const size_t n = (size_t)nrows * ncols;
+    HIPCHK(bO.alloc(ctx, n * sizeof(double)));
+    {
+        prof_scope ps(ctx, "window_plane", 16.0 * (double)n, ctx->aux);
+        hipLaunchKernelGGL(k_window_plane, dim3((unsigned)std::min<size_t>((n + 255) / 256, 65535)), dim3(256), 0, ctx->aux, bref(band), row0,
+                           nrows, col0, ncols, M, (double*)bO.p);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, bO.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipStreamSynchronize(ctx->aux));
+    return STP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // order statistics of the positive pixels (getQuantile_original)
 struct stp_select {

@@ -1,8 +1,9 @@
 """`stripenn seeimage`: heat map of one genomic window at the given saturation quantiles
-(reference: seeimage.py:32-97).  The only heavy step -- the whole-chromosome quantile that sets the
-saturation level -- runs through the backend's exact GPU select like `compute` does; the window itself is a
-few hundred bins, coloured with the same arithmetic as StripeSearch's image build (getStripe.py:889-895:
-red = 1, green = blue = clip((255 * (M - A) / M) / 255, 0, 1))."""
+(reference: seeimage.py:32-97).  Both steps run on the device: the whole-chromosome quantile that sets the
+saturation level goes through the backend's exact select like `compute` does, and the window is coloured from the
+resident band by the image-build arithmetic of StripeSearch (stp_window_plane: getStripe.py:889-895, red = 1,
+green = blue = clip((255 * (M - A) / M) / 255, 0, 1)); matplotlib only draws the array.  `window_rgb` is the same
+arithmetic in numpy (what the reference's lines 78-85 compute), kept as the checker of the GPU test."""
 import sys
 
 import numpy as np
@@ -42,17 +43,22 @@ def seeimage(cool, position, maxpixel, norm, out, slow, seed, backend=None, devi
         sys.exit('Exit: All chromosomes are shorter than 50kb.')
     sel = Lib.matrix(balance=norm)
     resol = Lib.binsize
+    # cooler's extent of the window; the band must hold every pixel of it
+    rng = position.split(':')[1].replace(',', '')
+    w0, w1 = getStripe._extent(int(rng.split('-')[0]), int(rng.split('-')[1]), resol)
+    hw = max(getStripe.HALFWIDTH, -(-(w1 - w0 + 1) // 64) * 64)
     obj = getStripe.getStripe(sel, resol, 10, 8, 2.5, all_names, [chrom], all_sizes, sizes[chrom], 2, 3, seed,
-                              backend=backend, device=device)
+                              backend=backend, device=device, halfwidth=hw)
+    written = []
     try:
         MP = (obj.getQuantile_slow if slow else obj.getQuantile_original)(Lib, [chrom], levels)
+        band = obj._band(chrom)
+        planes = [obj.backend.window_plane(band, w0, w1 - w0, w0, w1 - w0, MP[chrom][i]) for i in range(len(levels))]
     finally:
         if backend is None:
             obj.backend.close()
-    A = sel.fetch(position, position)
-    written = []
     for i, q in enumerate(levels):
-        img = window_rgb(A, MP[chrom][i])
+        img = np.stack([np.ones_like(planes[i]), planes[i], planes[i]], axis=-1)
         ax = plt.subplot(111)
         plt.imshow(img)
         plt.title(position)

@@ -126,6 +126,10 @@ class OracleBackend:
         r = [O.stripe_mean_one(band.block(int(q['row0']), int(q['row1']), int(q['col0']), int(q['col1']))) for q in rects]
         return np.array([a for a, _ in r]), np.array([b for _, b in r])
 
+    def window_plane(self, band, row0, nrows, col0, ncols, M):
+        from stripenn_amd.seeimage import window_rgb          # the reference's colour arithmetic (seeimage.py:78-85) in numpy
+        return window_rgb(band.block(row0, row0 + nrows, col0, col0 + ncols), M)[..., 1]
+
     def close(self):
         pass
 

