@@ -320,7 +320,7 @@ def main():
             if k.get('valu_insts') is not None and k.get('image_px'):
                 per_px = k['valu_insts'] / k['image_px']
                 step_insts = per_px * image_px                      # wave-instructions of this kernel per step
-                valu = {'kernel': 'k_' + dom, 'wave_insts_per_image_px': round(per_px, 1),
+                valu = {'kernel': 'k_' + dom, 'wave_insts_per_image_px': round(per_px, 3), 'lane_insts_per_image_px': round(per_px * 64, 1),
                         'cycles_per_inst': 4, 'peak_wave_insts_per_s': N_SIMD * CLOCK_HZ / 4,
                         'achieved_wave_insts_per_s': round(step_insts / (d['ms'] / args.steps * 1e-3), 0),
                         'frac': round(step_insts / (d['ms'] / args.steps * 1e-3) / (N_SIMD * CLOCK_HZ / 4), 4),
