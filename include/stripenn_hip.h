@@ -72,6 +72,13 @@ int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_
 int stp_band_pack(stp_ctx* ctx, const int64_t* bin1_id, const int64_t* bin2_id, const int32_t* count, int64_t npix,
                   const double* weight, int64_t nbins_total, int64_t bin_lo, int64_t nrows, int32_t halfwidth,
                   stp_band** out);
+/* stp_band_pack that ALSO appends the chromosome's balanced pixel values to an order-statistic select (see
+ * stp_select_append_pixels below; `sel` may be NULL): the maxpixel quantile (getStripe.py:160-176) and the band then
+ * share one trip of the pixel table over PCIe.  Pass every cis pixel of the chromosome. */
+typedef struct stp_select stp_select;
+int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1_id, const int64_t* bin2_id, const int32_t* count, int64_t npix,
+                         const double* weight, int64_t nbins_total, int64_t bin_lo, int64_t nrows, int32_t halfwidth,
+                         stp_select* sel, stp_band** out);
 /* For a band built by stp_band_pack: the distance from every bin to the nearest stored pixel with a positive
  * value in its row of the symmetric matrix, to the right (column >= row; 0 = a positive diagonal pixel) and to
  * the left (column < row); INT32_MAX where there is none.  Every cis pixel handed to stp_band_pack takes part,
@@ -247,7 +254,6 @@ int stp_window_plane(stp_ctx* ctx, const stp_band* band, int64_t row0, int32_t n
  * are ignored, exactly like `mat[mat > 0]`), so the dense chromosome (12 GB for chr1 at 5 kb) never
  * exists; `stp_select_ranks` returns the exact order statistics a[rank] (0-based, ascending) by
  * radix select; numpy's interpolation between them is applied by the caller (stripenn_amd/getStripe.py). */
-typedef struct stp_select stp_select;
 int stp_select_create(stp_ctx* ctx, stp_select** out);
 int stp_select_append(stp_ctx* ctx, stp_select* sel, const double* values_host, int64_t n);
 /* Append the balanced values of cooler pixels (bin1_id <= bin2_id, count; value = count * (bias[bin1] * bias[bin2]), or

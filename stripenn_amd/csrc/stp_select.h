@@ -25,10 +25,11 @@ __global__ __launch_bounds__(256) void k_sel_count(const double* __restrict__ v,
 // balanced value of every stored pixel, twice for off-diagonal ones (slot 2p+1 stays 0 = ignored on the diagonal)
 __global__ __launch_bounds__(256) void k_sel_pixel_values(const int64_t* __restrict__ b1, const int64_t* __restrict__ b2,
                                                            const int32_t* __restrict__ cnt, long long n,
-                                                           const double* __restrict__ w, long long nbins, double* __restrict__ out)
+                                                           const double* __restrict__ w /* bias of bins [lo, lo + nbins) */,
+                                                           long long nbins, double* __restrict__ out, long long lo)
 {
     for (long long p = blockIdx.x * 256ll + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
-        const long long i = b1[p], j = b2[p];
+        const long long i = b1[p] - lo, j = b2[p] - lo;
         double v = (double)cnt[p];
         if (w) v = (i >= 0 && j >= 0 && i < nbins && j < nbins) ? v * (w[i] * w[j]) : 0.0;
         out[2 * p] = v;

@@ -1163,8 +1163,22 @@ struct dev_buf {                      // per-call device buffer, recycled throug
     hipError_t alloc(stp_ctx* ctx, size_t bytes) { c = ctx; n = bytes; return pool_alloc(ctx, bytes, &p); }
 };
 
+struct stp_select {
+    std::vector<std::pair<double*, long long>> chunks;   // device buffers
+    long long npos = -1;                                 // cached count of positive values
+    stp_sel_state* state = nullptr;
+};
+static unsigned sel_grid(long long n);
+
 int stp_band_pack(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2, const int32_t* count, int64_t npix,
                   const double* weight, int64_t nbins_total, int64_t lo, int64_t nrows, int32_t hw, stp_band** out)
+{
+    return stp_band_pack_select(ctx, bin1, bin2, count, npix, weight, nbins_total, lo, nrows, hw, nullptr, out);
+}
+
+int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2, const int32_t* count, int64_t npix,
+                         const double* weight, int64_t nbins_total, int64_t lo, int64_t nrows, int32_t hw, stp_select* sel,
+                         stp_band** out)
 {
     if (!ctx || !out || npix < 0 || (npix > 0 && (!bin1 || !bin2 || !count))) return STP_E_ARG;
     if (lo < 0 || (weight && lo + nrows > nbins_total)) return set_err(ctx, STP_E_ARG, "bin range outside the weight column");
@@ -1206,6 +1220,21 @@ int stp_band_pack(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2, const 
                                (const int32_t*)bc.p, n, weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d, near);
         }
         e = hipGetLastError();
+        if (e == hipSuccess && sel) {
+            // the same staged columns also feed the quantile's order-statistic select (values as the dense symmetric
+            // matrix holds them: off-diagonal pixels twice), so the table crosses PCIe once
+            double* vals = nullptr;
+            e = hipMalloc((void**)&vals, (size_t)n * 2 * sizeof(double));
+            if (e == hipSuccess) {
+                prof_scope ps(ctx, "select_pixels", 36.0 * n);
+                hipLaunchKernelGGL(k_sel_pixel_values, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)b1.p,
+                                   (const int64_t*)b2.p, (const int32_t*)bc.p, (long long)n, weight ? (const double*)bw.p : nullptr,
+                                   (long long)nrows, vals, (long long)lo);
+                e = hipGetLastError();
+                sel->chunks.push_back(std::make_pair(vals, (long long)(2 * n)));
+                sel->npos = -1;
+            }
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the staging buffers are reused
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1914,11 +1943,6 @@ int stp_window_plane(stp_ctx* ctx, const stp_band* band, int64_t row0, int32_t n
 
 // ---------------------------------------------------------------------------------------------
 // order statistics of the positive pixels (getQuantile_original)
-struct stp_select {
-    std::vector<std::pair<double*, long long>> chunks;   // device buffers
-    long long npos = -1;                                 // cached count of positive values
-    stp_sel_state* state = nullptr;
-};
 
 int stp_select_create(stp_ctx* ctx, stp_select** out)
 {
@@ -1955,8 +1979,6 @@ int stp_select_append(stp_ctx* ctx, stp_select* s, const double* values_host, in
     return STP_OK;
 }
 
-static unsigned sel_grid(long long n);
-
 int stp_select_append_pixels(stp_ctx* ctx, stp_select* s, const int64_t* bin1, const int64_t* bin2, const int32_t* count,
                              int64_t npix, const double* weight, int64_t nbins_total)
 {
@@ -1984,7 +2006,7 @@ int stp_select_append_pixels(stp_ctx* ctx, stp_select* s, const int64_t* bin1, c
             prof_scope ps(ctx, "select_pixels", 36.0 * n);
             hipLaunchKernelGGL(k_sel_pixel_values, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)d1.p,
                                (const int64_t*)d2.p, (const int32_t*)dc.p, (long long)n, weight ? (const double*)dw.p : nullptr,
-                               (long long)nbins_total, out);
+                               (long long)nbins_total, out, 0ll);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the staging buffers are reused

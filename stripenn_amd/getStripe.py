@@ -107,7 +107,7 @@ class getStripe:
     def _nbins(self, chrom):
         return int(math.ceil(int(self.chromnames2sizes[str(chrom)]) / self.resol))
 
-    def _band(self, chrom, whole=True):
+    def _band(self, chrom, whole=True, select=None):
         """Resident band of one chromosome; built from row strips fetched through the selector, or packed on the
         device from the pixel table.  whole=False (extract and the per-stripe kernels) accepts a band that holds
         only the rows of the chromosome's frame span; the whole-chromosome steps (expected values, background)
@@ -134,7 +134,8 @@ class getStripe:
             if (ra, rb) != (0, nb):                                # stored pixels (i <= j) that land in rows [ra, rb)
                 a, b = np.searchsorted(px['bin1'], [px['lo'] + ra - hw, px['lo'] + rb], side='left')
                 px = dict(px, bin1=px['bin1'][a:b], bin2=px['bin2'][a:b], count=px['count'][a:b])
-            self._bands[chrom] = self.backend.pack_chrom(px, hw)
+                select = None                                      # (a partial band does not see every pixel)
+            self._bands[chrom] = self.backend.pack_chrom(px, hw, select) if select is not None else self.backend.pack_chrom(px, hw)
             self.timing['band_build_s'] = self.timing.get('band_build_s', 0.0) + time.time() - t0
             return self._bands[chrom]
         band = np.zeros((nb, 2 * hw), dtype=np.float64)
@@ -183,9 +184,14 @@ class getStripe:
             sel = self.backend.select_open()
             try:
                 if hasattr(self.unbalLib, 'chrom_pixels'):
-                    # pixel-table source: the dense symmetric matrix holds every off-diagonal pixel twice
-                    px = self.unbalLib.chrom_pixels(CHROM)
-                    self.backend.select_append_pixels(sel, px['bin1'], px['bin2'], px['count'], px['weight'])
+                    # pixel-table source: the dense symmetric matrix holds every off-diagonal pixel twice.  When the
+                    # chromosome's band is still to be built, one pass over the table columns (one trip over PCIe)
+                    # packs the band AND appends the values to the select.
+                    if str(CHROM) not in self._bands and hasattr(self.backend, 'pack_chrom'):
+                        self._band(CHROM, whole=True, select=sel)
+                    else:
+                        px = self.unbalLib.chrom_pixels(CHROM)
+                        self.backend.select_append_pixels(sel, px['bin1'], px['bin2'], px['count'], px['weight'])
                     nb = 0
                 strip = max(1, int(16e6 // max(nb, 1)))                 # <= 128 MB of float64 per fetch
                 for r0 in range(0, nb, strip):

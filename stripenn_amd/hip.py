@@ -18,7 +18,7 @@ _ERRNAMES = {-1: 'STP_E_ARG', -2: 'STP_E_CAPACITY', -3: 'STP_E_HIP', -4: 'STP_E_
 
 EXPORTS = [
     'stp_version', 'stp_ctx_create', 'stp_ctx_destroy', 'stp_last_error', 'stp_ctx_set_stream',
-    'stp_ctx_synchronize', 'stp_band_upload', 'stp_band_pack', 'stp_band_nearest', 'stp_band_download', 'stp_band_wrap_device', 'stp_band_free',
+    'stp_ctx_synchronize', 'stp_band_upload', 'stp_band_pack', 'stp_band_pack_select', 'stp_band_nearest', 'stp_band_download', 'stp_band_wrap_device', 'stp_band_free',
     'stp_frames_create', 'stp_frames_create_ex', 'stp_frames_info', 'stp_frames_free', 'stp_stripe_search', 'stp_stripe_search_begin', 'stp_stripe_search_count', 'stp_stripe_search_fetch',
     'stp_stripe_search_cancel', 'stp_dbg_stages', 'stp_dbg_set_sweep_slots',
     'stp_set_profiling', 'stp_get_stats', 'stp_reset_stats',
@@ -72,6 +72,7 @@ def load():
     L.stp_band_upload.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.stp_band_wrap_device.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.stp_band_pack.argtypes = [vp, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.stp_band_pack_select.argtypes = [vp, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, vp, C.POINTER(vp)]
     L.stp_band_download.argtypes = [vp, vp, vp]
     L.stp_band_nearest.argtypes = [vp, vp, vp, vp]
     L.stp_band_free.argtypes = [vp, vp]
@@ -186,8 +187,9 @@ class Context:
             raise ValueError('band width must be 2*halfwidth (columns d = -hw .. hw-1), got %d' % W)
         return Band(self, band_host=band, nrows=nrows, hw=W // 2)
 
-    def band_pack(self, bin1, bin2, count, weight, lo, nrows, hw):
-        """Band of bins [lo, lo + nrows) built on the device from cooler's pixel table (stp_band_pack)."""
+    def band_pack(self, bin1, bin2, count, weight, lo, nrows, hw, select=None):
+        """Band of bins [lo, lo + nrows) built on the device from cooler's pixel table (stp_band_pack); with `select`
+        (an stp_select handle) the same pass appends the balanced pixel values to it (stp_band_pack_select)."""
         bin1 = np.ascontiguousarray(bin1, dtype=np.int64)
         bin2 = np.ascontiguousarray(bin2, dtype=np.int64)
         count = np.ascontiguousarray(count, dtype=np.int32)
@@ -195,8 +197,8 @@ class Context:
             raise ValueError('pixel columns differ in length')
         w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
         h = C.c_void_p()
-        self._chk(self.L.stp_band_pack(self.h, _ptr(bin1), _ptr(bin2), _ptr(count), len(bin1), _ptr(w),
-                                       0 if w is None else len(w), int(lo), int(nrows), int(hw), C.byref(h)))
+        self._chk(self.L.stp_band_pack_select(self.h, _ptr(bin1), _ptr(bin2), _ptr(count), len(bin1), _ptr(w),
+                                              0 if w is None else len(w), int(lo), int(nrows), int(hw), select, C.byref(h)))
         return Band(self, handle=h, nrows=nrows, hw=hw)
 
     def band_wrap(self, dptr, nrows, hw, keepalive=None):

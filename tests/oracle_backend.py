@@ -59,7 +59,9 @@ class OracleBackend:
     def open_chrom(self, band_host):
         return _Band(band_host)
 
-    def pack_chrom(self, px, hw):
+    def pack_chrom(self, px, hw, select=None):
+        if select is not None:
+            self.select_append_pixels(select, px['bin1'], px['bin2'], px['count'], px['weight'])
         b = _Band(O.band_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], hw))
         b.near = O.nearest_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'])
         return b
