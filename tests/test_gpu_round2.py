@@ -409,3 +409,33 @@ def test_chr1_size_search_is_deterministic_and_span_invariant(hip_ctx):
     got = np.concatenate(got)
     assert got.tobytes() == a.tobytes()
     fr.close(); band.close()
+
+
+# --------------------------------------------------------------------------------------------- configs[3]: compute, then score
+def test_score_rescoring_reproduces_the_compute_columns(tmp_path):
+    """configs[3]'s flow: `compute` calls stripes, `score` re-scores the written table.  With the same seed and
+    numcores the background tables are the same, so the added p-value and Stripiness columns must equal the ones
+    `compute` wrote for the same stripes (a size-independent idempotence property; checked here on the
+    six-chromosome genome, and on the whole mm10-size genome by tools/probe_genome.py)."""
+    import stripenn_amd.score as score_mod
+    from stripenn_amd import backend as BK, io as sio
+    names, chroms, table = _six_chrom_table()
+    hb = BK.HipBackend(0)
+    out = str(tmp_path / 'c')
+    _compute(table, out, backend=hb, numcores=4)
+    orig = score_mod.open_matrix
+    score_mod.open_matrix = lambda cool: sio.pixel_matrix(table)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = score_mod.getScore('pixels:in-memory', os.path.join(out, 'result_unfiltered.tsv'), 'weight', 4, 123456789,
+                                     str(tmp_path / 'scores.tsv'), backend=hb)
+    finally:
+        score_mod.open_matrix = orig
+    hb.close()
+    assert len(res) > 100
+    # (score reads the table with pandas' default float parser like the reference, score.py:11, which may be 1 ulp
+    #  off; the columns compute wrote are compared as exactly parsed numbers)
+    ref = pd.read_csv(os.path.join(out, 'result_unfiltered.tsv'), sep='\t', float_precision='round_trip')
+    assert np.array_equal(res['pvalue_added'].to_numpy(), ref['pvalue'].to_numpy())
+    assert np.array_equal(res['Stripiness_added'].to_numpy(), ref['Stripiness'].to_numpy(), equal_nan=True)
+    assert np.allclose(res['O_Mean_added'].to_numpy(), ref['Mean'].to_numpy(), rtol=1e-9, atol=0)

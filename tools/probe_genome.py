@@ -4,15 +4,17 @@ synthetic pixel table held in memory, the unmodified driver stripenn_amd.stripen
 import contextlib, io as _io, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from stripenn_amd import getStripe, io, pixels, stripenn, synth
+import torch
+from stripenn_amd import getStripe, io, pixels, stripenn, synth, synth_device
 
 MM10 = [195471971, 182113224, 160039680, 156508116, 151834684, 149736546, 145441459, 129401213, 124595110, 130694993,
         122082543, 120129022, 120421639, 124902244, 104043685, 98207768, 94987271, 90702639, 61431566, 171031299]
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 names = ['chr%d' % (i + 1) for i in range(19)] + ['chrX']
 t0 = time.time()
-chroms = {n: synth.SynthChrom(int(-(-s * scale // 5000)), 1 + i) for i, (n, s) in enumerate(zip(names, MM10))}
-table = pixels.PixelTable.from_synth(names, chroms, 5000)
+torch.cuda.init()
+chroms = {n: synth_device.DeviceChrom(int(-(-s * scale // 5000)), 1 + i, torch.device('cuda', 0)) for i, (n, s) in enumerate(zip(names, MM10))}
+table = synth_device.pixel_table(names, chroms, 5000)          # synth.py's pixel function evaluated on the device
 print('genome: %d bins, %d stored pixels, table built in %.0f s' % (table.chrom_offset[-1], len(table.count), time.time() - t0), flush=True)
 stripenn.open_matrix = lambda cool: io.pixel_matrix(table)
 acc = {}
@@ -35,3 +37,18 @@ for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
     print('  %-22s %.2f s (inclusive)' % (k, v))
 print(open('gpurun_out/genome_out/result_filtered.tsv').read().count('\n') - 1, 'filtered stripes;',
       open('gpurun_out/genome_out/result_unfiltered.tsv').read().count('\n') - 1, 'unfiltered')
+
+# configs[3]'s second half: `stripenn score` re-scoring of the called stripes, on the same genome.  Same seed and
+# numcores -> same background tables -> the added columns must reproduce the ones compute wrote.
+import pandas as pd
+from stripenn_amd import score as score_mod
+score_mod.open_matrix = lambda cool: io.pixel_matrix(table)
+t0 = time.time()
+with contextlib.redirect_stdout(_io.StringIO()):
+    res = score_mod.getScore('pixels:in-memory', 'gpurun_out/genome_out/result_unfiltered.tsv', 'weight', 8, 123456789,
+                             'gpurun_out/genome_out/scores.tsv')
+dt = time.time() - t0
+ref = pd.read_csv('gpurun_out/genome_out/result_unfiltered.tsv', sep='\t', float_precision='round_trip')   # exactly parsed
+print('score: %.1f s for %d stripes; p-values identical to compute: %s; Stripiness identical: %s'
+      % (dt, len(res), bool(np.array_equal(res['pvalue_added'].to_numpy(), ref['pvalue'].to_numpy())),
+         bool(np.array_equal(res['Stripiness_added'].to_numpy(), ref['Stripiness'].to_numpy(), equal_nan=True))))
