@@ -76,9 +76,11 @@ int stp_band_pack(stp_ctx* ctx, const int64_t* bin1_id, const int64_t* bin2_id, 
  * stp_select_append_pixels below; `sel` may be NULL): the maxpixel quantile (getStripe.py:160-176) and the band then
  * share one trip of the pixel table over PCIe.  Pass every cis pixel of the chromosome. */
 typedef struct stp_select stp_select;
-int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1_id, const int64_t* bin2_id, const int32_t* count, int64_t npix,
-                         const double* weight, int64_t nbins_total, int64_t bin_lo, int64_t nrows, int32_t halfwidth,
-                         stp_select* sel, stp_band** out);
+#define STP_COUNT_I32 0     /* pixels/count as int32 (cooler's default) */
+#define STP_COUNT_F64 1     /* ... as float64: coolers written with --count-as-float, merged or scaled ones */
+int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1_id, const int64_t* bin2_id, const void* count, int32_t count_type,
+                         int64_t npix, const double* weight, int64_t nbins_total, int64_t bin_lo, int64_t nrows,
+                         int32_t halfwidth, stp_select* sel, stp_band** out);
 /* For a band built by stp_band_pack: the distance from every bin to the nearest stored pixel with a positive
  * value in its row of the symmetric matrix, to the right (column >= row; 0 = a positive diagonal pixel) and to
  * the left (column < row); INT32_MAX where there is none.  Every cis pixel handed to stp_band_pack takes part,
@@ -262,6 +264,9 @@ int stp_select_append(stp_ctx* ctx, stp_select* sel, const double* values_host, 
  * device from the table columns; nothing dense and no host-side product array exists. */
 int stp_select_append_pixels(stp_ctx* ctx, stp_select* sel, const int64_t* bin1_id, const int64_t* bin2_id,
                              const int32_t* count, int64_t npix, const double* weight, int64_t nbins_total);
+int stp_select_append_pixels_ex(stp_ctx* ctx, stp_select* sel, const int64_t* bin1_id, const int64_t* bin2_id,
+                                const void* count, int32_t count_type /* STP_COUNT_* */, int64_t npix, const double* weight,
+                                int64_t nbins_total);
 int stp_select_count(stp_ctx* ctx, stp_select* sel, int64_t* n_positive);
 int stp_select_ranks(stp_ctx* ctx, stp_select* sel, const int64_t* ranks, int32_t nranks, double* out);
 void stp_select_free(stp_ctx* ctx, stp_select* sel);

@@ -73,7 +73,7 @@ class HipBackend:
         L.stp_remove_redundant.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
         L.stp_select_create.argtypes = [vp, C.POINTER(vp)]
         L.stp_select_append.argtypes = [vp, vp, vp, C.c_int64]
-        L.stp_select_append_pixels.argtypes = [vp, vp, vp, vp, vp, C.c_int64, vp, C.c_int64]
+        L.stp_select_append_pixels_ex.argtypes = [vp, vp, vp, vp, vp, C.c_int32, C.c_int64, vp, C.c_int64]
         L.stp_select_count.argtypes = [vp, vp, C.POINTER(C.c_int64)]
         L.stp_select_ranks.argtypes = [vp, vp, vp, C.c_int32, vp]
         L.stp_select_free.argtypes = [vp, vp]
@@ -210,11 +210,11 @@ class HipBackend:
     def select_append_pixels(self, sel, bin1, bin2, count, weight):
         """Balanced values of stored pixels, off-diagonal ones twice, formed on the device (stp_select_append_pixels)."""
         bin1 = np.ascontiguousarray(bin1, dtype=np.int64); bin2 = np.ascontiguousarray(bin2, dtype=np.int64)
-        count = np.ascontiguousarray(count, dtype=np.int32)
+        count, ctype = hip.count_column(count)
         w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
         if len(bin1):
-            self.ctx._chk(self.ctx.L.stp_select_append_pixels(self.ctx.h, sel, _p(bin1), _p(bin2), _p(count), len(bin1),
-                                                              None if w is None else _p(w), 0 if w is None else len(w)))
+            self.ctx._chk(self.ctx.L.stp_select_append_pixels_ex(self.ctx.h, sel, _p(bin1), _p(bin2), _p(count), ctype, len(bin1),
+                                                                 None if w is None else _p(w), 0 if w is None else len(w)))
 
     def select_count(self, sel):
         n = C.c_int64()

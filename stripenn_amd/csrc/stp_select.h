@@ -23,8 +23,9 @@ __global__ __launch_bounds__(256) void k_sel_count(const double* __restrict__ v,
 }
 
 // balanced value of every stored pixel, twice for off-diagonal ones (slot 2p+1 stays 0 = ignored on the diagonal)
+template <typename CT>     // pixels/count as stored: int32, or float64 (coolers written with --count-as-float, merged / scaled ones)
 __global__ __launch_bounds__(256) void k_sel_pixel_values(const int64_t* __restrict__ b1, const int64_t* __restrict__ b2,
-                                                           const int32_t* __restrict__ cnt, long long n,
+                                                           const CT* __restrict__ cnt, long long n,
                                                            const double* __restrict__ w /* bias of bins [lo, lo + nbins) */,
                                                            long long nbins, double* __restrict__ out, long long lo)
 {

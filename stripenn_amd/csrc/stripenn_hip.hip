@@ -718,8 +718,9 @@ __global__ __launch_bounds__(1024) void k_compact_recs(const stp_drec* __restric
 // near[0..nrows) / near[nrows..2 nrows): distance from each bin to the nearest stored pixel with a positive value
 // in its row of the symmetric matrix, to the right (column >= row) / to the left (column < row) -- every cis pixel
 // takes part, also those beyond the band's halfwidth.
+template <typename CT>     // pixels/count as stored: int32 or float64
 __global__ __launch_bounds__(256) void k_band_pack(const int64_t* __restrict__ bin1, const int64_t* __restrict__ bin2,
-                                                    const int32_t* __restrict__ count, int64_t npix,
+                                                    const CT* __restrict__ count, int64_t npix,
                                                     const double* __restrict__ wloc /* bias of [lo, lo+nrows) or null */,
                                                     int64_t lo, int64_t nrows, int W, int hw, double* __restrict__ band,
                                                     int32_t* __restrict__ near)
@@ -1173,13 +1174,16 @@ static unsigned sel_grid(long long n);
 int stp_band_pack(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2, const int32_t* count, int64_t npix,
                   const double* weight, int64_t nbins_total, int64_t lo, int64_t nrows, int32_t hw, stp_band** out)
 {
-    return stp_band_pack_select(ctx, bin1, bin2, count, npix, weight, nbins_total, lo, nrows, hw, nullptr, out);
+    return stp_band_pack_select(ctx, bin1, bin2, count, STP_COUNT_I32, npix, weight, nbins_total, lo, nrows, hw, nullptr, out);
 }
 
-int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2, const int32_t* count, int64_t npix,
-                         const double* weight, int64_t nbins_total, int64_t lo, int64_t nrows, int32_t hw, stp_select* sel,
-                         stp_band** out)
+int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2, const void* count_v, int32_t count_type,
+                         int64_t npix, const double* weight, int64_t nbins_total, int64_t lo, int64_t nrows, int32_t hw,
+                         stp_select* sel, stp_band** out)
 {
+    if (count_type != STP_COUNT_I32 && count_type != STP_COUNT_F64) return set_err(ctx, STP_E_ARG, "count_type must be STP_COUNT_I32 or STP_COUNT_F64");
+    const size_t csz = count_type == STP_COUNT_F64 ? sizeof(double) : sizeof(int32_t);
+    const char* count = (const char*)count_v;
     if (!ctx || !out || npix < 0 || (npix > 0 && (!bin1 || !bin2 || !count))) return STP_E_ARG;
     if (lo < 0 || (weight && lo + nrows > nbins_total)) return set_err(ctx, STP_E_ARG, "bin range outside the weight column");
     int rc = check_hw(ctx, nrows, hw);
@@ -1203,7 +1207,7 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
     if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)near, 0x7FFFFFFF, (size_t)nrows * 2, ctx->stream);
     if (e == hipSuccess && nch) e = b1.alloc(ctx, (size_t)nch * sizeof(int64_t));
     if (e == hipSuccess && nch) e = b2.alloc(ctx, (size_t)nch * sizeof(int64_t));
-    if (e == hipSuccess && nch) e = bc.alloc(ctx, (size_t)nch * sizeof(int32_t));
+    if (e == hipSuccess && nch) e = bc.alloc(ctx, (size_t)nch * csz);
     if (e == hipSuccess && weight) e = bw.alloc(ctx, (size_t)nrows * sizeof(double));
     if (e == hipSuccess && weight)
         e = hipMemcpyAsync(bw.p, weight + lo, (size_t)nrows * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
@@ -1211,13 +1215,17 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
         const int64_t n = npix - p0 < CH ? npix - p0 : CH;
         e = hipMemcpyAsync(b1.p, bin1 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(b2.p, bin2 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(bc.p, count + p0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(bc.p, count + (size_t)p0 * csz, (size_t)n * csz, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) break;
         {
             prof_scope ps(ctx, "band_pack", (double)n * 36.0);    // 20 B of table read + two 8 B cells written
             const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 64);
-            hipLaunchKernelGGL(k_band_pack, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)b1.p, (const int64_t*)b2.p,
-                               (const int32_t*)bc.p, n, weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d, near);
+            if (count_type == STP_COUNT_F64)
+                hipLaunchKernelGGL(k_band_pack<double>, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)b1.p, (const int64_t*)b2.p,
+                                   (const double*)bc.p, n, weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d, near);
+            else
+                hipLaunchKernelGGL(k_band_pack<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)b1.p, (const int64_t*)b2.p,
+                                   (const int32_t*)bc.p, n, weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d, near);
         }
         e = hipGetLastError();
         if (e == hipSuccess && sel) {
@@ -1227,9 +1235,14 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
             e = hipMalloc((void**)&vals, (size_t)n * 2 * sizeof(double));
             if (e == hipSuccess) {
                 prof_scope ps(ctx, "select_pixels", 36.0 * n);
-                hipLaunchKernelGGL(k_sel_pixel_values, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)b1.p,
-                                   (const int64_t*)b2.p, (const int32_t*)bc.p, (long long)n, weight ? (const double*)bw.p : nullptr,
-                                   (long long)nrows, vals, (long long)lo);
+                if (count_type == STP_COUNT_F64)
+                    hipLaunchKernelGGL(k_sel_pixel_values<double>, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)b1.p,
+                                       (const int64_t*)b2.p, (const double*)bc.p, (long long)n, weight ? (const double*)bw.p : nullptr,
+                                       (long long)nrows, vals, (long long)lo);
+                else
+                    hipLaunchKernelGGL(k_sel_pixel_values<int32_t>, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)b1.p,
+                                       (const int64_t*)b2.p, (const int32_t*)bc.p, (long long)n, weight ? (const double*)bw.p : nullptr,
+                                       (long long)nrows, vals, (long long)lo);
                 e = hipGetLastError();
                 sel->chunks.push_back(std::make_pair(vals, (long long)(2 * n)));
                 sel->npos = -1;
@@ -1982,6 +1995,15 @@ int stp_select_append(stp_ctx* ctx, stp_select* s, const double* values_host, in
 int stp_select_append_pixels(stp_ctx* ctx, stp_select* s, const int64_t* bin1, const int64_t* bin2, const int32_t* count,
                              int64_t npix, const double* weight, int64_t nbins_total)
 {
+    return stp_select_append_pixels_ex(ctx, s, bin1, bin2, count, STP_COUNT_I32, npix, weight, nbins_total);
+}
+
+int stp_select_append_pixels_ex(stp_ctx* ctx, stp_select* s, const int64_t* bin1, const int64_t* bin2, const void* count_v,
+                                int32_t count_type, int64_t npix, const double* weight, int64_t nbins_total)
+{
+    if (count_type != STP_COUNT_I32 && count_type != STP_COUNT_F64) return set_err(ctx, STP_E_ARG, "count_type must be STP_COUNT_I32 or STP_COUNT_F64");
+    const size_t csz = count_type == STP_COUNT_F64 ? sizeof(double) : sizeof(int32_t);
+    const char* count = (const char*)count_v;
     if (!ctx || !s || npix < 0 || (npix > 0 && (!bin1 || !bin2 || !count)) || (weight && nbins_total <= 0)) return STP_E_ARG;
     if (npix == 0) return STP_OK;
     HIPCHK(hipSetDevice(ctx->device));
@@ -1990,7 +2012,7 @@ int stp_select_append_pixels(stp_ctx* ctx, stp_select* s, const int64_t* bin1, c
     dev_buf d1, d2, dc, dw;
     HIPCHK(d1.alloc(ctx, (size_t)nch * sizeof(int64_t)));
     HIPCHK(d2.alloc(ctx, (size_t)nch * sizeof(int64_t)));
-    HIPCHK(dc.alloc(ctx, (size_t)nch * sizeof(int32_t)));
+    HIPCHK(dc.alloc(ctx, (size_t)nch * csz));
     if (weight) {
         HIPCHK(dw.alloc(ctx, (size_t)nbins_total * sizeof(double)));
         HIPCHK(hipMemcpyAsync(dw.p, weight, (size_t)nbins_total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -2001,12 +2023,17 @@ int stp_select_append_pixels(stp_ctx* ctx, stp_select* s, const int64_t* bin1, c
         HIPCHK(hipMalloc((void**)&out, (size_t)n * 2 * sizeof(double)));
         hipError_t e = hipMemcpyAsync(d1.p, bin1 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d2.p, bin2 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(dc.p, count + p0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dc.p, count + (size_t)p0 * csz, (size_t)n * csz, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
             prof_scope ps(ctx, "select_pixels", 36.0 * n);
-            hipLaunchKernelGGL(k_sel_pixel_values, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)d1.p,
-                               (const int64_t*)d2.p, (const int32_t*)dc.p, (long long)n, weight ? (const double*)dw.p : nullptr,
-                               (long long)nbins_total, out, 0ll);
+            if (count_type == STP_COUNT_F64)
+                hipLaunchKernelGGL(k_sel_pixel_values<double>, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)d1.p,
+                                   (const int64_t*)d2.p, (const double*)dc.p, (long long)n, weight ? (const double*)dw.p : nullptr,
+                                   (long long)nbins_total, out, 0ll);
+            else
+                hipLaunchKernelGGL(k_sel_pixel_values<int32_t>, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)d1.p,
+                                   (const int64_t*)d2.p, (const int32_t*)dc.p, (long long)n, weight ? (const double*)dw.p : nullptr,
+                                   (long long)nbins_total, out, 0ll);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the staging buffers are reused

@@ -72,7 +72,7 @@ def load():
     L.stp_band_upload.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.stp_band_wrap_device.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.stp_band_pack.argtypes = [vp, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(vp)]
-    L.stp_band_pack_select.argtypes = [vp, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, vp, C.POINTER(vp)]
+    L.stp_band_pack_select.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, vp, C.POINTER(vp)]
     L.stp_band_download.argtypes = [vp, vp, vp]
     L.stp_band_nearest.argtypes = [vp, vp, vp, vp]
     L.stp_band_free.argtypes = [vp, vp]
@@ -137,6 +137,15 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def count_column(count):
+    """(contiguous array, STP_COUNT_* code) of a pixels/count column: float64 columns travel as they are, anything
+    else as int32."""
+    c = np.asarray(count)
+    if c.dtype == np.float64:
+        return np.ascontiguousarray(c), 1
+    return np.ascontiguousarray(c, dtype=np.int32), 0
+
+
 class Context:
     """One HIP device + stream.  Not thread-safe; one per process / GPU."""
 
@@ -192,12 +201,12 @@ class Context:
         (an stp_select handle) the same pass appends the balanced pixel values to it (stp_band_pack_select)."""
         bin1 = np.ascontiguousarray(bin1, dtype=np.int64)
         bin2 = np.ascontiguousarray(bin2, dtype=np.int64)
-        count = np.ascontiguousarray(count, dtype=np.int32)
+        count, ctype = count_column(count)
         if not (len(bin1) == len(bin2) == len(count)):
             raise ValueError('pixel columns differ in length')
         w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
         h = C.c_void_p()
-        self._chk(self.L.stp_band_pack_select(self.h, _ptr(bin1), _ptr(bin2), _ptr(count), len(bin1), _ptr(w),
+        self._chk(self.L.stp_band_pack_select(self.h, _ptr(bin1), _ptr(bin2), _ptr(count), ctype, len(bin1), _ptr(w),
                                               0 if w is None else len(w), int(lo), int(nrows), int(hw), select, C.byref(h)))
         return Band(self, handle=h, nrows=nrows, hw=hw)
 

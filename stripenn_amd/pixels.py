@@ -21,19 +21,19 @@ import numpy as np
 DIVISIVE_WEIGHTS = ('KR', 'VC', 'SQRT_VC')       # cooler's _4DN_DIVISIVE_WEIGHTS
 
 
-def _int32_counts(count):
-    """pixels/count as the int32 column the C ABI takes.  Float or wide-integer columns are accepted when every
-    value is an integer that fits; anything else (cooler files written with --count-as-float, merged or scaled
-    coolers) is refused rather than silently truncated."""
+def _counts(count):
+    """pixels/count as one of the two column types the C ABI takes: int32 (cooler's default; wider integer columns
+    and integer-valued float columns that fit are narrowed) or float64 (coolers written with --count-as-float,
+    merged or scaled coolers: kept as they are, never truncated)."""
     c = np.asarray(count)
     if c.dtype == np.int32:
         return np.ascontiguousarray(c)
-    if c.size:
-        if c.dtype.kind == 'f' and not np.all(np.isfinite(c) & (c == np.floor(c))):
-            raise ValueError('pixels/count holds non-integer values (a float-count cooler); this build packs int32 '
-                             'counts only -- refusing to truncate them')
-        if c.min() < -2**31 or c.max() > 2**31 - 1:
-            raise ValueError('pixels/count does not fit int32 (max %r)' % c.max())
+    if c.dtype.kind == 'f':
+        if c.size == 0 or (np.all(np.isfinite(c) & (c == np.floor(c))) and c.min() >= -2**31 and c.max() <= 2**31 - 1):
+            return np.ascontiguousarray(c, dtype=np.int32)
+        return np.ascontiguousarray(c, dtype=np.float64)
+    if c.size and (c.min() < -2**31 or c.max() > 2**31 - 1):
+        return np.ascontiguousarray(c, dtype=np.float64)            # exact below 2^53
     return np.ascontiguousarray(c, dtype=np.int32)
 
 
@@ -45,7 +45,7 @@ class PixelTable:
         self.chrom_offset = np.asarray(chrom_offset, dtype=np.int64)          # len(chromnames) + 1
         self.bin1_id = np.ascontiguousarray(bin1_id, dtype=np.int64)
         self.bin2_id = np.ascontiguousarray(bin2_id, dtype=np.int64)
-        self.count = _int32_counts(count)
+        self.count = _counts(count)
         self.weights = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in (weights or {}).items()}
         if len(self.chrom_offset) != len(self.chromnames) + 1:
             raise ValueError('chrom_offset must have one entry per chromosome plus one')

@@ -439,3 +439,34 @@ def test_score_rescoring_reproduces_the_compute_columns(tmp_path):
     assert np.array_equal(res['pvalue_added'].to_numpy(), ref['pvalue'].to_numpy())
     assert np.array_equal(res['Stripiness_added'].to_numpy(), ref['Stripiness'].to_numpy(), equal_nan=True)
     assert np.allclose(res['O_Mean_added'].to_numpy(), ref['Mean'].to_numpy(), rtol=1e-9, atol=0)
+
+
+# --------------------------------------------------------------------------------------------- float-count coolers
+def test_float_count_table_through_the_device(tmp_path):
+    """pixels/count as float64 (merged / scaled / --count-as-float coolers): the packer, the nearest-pixel table and the
+    quantile select take the column as it is (STP_COUNT_F64); the whole driver on such a table: HIP == oracle backend."""
+    from stripenn_amd import backend as BK, pixels, synth
+    names = ['chr1', 'chr2']
+    chroms = {n: synth.SynthChrom(nb, 33 + k) for k, (n, nb) in enumerate(zip(names, (1300, 800)))}
+    t = pixels.PixelTable.from_synth(names, chroms, 5000)
+    scale = np.where(np.arange(len(t.count)) % 7 == 0, 0.37, 1.6180339887)           # non-integer, not exactly representable products
+    tf = pixels.PixelTable(names, t.chromsizes, 5000, t.chrom_offset, t.bin1_id, t.bin2_id, t.count * scale, t.weights)
+    assert tf.count.dtype == np.float64
+    hb = BK.HipBackend(0)
+    sel = pixels.PixelSelector(tf, True)
+    for nm in names:
+        px = sel.chrom_pixels(nm)
+        s = hb.select_open()
+        band = hb.pack_chrom(px, HW, s)
+        assert np.array_equal(band.download(), O.band_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'],
+                                                                  px['nrows'], HW), equal_nan=True)
+        D = sel.fetch(nm)
+        pos = np.sort(D[D > 0])
+        assert hb.select_count(s) == len(pos)
+        ranks = np.array([0, len(pos) // 3, len(pos) - 1])
+        assert np.array_equal(hb.select_ranks(s, ranks), pos[ranks])
+        hb.select_close(s); band.close()
+    a = _compute(tf, str(tmp_path / 'hip'), backend=hb)
+    b = _compute(tf, str(tmp_path / 'ora'), backend=OracleBackend())
+    hb.close()
+    assert len(a[0].splitlines()) > 20 and a == b

@@ -181,11 +181,26 @@ def test_divisive_and_multiplicative_columns_follow_coolers_rule():
             assert (band[i, j - i + 512] == div[i, j]) or (np.isnan(div[i, j]) and np.isnan(band[i, j - i + 512]))
 
 
-def test_float_counts_are_refused_not_truncated():
-    b = np.array([0, 0, 1]); c = np.array([0, 1, 1])
-    ok = pixels.PixelTable(['c'], [2 * RESOL], RESOL, [0, 2], b, c, np.array([2.0, 5.0, 1.0]))
-    assert ok.count.dtype == np.int32 and ok.count.tolist() == [2, 5, 1]
-    with pytest.raises(ValueError, match='non-integer'):
-        pixels.PixelTable(['c'], [2 * RESOL], RESOL, [0, 2], b, c, np.array([2.0, 0.5, 1.0]))
-    with pytest.raises(ValueError, match='int32'):
-        pixels.PixelTable(['c'], [2 * RESOL], RESOL, [0, 2], b, c, np.array([2, 2**40, 1], dtype=np.int64))
+def test_float_counts_are_kept_not_truncated():
+    """pixels/count as float64 (coolers written with --count-as-float, merged / scaled coolers): integer-valued
+    columns are narrowed to int32, anything else stays float64 and flows through the dense read, the band
+    restatement and the nearest-pixel table unchanged (a value of 0.5 must not disappear)."""
+    b = np.array([0, 0, 1, 2]); c = np.array([0, 1, 1, 2])
+    ok = pixels.PixelTable(['c'], [3 * RESOL], RESOL, [0, 3], b, c, np.array([2.0, 5.0, 1.0, 7.0]))
+    assert ok.count.dtype == np.int32 and ok.count.tolist() == [2, 5, 1, 7]
+    w = np.array([0.5, 2.0, 1.5])
+    t = pixels.PixelTable(['c'], [3 * RESOL], RESOL, [0, 3], b, c, np.array([2.0, 0.5, 1.25, 0.0]), {'weight': w})
+    assert t.count.dtype == np.float64
+    sel = pixels.PixelSelector(t, True)
+    D = sel.fetch('c')
+    exp = np.zeros((3, 3))
+    for i, j, v in zip(b, c, [2.0, 0.5, 1.25, 0.0]):
+        exp[i, j] = exp[j, i] = v * (w[i] * w[j])
+    assert np.array_equal(D, exp) and D[0, 1] == 0.5 * (0.5 * 2.0)
+    px = sel.chrom_pixels('c')
+    band = O.band_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], 0, 3, 512)
+    assert band[0, 512 + 1] == D[0, 1] and band[1, 512 - 1] == D[1, 0] and band[2, 512] == 0.0
+    right, left = O.nearest_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], 0, 3)
+    assert right.tolist()[:2] == [0, 0] and right[2] == np.iinfo(np.int32).max      # the stored 0.0 is not a positive pixel
+    big = pixels.PixelTable(['c'], [3 * RESOL], RESOL, [0, 3], b, c, np.array([2, 2**40, 1, 3], dtype=np.int64))
+    assert big.count.dtype == np.float64 and big.count[1] == float(2**40)
