@@ -177,6 +177,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     # STP_BENCH_REHEARSE=1: every rank on device 0 with gloo (a one-GPU box cannot host an RCCL group of 2)
     rehearse = os.environ.get('STP_BENCH_REHEARSE') == '1'
+    rehearse_reduce = False
     if rehearse:
         local_rank = 0
     if world > 1:
@@ -185,10 +186,26 @@ def main():
         if rehearse:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+            # the group only carries the barrier and the max-over-ranks time (the path has no data collective): RCCL
+            # when it comes up, gloo otherwise -- a rank that cannot join must not cost the whole measurement
+            torch.cuda.set_device(local_rank)
+            try:
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+                probe = torch.zeros(1, device='cuda')
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as e:      # noqa: BLE001
+                print('bench.py: RCCL group failed (%s); using gloo for the timing scalars' % str(e)[:120], file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:       # noqa: BLE001
+                    pass
+                os.environ['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29500')) + 1)
+                dist.init_process_group('gloo', rank=rank, world_size=world)
+                rehearse_reduce = True
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    rdev = 'cpu' if rehearse else 'cuda'      # where the timing scalars are reduced
+    rdev = 'cpu' if (rehearse or rehearse_reduce) else 'cuda'      # where the timing scalars are reduced
 
     from stripenn_amd import synth_device, hip, shard, getStripe as GS, backend as BK
     hw = 512
