@@ -109,6 +109,10 @@ class HipBackend:
     def stripe_search(self, frames, M_levels, sigma, minH, maxW, bfilter):
         return frames.stripe_search(M_levels, sigma=sigma, minH=minH, maxW=maxW, bfilter=bfilter)
 
+    def stripe_search_begin(self, frames, M_levels, sigma, minH, maxW, bfilter):
+        """The same search enqueued without waiting; `.wait()` on the result gives the records."""
+        return frames.stripe_search_begin(M_levels, sigma=sigma, minH=minH, maxW=maxW, bfilter=bfilter)
+
     # ---- score path
     def diag_sums(self, band):
         n400 = -(-band.nrows // 400)

@@ -159,6 +159,10 @@ class getStripe:
     def release(self, chrom=None):
         """Free device memory of one / all chromosomes (not in the reference)."""
         for c in ([str(chrom)] if chrom is not None else list(self._bands)):
+            for key in [k for k in self._search_cache if k[0] == c]:      # a search still in flight reads these buffers
+                pend = self._search_cache[key]
+                if hasattr(pend, 'wait'):
+                    self._search_cache[key] = pend.wait()
             fr = self._frames.pop(c, None)
             if fr is not None and hasattr(fr[0], 'close'):
                 fr[0].close()
@@ -673,17 +677,33 @@ class getStripe:
         re-runs every frame per level (stripenn.py:134-138); the kernels share the band reads."""
         key = (chrom, tuple(float(m) for m in M_levels))
         if key not in self._search_cache:
-            fr = self._chrom_frames(chrom, chridx)[0]
+            self._search_begin(chrom, chridx, M_levels)
+        recs = self._search_cache[key]
+        if hasattr(recs, 'wait'):                                        # still in flight: collect it now
             t0 = time.time()
-            recs = self.backend.stripe_search(fr, np.asarray(M_levels, dtype=np.float64), self.canny, self.minH,
-                                              self.maxW, int(self.bfilter))
+            recs = self._search_cache[key] = recs.wait()
             self.timing['stripe_search_s'] = self.timing.get('stripe_search_s', 0.0) + time.time() - t0
-            self._search_cache[key] = recs
-        return self._search_cache[key]
+        return recs
+
+    def _search_begin(self, chrom, chridx, M_levels):
+        """Enqueue the search of one chromosome (all levels) without waiting for it, where the backend can
+        (stp_stripe_search_begin); extract() starts the searches of ALL its chromosomes before it collects the first,
+        so the host builds one chromosome's table while the device searches the next ones."""
+        key = (chrom, tuple(float(m) for m in M_levels))
+        if key in self._search_cache:
+            return
+        fr = self._chrom_frames(chrom, chridx)[0]
+        t0 = time.time()
+        begin = getattr(self.backend, 'stripe_search_begin', None)
+        args = (fr, np.asarray(M_levels, dtype=np.float64), self.canny, self.minH, self.maxW, int(self.bfilter))
+        self._search_cache[key] = begin(*args) if begin is not None else self.backend.stripe_search(*args)
+        self.timing['stripe_search_s'] = self.timing.get('stripe_search_s', 0.0) + time.time() - t0
 
     def extract(self, MP, index, perc, bgleft_up, bgright_up, bgleft_down, bgright_down):
         """getStripe.py:790-862: candidate stripes of one maxpixel level, all chromosomes."""
         parts = []
+        for chridx in range(len(self.chromnames)):                       # (no-ops once the searches are cached)
+            self._search_begin(self.chromnames[chridx], chridx, MP[self.chromnames[chridx]])
         for chridx in range(len(self.chromnames)):
             chrom = self.chromnames[chridx]
             print('Chromosome: ' + str(chrom) + " / Maximum pixel: " + str(round(perc * 100, 3)) + "%")
