@@ -159,6 +159,7 @@ def main():
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end `compute` run (quantile -> TSVs) at N = 1')
     ap.add_argument('--no-score', action='store_true', help='StripeSearch chain only (for very long chromosomes)')
     ap.add_argument('--allow-stp-lib', action='store_true', help='accept a library named by STP_LIB (profiling builds)')
+    ap.add_argument('--emulate-rank', default='', help='R/N: time the share rank R of an N-rank run would get, alone on this GPU (diagnostic: per-rank fixed costs without an N-GPU node; the line is NOT a multi-GPU measurement)')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -222,6 +223,13 @@ def main():
     sizes = np.array([n * RESOL for n in nbins], dtype=np.int64)
     nframes = [-(-n // 200) for n in nbins]
     my_units = shard.frame_spans(nframes, world)[rank]       # (chromosome index, first frame, end frame)
+    if args.emulate_rank:
+        er, en_ = (int(v) for v in args.emulate_rank.split('/'))
+        my_units = shard.frame_spans(nframes, en_)[er]
+    # pipeline stages: pieces of at most one device chunk (3 072 images = 102 frames at 5 levels x 6 brightness), so that
+    # filling and draining the two-deep pipeline costs a chunk's latency, not a chromosome's
+    piece = max(1, int(os.environ.get('STP_BENCH_PIECE', '102')))
+    my_units = [(ci, a, min(a + piece, f1)) for ci, f0, f1 in my_units for a in range(f0, f1, piece)]
 
     # ---- untimed set-up: every band in HBM, maxpixel quantiles, expected values, background tables
     t_setup = time.time()
@@ -356,6 +364,7 @@ def main():
                'unit': 'contact-Mpx/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
                'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+               'emulated_rank': args.emulate_rank or None,
                'config': {'workload': '%s: %d bins, %d frames x %d maxpixel levels (0.95-0.99) x 6 brightness levels; step = frame '
                                       'compaction + medpixel + StripeSearch chain%s, bands resident in HBM'
                                       % (wl, sum(nbins), sum(nframes), len(MAXPIXEL),
