@@ -17,6 +17,8 @@ with h5py.File(path,'w') as f:
     start=np.concatenate([np.arange(n)*5000 for n in np.diff(t.chrom_offset)])
     g.create_dataset('bins/chrom',data=chrom_id); g.create_dataset('bins/start',data=start); g.create_dataset('bins/end',data=start+5000)
     g.create_dataset('bins/weight',data=t.weights['weight'])
+    kr=1.0/np.where(np.isnan(t.weights['weight']),np.nan,t.weights['weight']*1.37)      # a divisive column as hic2cool writes it
+    g.create_dataset('bins/KR',data=kr)
     g.create_dataset('pixels/bin1_id',data=t.bin1_id); g.create_dataset('pixels/bin2_id',data=t.bin2_id); g.create_dataset('pixels/count',data=t.count)
     g.create_dataset('indexes/chrom_offset',data=t.chrom_offset)
 u=pixels.PixelTable.from_cool(path,'resolutions/5000')
@@ -27,4 +29,18 @@ from stripenn_amd import io
 sys.modules['cooler']=None          # force the h5py route of open_matrix
 info=io.open_matrix(path+'::resolutions/5000')
 print(info.chromnames, info.binsize, list(info.bins().columns), info.matrix(balance='weight').fetch('chrB').shape)
-print('from_cool round trip ok')
+# the divisive KR column (cooler: bias = 1 / KR) through the h5py route: hand-computed on a window
+selkr=info.matrix(balance='KR')
+blk=selkr.fetch('chrA:500001-1000000')
+cnt=chroms['chrA'].counts(100,200,100,200)
+b=1.0/kr[100:200]
+with np.errstate(invalid='ignore'):
+    exp=np.where(cnt>0, cnt*np.outer(b,b), 0.0)
+assert np.array_equal(blk,exp,equal_nan=True)
+# float counts survive the file
+with h5py.File(path,'a') as f:
+    del f['resolutions/5000/pixels/count']
+    f['resolutions/5000'].create_dataset('pixels/count',data=t.count*0.25)
+v=pixels.PixelTable.from_cool(path,'resolutions/5000')
+assert v.count.dtype==np.float64 and np.array_equal(v.count,t.count*0.25)
+print('from_cool round trip ok (weight, divisive KR column, float counts)')
