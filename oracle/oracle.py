@@ -320,7 +320,12 @@ def band_from_pixels(bin1, bin2, count, weight, lo, nrows, hw):
     (stripenn.py:80-118, getStripe.py:808) would put into the diagonal band.  value = count * (b[bin1] *
     b[bin2]) (cooler's dense branch: count block times np.outer(bias1, bias2); `weight` here is that multiplicative
     bias, 1 / w for the divisive columns; raw counts when weight is None), written at (i, j) and mirrored at
-    (j, i); cells no stored pixel names are 0.  cooler itself is absent here: parity unpinned for this reader."""
+    (j, i).  A cell no stored pixel names is the count 0 times the same product: 0 where the product is finite,
+    NaN along the whole row and column of a bin whose weight is NaN (cooler multiplies the DENSE count block, so an
+    unbalanced bin is NaN everywhere, not only where pixels are stored -- the reference's all-NaN column deletion,
+    getStripe.py:709-737, and nanmean, :518-521, see exactly that; pinned by tests/golden/e2e_chr16.npz, whose
+    reference run read the same matrix through dense fetches); cells outside the chromosome are 0.
+    cooler itself is absent here: parity unpinned for this reader."""
     bin1 = np.asarray(bin1, np.int64); bin2 = np.asarray(bin2, np.int64)
     v = np.asarray(count).astype(np.float64)
     if weight is not None:
@@ -331,6 +336,15 @@ def band_from_pixels(bin1, bin2, count, weight, lo, nrows, hw):
     i, j, v = i[ok], j[ok], v[ok]
     d = j - i
     band = np.zeros((int(nrows), 2 * hw), np.float64)
+    if weight is not None:
+        wl = np.asarray(weight, np.float64)[lo:lo + int(nrows)]
+        for r0 in range(0, int(nrows), 4096):
+            r1 = min(r0 + 4096, int(nrows))
+            cc = np.arange(r0, r1)[:, None] + np.arange(-hw, hw)[None, :]
+            inside = (cc >= 0) & (cc < nrows)
+            with np.errstate(invalid='ignore', over='ignore'):
+                z = 0.0 * (wl[r0:r1][:, None] * wl[np.clip(cc, 0, int(nrows) - 1)])
+            band[r0:r1] = np.where(inside, z, 0.0)
     m = (d >= -hw) & (d < hw)
     band[i[m], d[m] + hw] = v[m]
     m = (-d >= -hw) & (-d < hw)

@@ -223,6 +223,9 @@ if __name__ == '__main__':
     if 'e2e' in which:
         from gen_golden_e2e import e2e_goldens
         e2e_goldens()
+    if 'chr16' in which:
+        from gen_golden_e2e import run_chr16
+        run_chr16()
     if 'e2e1kb' in which:
         from gen_golden_e2e import e2e_goldens
         e2e_goldens(which=('1kb',))

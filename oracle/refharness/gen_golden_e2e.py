@@ -151,3 +151,91 @@ def e2e_goldens(which=('seq', 'par', '1kb')):
         # No NaN bins: with 50-bin flanks the reference itself raises IndexError in np.delete
         # (getStripe.py:735) as soon as an all-NaN flank column has an index >= the stripe height.
         run(1, '1kb', resol=1000, sizes_bp=[2600 * 1000 - 321, 1800 * 1000 - 77], maxpixel=[0.97], seed0=77, nan_frac=0.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[0] / configs[1] at CONFIG size: the chr16-size chromosome (19 642 bins of 5 kb, seed 16),
+# the unmodified reference with numcores = 8 (= nproc of the build container), driven like stripenn.compute
+# (stripenn.py:120-159): configs[1] = maxpixel 0.95-0.99, configs[0] = the README example's single level 0.99.
+# The wall time of every step is stored next to the tables (the reference's own CPU rate, quoted in BASELINE.md
+# and printed beside bench.py's cpu_baseline).
+CHR16_SIZE = 98207768            # mm10 chr16 -> 19 642 bins at 5 kb
+CHR16_SEED = 16
+CHR16_MAXPIXEL = [0.95, 0.96, 0.97, 0.98, 0.99]
+
+
+def run_chr16(core=8, tag='chr16'):
+    import time
+    resol = 5000
+    names, sizes, sel = synth.make_genome([CHR16_SIZE], resol, seed0=CHR16_SEED, names=['chr16'])
+    obj = gs_mod.getStripe(sel, resol, 10, 8, 2.0, list(names), list(names), np.array(sizes), np.array(sizes), core,
+                           3, E2E_PRNG_SEED)
+    info = Info(); info.chromsizes = pd.Series(sizes, index=names)
+    store = {'resol': resol, 'sizes': np.array(sizes), 'names': np.array(names), 'seed0': CHR16_SEED,
+             'nan_frac': 0.005, 'maxpixel': np.array(CHR16_MAXPIXEL), 'prng_seed': E2E_PRNG_SEED, 'core': core}
+    T = {}
+    t0 = time.time()
+    with quiet():
+        MP = obj.getQuantile_original(info, names, CHR16_MAXPIXEL)
+    T['quantile'] = time.time() - t0; t0 = time.time()
+    with quiet():
+        EV = obj.mpmean()
+    T['mpmean'] = time.time() - t0; t0 = time.time()
+    with quiet():
+        bg = obj.nulldist()
+    T['nulldist'] = time.time() - t0
+    print('chr16 quantile %.1f s, mpmean %.1f s, nulldist %.1f s' % (T['quantile'], T['mpmean'], T['nulldist']), flush=True)
+    store['MP_chr16'] = MP['chr16']
+    store['EV_chr16'] = np.array(EV['chr16'], dtype=np.float64)
+    for k, t in zip(('lu', 'ru', 'ld', 'rd'), bg):
+        store['bg_%s_sha' % k] = sha(t)
+        store['bg_%s_shape' % k] = np.array(t.shape)
+    cols = ['chr', 'pos1', 'pos2', 'chr2', 'pos3', 'pos4', 'length', 'width', 'total', 'Mean', 'maxpixel', 'num',
+            'start', 'end', 'x', 'y', 'h', 'w', 'medpixel', 'pvalue']
+    ints = ['pos1', 'pos2', 'pos3', 'pos4', 'length', 'width', 'num', 'start', 'end', 'x', 'y', 'h', 'w']
+    flts = ['total', 'Mean', 'medpixel', 'pvalue']
+    tables = []
+    text = []
+    for i, perc in enumerate(CHR16_MAXPIXEL):
+        t0 = time.time()
+        with quiet():
+            res = obj.extract(MP, i, perc, *bg)
+        T['extract%d' % i] = time.time() - t0
+        df_to_store(store, 'ex%d_' % i, res, ints, flts, ['chr', 'maxpixel'])
+        tables.append(res)
+        print('chr16 extract', perc, len(res), 'rows, %.1f s' % T['extract%d' % i], flush=True)
+
+    def finish(prefix, parts):
+        t0 = time.time()
+        rt = pd.DataFrame(columns=cols)
+        for r in parts:
+            rt = pd.concat([rt, r])
+        with quiet():
+            rt = gs_mod.getStripe.RemoveRedundant(obj, df=rt, by='pvalue')
+        T[prefix + 'filter'] = time.time() - t0; t0 = time.time()
+        with quiet():
+            s = obj.scoringstripes(rt, EV, '0')
+        T[prefix + 'stripiness'] = time.time() - t0
+        df_to_store(store, prefix + 'rr_', rt, ints, flts, ['chr', 'maxpixel'])
+        store[prefix + 'rr_g'] = np.array(s[0], dtype=np.float64)
+        out = rt.drop(columns=['total', 'num', 'start', 'end', 'x', 'y', 'h', 'w', 'medpixel'])
+        out.insert(out.shape[1], 'Stripiness', s[0], True)
+        filt = out[out['pvalue'] < 0.1].sort_values(by=['Stripiness'], ascending=False)
+        b1, b2 = io.StringIO(), io.StringIO()
+        out.to_csv(b1, sep='\t', header=True, index=False)
+        filt.to_csv(b2, sep='\t', header=True, index=False)
+        store[prefix + 'tsv_unfiltered'] = np.array(b1.getvalue())
+        store[prefix + 'tsv_filtered'] = np.array(b2.getvalue())
+        print('chr16', prefix or 'sweep', 'rows', len(out), 'filtered', len(filt), flush=True)
+
+    finish('', tables)               # configs[1]: the five-level sweep
+    finish('c0_', tables[4:])        # configs[0]: maxpixel 0.99 only (its extract table is ex4_)
+    # wall times: configs[1] = every step once + five extracts; configs[0] = the same fixed steps + one extract
+    fixed = T['quantile'] + T['mpmean'] + T['nulldist']
+    T['config1_total'] = fixed + sum(T['extract%d' % i] for i in range(5)) + T['filter'] + T['stripiness']
+    T['config0_total'] = fixed + T['extract4'] + T['c0_filter'] + T['c0_stripiness']
+    store['time_keys'] = np.array(sorted(T))
+    store['time_s'] = np.array([T[k] for k in sorted(T)])
+    store['host'] = np.array('%d cpus' % os.cpu_count())
+    np.savez_compressed(os.path.join(OUT, 'e2e_%s.npz' % tag), **store)
+    print('chr16 times', {k: round(v, 1) for k, v in T.items()}, flush=True)

@@ -718,6 +718,25 @@ __global__ __launch_bounds__(1024) void k_compact_recs(const stp_drec* __restric
 // near[0..nrows) / near[nrows..2 nrows): distance from each bin to the nearest stored pixel with a positive value
 // in its row of the symmetric matrix, to the right (column >= row) / to the left (column < row) -- every cis pixel
 // takes part, also those beyond the band's halfwidth.
+// Band cells no stored pixel names: cooler multiplies the DENSE count block by np.outer(bias1, bias2), so such a cell is
+// 0 * (b[row] * b[col]) -- NaN along the whole row and column of a bin whose weight is NaN (or whose product overflows),
+// 0 elsewhere; cells outside the chromosome are 0.  One lane per two cells (16 B stores), rows coalesced.
+__global__ __launch_bounds__(256) void k_band_init(const double* __restrict__ wloc, int64_t nrows, int W, int hw,
+                                                    double* __restrict__ band)
+{
+    const int64_t n2 = nrows * (int64_t)(W / 2);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n2; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = p / (W / 2);
+        const int c2 = (int)(p - r * (W / 2)) * 2;
+        const double wr = wloc[r];
+        double2 v;
+        const int64_t ca = r + c2 - hw, cb = ca + 1;
+        v.x = (ca >= 0 && ca < nrows) ? 0.0 * (wr * wloc[ca]) : 0.0;
+        v.y = (cb >= 0 && cb < nrows) ? 0.0 * (wr * wloc[cb]) : 0.0;
+        *(double2*)(band + r * (int64_t)W + c2) = v;
+    }
+}
+
 template <typename CT>     // pixels/count as stored: int32 or float64
 __global__ __launch_bounds__(256) void k_band_pack(const int64_t* __restrict__ bin1, const int64_t* __restrict__ bin2,
                                                     const CT* __restrict__ count, int64_t npix,
@@ -1203,14 +1222,20 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
         (void)hipFree(d); delete b;
         return set_err(ctx, STP_E_NOMEM, "hipMalloc(band nearest-pixel table) failed");
     }
-    hipError_t e = hipMemsetAsync(d, 0, bytes, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)near, 0x7FFFFFFF, (size_t)nrows * 2, ctx->stream);
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)near, 0x7FFFFFFF, (size_t)nrows * 2, ctx->stream);
     if (e == hipSuccess && nch) e = b1.alloc(ctx, (size_t)nch * sizeof(int64_t));
     if (e == hipSuccess && nch) e = b2.alloc(ctx, (size_t)nch * sizeof(int64_t));
     if (e == hipSuccess && nch) e = bc.alloc(ctx, (size_t)nch * csz);
     if (e == hipSuccess && weight) e = bw.alloc(ctx, (size_t)nrows * sizeof(double));
     if (e == hipSuccess && weight)
         e = hipMemcpyAsync(bw.p, weight + lo, (size_t)nrows * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && weight) {
+        prof_scope ps(ctx, "band_init", (double)bytes);
+        hipLaunchKernelGGL(k_band_init, dim3(256 * 16), dim3(256), 0, ctx->stream, (const double*)bw.p, nrows, b->W, hw, d);
+        e = hipGetLastError();
+    } else if (e == hipSuccess) {
+        e = hipMemsetAsync(d, 0, bytes, ctx->stream);
+    }
     for (int64_t p0 = 0; e == hipSuccess && p0 < npix; p0 += CH) {
         const int64_t n = npix - p0 < CH ? npix - p0 : CH;
         e = hipMemcpyAsync(b1.p, bin1 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);

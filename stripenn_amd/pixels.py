@@ -6,8 +6,9 @@ vector), ``pixels`` (bin1_id <= bin2_id, count; sorted by (bin1_id, bin2_id)) an
 reads it (stripenn.py:80-118, getStripe.py .fetch sites) -- turns a rectangle of that table into a dense
 array: the count block times np.outer(bias1, bias2), i.e. value = count * (b[bin1] * b[bin2]) with b = w for a
 multiplicative column ("weight") and b = 1 / w for the divisive ones cooler knows by name (KR, VC, SQRT_VC:
-the columns hic2cool writes; `--norm KR` is the reference CLI's default), NaN where a weight is NaN, mirrored
-below the diagonal, 0 where no pixel is stored.  ``PixelTable`` holds the same arrays; ``PixelSelector.fetch`` is that dense read
+the columns hic2cool writes; `--norm KR` is the reference CLI's default), mirrored below the diagonal; a cell
+without a stored pixel is the count 0 times the same product, i.e. NaN along the whole row and column of a bin
+whose weight is NaN and 0 elsewhere.  ``PixelTable`` holds the same arrays; ``PixelSelector.fetch`` is that dense read
 on the host, and ``chrom_pixels`` hands the cis pixels of one chromosome to the HIP band packer
 (``stp_band_pack``), which builds the resident diagonal band without any dense intermediate.
 
@@ -270,6 +271,11 @@ class PixelSelector:
         """Dense block of global bins rows [R0, R1) x cols [C0, C1)."""
         t = self.table
         out = np.zeros((R1 - R0, C1 - C0), dtype=np.float64)
+        if self.w is not None:
+            # cooler multiplies the dense count block by np.outer(bias1, bias2): a cell without a stored pixel is
+            # 0 * (b1 * b2) -- NaN along the whole row / column of an unbalanced (NaN-weight) bin, 0 elsewhere
+            with np.errstate(invalid='ignore', over='ignore'):
+                out = 0.0 * (self.w[R0:R1][:, None] * self.w[C0:C1][None, :])
         # stored pixels (bin1 in rows, bin2 in cols), then their mirror images (bin2 in rows, bin1 in cols)
         for (A0, A1, B0, B1, mirror) in ((R0, R1, C0, C1, False), (C0, C1, R0, R1, True)):
             a, b = t.rows_slice(A0, A1)

@@ -168,7 +168,17 @@ class SynthSelector:
             n2, c0, c1 = self._extent(region2)
         if n1 != n2:
             raise ValueError('trans fetch not supported by the synthetic selector')
-        return self.chroms[n1].block(r0, r1, c0, c1)
+        ch = self.chroms[n1]
+        if (r1 - r0) * (c1 - c0) <= (1 << 24):
+            return ch.block(r0, r1, c0, c1)
+        # whole-chromosome fetches (getQuantile_original): same array, built in row strips so that the
+        # generator's temporaries stay small next to the dense result
+        out = np.empty((r1 - r0, c1 - c0), dtype=np.float64)
+        step = max(1, (1 << 24) // max(c1 - c0, 1))
+        for a in range(r0, r1, step):
+            b = min(a + step, r1)
+            out[a - r0:b - r0] = ch.block(a, b, c0, c1)
+        return out
 
 
 def make_genome(sizes_bp, resol, seed0=1, names=None, **kw):

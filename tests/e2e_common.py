@@ -152,3 +152,73 @@ def run_nan_flank_indexerror(make_backend):
     with pytest.raises(IndexError):
         obj.scoringstripes(table, EV, '0')
     return obj
+
+
+def chr16_source(g):
+    """The chr16-size synthetic chromosome of tests/golden/e2e_chr16.npz as cooler's pixel table (the reference read
+    the same matrix through dense `fetch` calls; the table holds its raw counts and the weight column)."""
+    from stripenn_amd import pixels
+    names = [str(x) for x in g['names']]
+    sizes = g['sizes']
+    _, _, dense = synth.make_genome(list(sizes), int(g['resol']), seed0=int(g['seed0']), names=names,
+                                    nan_frac=float(g['nan_frac']))
+    table = pixels.PixelTable.from_synth(names, dense.chroms, int(g['resol']))
+    table.chromsizes = np.asarray(sizes, dtype=np.int64)           # the true bp sizes (the last bin is partial)
+    return names, sizes, pixels.PixelSelector(table, balance=True)
+
+
+def run_chr16(make_backend, float_exact, configs=(1, 0)):
+    """BASELINE.json configs[1] (maxpixel 0.95-0.99) and configs[0] (0.99 only) on the chr16-size chromosome against
+    the tables the UNMODIFIED reference produced at that size with numcores = 8 (oracle/refharness/gen_golden_e2e.py
+    run_chr16): quantiles, expected values, background tables, every extract table row by row, the redundancy filter,
+    Stripiness and both TSVs."""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'e2e_chr16.npz'))
+    st = np.load(os.path.join(ROOT, 'tests', 'golden', 'stages_chr7.npz'))
+    names, sizes, sel = chr16_source(g)
+    obj = GS.getStripe(sel, int(g['resol']), 10, 8, 2.0, names, names, sizes, sizes, int(g['core']), 3,
+                       int(g['prng_seed']), backend=make_backend(np.ascontiguousarray(st['gw_2p0'])))
+    info = Info(); info.chromsizes = pd.Series(sizes, index=names)
+    MP = obj.getQuantile_original(info, names, list(g['maxpixel']))
+    assert np.array_equal(MP['chr16'], g['MP_chr16']), 'maxpixel quantiles differ'
+    EV = obj.mpmean()
+    assert np.array_equal(np.array(EV['chr16']), g['EV_chr16']), 'expected values differ'
+    bg = obj.nulldist()
+    for t, k in zip(bg, ('lu', 'ru', 'ld', 'rd')):
+        assert tuple(g['bg_%s_shape' % k]) == t.shape
+        assert sha(t) == str(g['bg_%s_sha' % k]), 'background table %s differs from the reference' % k
+    tables = []
+    for i, perc in enumerate(g['maxpixel']):
+        if 1 not in configs and i != 4:
+            tables.append(None)
+            continue
+        res = obj.extract(MP, i, float(perc), *bg)
+        check_table(g, 'ex%d_' % i, res, float_exact)
+        tables.append(res)
+    rows = {}
+    for cfg in configs:
+        prefix, parts = ('', tables) if cfg == 1 else ('c0_', tables[4:])
+        rt = pd.DataFrame(columns=GS.EXTRACT_COLUMNS + ['pvalue'])
+        for r in parts:
+            rt = pd.concat([rt, r])
+        rt = obj.RemoveRedundant(df=rt, by='pvalue')
+        check_table(g, prefix + 'rr_', rt, float_exact)
+        s = obj.scoringstripes(rt, EV, '0')
+        assert close(s[0], g[prefix + 'rr_g'], float_exact), 'Stripiness differs'
+        out = rt.drop(columns=['total', 'num', 'start', 'end', 'x', 'y', 'h', 'w', 'medpixel'])
+        out.insert(out.shape[1], 'Stripiness', s[0], True)
+        filt = out[out['pvalue'] < 0.1].sort_values(by=['Stripiness'], ascending=False)
+        b1, b2 = io.StringIO(), io.StringIO()
+        out.to_csv(b1, sep='\t', header=True, index=False)
+        filt.to_csv(b2, sep='\t', header=True, index=False)
+        for ref_txt, got_txt in ((str(g[prefix + 'tsv_unfiltered']), b1.getvalue()), (str(g[prefix + 'tsv_filtered']), b2.getvalue())):
+            ref = pd.read_csv(io.StringIO(ref_txt), sep='\t')
+            got = pd.read_csv(io.StringIO(got_txt), sep='\t')
+            assert list(ref.columns) == list(got.columns)
+            for c in ('chr', 'pos1', 'pos2', 'chr2', 'pos3', 'pos4', 'length', 'width', 'maxpixel'):
+                assert ref[c].tolist() == got[c].tolist(), c       # filtered stripe calls identical
+            for c in ('Mean', 'pvalue', 'Stripiness'):
+                assert close(got[c], ref[c], float_exact), c
+            if float_exact:
+                assert got_txt == ref_txt
+        rows[cfg] = (len(out), len(filt))
+    return obj, rows
