@@ -8,8 +8,8 @@
 // sum |e_k| + R ulp(o) <= 2^-53 o + R ulp(o) < (R+1) ulp(o) (all terms are non-negative -- grey values and weights
 // are -- so the partial sums never exceed the final one).  Hence the two sums round to the same float unless the
 // fused one lies within (R+1) <= 13 ulp(f64) of a float rounding boundary, i.e. unless the 29 mantissa bits the
-// conversion drops are within 13 of the half-way pattern 0x10000000.  The test below uses 32 and costs three 32-bit
-// integer instructions per output (add, and, min); a run in which some output fails it (about 1e-7 of the outputs)
+// conversion drops are within 13 of the half-way pattern 0x10000000.  The test below uses 32 and costs 1.5 32-bit
+// integer instructions per output (shift-add, half a three-way min); a run in which some output fails it (about 1e-7 of the outputs)
 // is recomputed in the reference's exact order.  R+1 instead of 2R+1 FP64 roundings = 17 instead of 25 FP64
 // instructions per output at R = 8, results bit for bit those of the exact order.  Checked on 24 M random windows by
 // tests/test_emu_kernels.py::test_fma_certification_random_windows; tests/emu also replays the kernels with EVERY
@@ -31,12 +31,15 @@ STP_HD unsigned stp_lo32(double v)
     return (unsigned)b;
 #endif
 }
-// 0 exactly when the float conversion of v could differ from that of a value up to STP_FMA_NEAR ulp(f64) away.
-// (A binade crossing needs no extra case: the pattern of a rounding boundary is the same in every binade, and the
-// binade edge itself is a float.)  A run keeps the minimum of these words: zero = some output is near a boundary.
+// The 29 mantissa bits the float conversion drops, moved to the top of a word and offset so that a value within
+// STP_FMA_NEAR ulp(f64) of a float rounding boundary (dropped bits within STP_FMA_NEAR of 0x10000000) gives a word
+// below 16 * STP_FMA_NEAR: ((lo + NEAR - 0x10000000) mod 2^29) << 3, ONE v_lshl_add_u32.  (A binade crossing needs
+// no extra case: the pattern of a rounding boundary is the same in every binade, and the binade edge itself is a
+// float.)  A run keeps the minimum of these words (v_min3_u32 takes two outputs at a time): 1.5 integer
+// instructions per output.
 STP_HD unsigned stp_fma_near_word(double v)
 {
-    return (stp_lo32(v) + (unsigned)(STP_FMA_NEAR - 0x10000000)) & (0x1FFFFFFFu & ~(2u * STP_FMA_NEAR - 1u));
+    return (stp_lo32(v) << 3) + (((unsigned)STP_FMA_NEAR - 0x10000000u) << 3);
 }
 
 // N consecutive outputs from a window of N + 2R f64 values (fused order).  Returns 0 when the run must be settled by
@@ -58,7 +61,8 @@ STP_HD unsigned stp_gauss_run_fma(const double* win, const double* w, float* out
         const unsigned nw = stp_fma_near_word(a);
         far = nw < far ? nw : far;
     }
-    return far;
+    if ((unsigned long long)STP_FMA_NEAR >= 0x10000000ull) return 0u;      // the all-flagged replay of tests/emu
+    return far >= 16u * (unsigned)STP_FMA_NEAR ? 1u : 0u;
 }
 
 // The reference's own order for ONE output, from a strided f32 line (run-time loops, no register arrays, not

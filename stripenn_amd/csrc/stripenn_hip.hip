@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
 // over the queue, 64 candidates at a time -- candidates are 7-25 % of the pixels but occur in every row,
 // so a per-row test would keep all lanes of every wave busy with the expensive path.
 __device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double* sS, const float* sM, uint16_t* sQ,
-                                               stp_u64* sBits, stp_u64* __restrict__ low_img, stp_u64* __restrict__ high_img)
+                                               stp_u64* sBits, stp_u64* __restrict__ low_img, stp_u64* __restrict__ high_img,
+                                               int nms_rows = CT_Y /* tile rows that can hold an interior pixel */)
 {
     const int lane = tid & 63, wv = tid >> 6;
     uint16_t* q = sQ + wv * 512;
@@ -192,12 +193,13 @@ __device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double
     stp_u64* highB = sBits + CT_Y;
     if (lane < 8) { lowB[wv * 8 + lane] = 0; highB[wv * 8 + lane] = 0; }
     int n = 0;
+    const int rows = min(8, nms_rows - wv * 8);       // wave-uniform: a strip below the image collects nothing
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const int yy = wv * 8 + r;
         const int y = T.ty0 + yy, x = T.tx0 + lane;
         bool c = false;
-        if (y >= 1 && x >= 1 && y < T.S - 1 && x < T.S - 1) c = sM[(yy + 1) * (CT_X + 2) + lane + 1] >= (float)(0.1 - 1e-6);
+        if (r < rows && y >= 1 && x >= 1 && x < T.S - 1) c = sM[(yy + 1) * (CT_X + 2) + lane + 1] >= (float)(0.1 - 1e-6);
         const stp_u64 m = __ballot(c);
         if (c) q[n + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((yy << 6) | lane);
         n += __popcll(m);
@@ -221,6 +223,64 @@ __device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double
             low_img[y * STP_NW + (T.tx0 >> 6)] = lowB[yy];
             high_img[y * STP_NW + (T.tx0 >> 6)] = highB[yy];
         }
+    }
+}
+
+// k_canny_pipe: magnitudes in 2 x 2 blocks (ct_sobel_blk2) and, in the same walk, collection of the pixels whose
+// magnitude reaches the low threshold (the only ones that can get a class) into ONE workgroup-wide LDS queue: per
+// block position a ballot, one LDS atomic of the wave's first lane for the base, a 16-bit entry per candidate.
+// Order in the queue is irrelevant: the classes are OR-ed into the bit rows.
+__device__ __forceinline__ void canny_p3_collect(int tid, stp_tile T, stp_p3walk W, const double* sS, float* sM, uint16_t* sQ,
+                                                 int* sQn)
+{
+    const int lane = tid & 63;
+    int r = W.r0, c = W.c0;
+    const int rounds = (W.n + 255) >> 8;                    // workgroup-uniform
+    for (int k = 0; k < rounds; k++) {
+        const bool act = tid + 256 * k < W.n;
+        float m[4] = {0.f, 0.f, 0.f, 0.f};
+        int y = 0, x = 0;
+        if (act) {
+            y = 2 * r < W.nmh - 2 ? 2 * r : W.nmh - 2; x = 2 * c < W.nmw - 2 ? 2 * c : W.nmw - 2;
+            ct_sobel_blk2(sS + W.soff + y * CT_SP + x, m);
+            float* o = sM + W.moff + y * (CT_X + 2) + x;
+            o[0] = m[0]; o[1] = m[1]; o[CT_X + 2] = m[2]; o[CT_X + 3] = m[3];
+        }
+        // tile coordinates of the block's first pixel; a block shifted back at an odd extent repeats one row / column
+        // of its neighbour: those pixels are not collected twice
+        const int ty = y + W.my_lo - 1, tx = x + W.mx_lo - 1;
+        const bool dupr = y != 2 * r, dupc = x != 2 * c;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int py = ty + (q >> 1), px = tx + (q & 1);
+            const int Y = T.ty0 + py, X = T.tx0 + px;
+            bool cand = act && (unsigned)py < (unsigned)CT_Y && (unsigned)px < (unsigned)CT_X && Y >= 1 && X >= 1 && Y < T.S - 1 &&
+                        X < T.S - 1 && m[q] >= (float)(0.1 - 1e-6);
+            if ((q >> 1) == 0 && dupr) cand = false;
+            if ((q & 1) == 0 && dupc) cand = false;
+            const stp_u64 bal = __ballot(cand);
+            if (bal) {                                       // wave-uniform
+                int base = 0;
+                if (lane == 0) base = atomicAdd(sQn, __popcll(bal));
+                base = __shfl(base, 0);
+                if (cand) sQ[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)((py << 6) | px);
+            }
+        }
+        c += W.dc; r += W.dr;
+        if (c >= W.nbw) { c -= W.nbw; r++; }
+    }
+}
+// the interpolation test over the queue, all threads of the workgroup, 256 candidates at a time
+__device__ __forceinline__ void canny_nms_queue(int tid, stp_tile T, const double* sS, const float* sM, const uint16_t* sQ, int n,
+                                                stp_u64* sBits)
+{
+    stp_u64* lowB = sBits;
+    stp_u64* highB = sBits + CT_Y;
+    for (int k = tid; k < n; k += 256) {
+        const int e = sQ[k], yy = e >> 6, xx = e & 63;
+        const int cls = ct_nms(sS, sM, T, T.ty0 + yy, T.tx0 + xx);
+        if (cls >= 1) atomicOr(&lowB[yy], 1ull << xx);
+        if (cls == 2) atomicOr(&highB[yy], 1ull << xx);
     }
 }
 
@@ -294,7 +354,7 @@ static __host__ __device__ size_t canny_pipe_smem_bytes(int R)
     size_t m = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(float) + 4 * 512 * sizeof(uint16_t);
     return fixed + (v > m ? v : m);
 }
-#define CANNY_PIPE_BITS_BYTES (2 * CT_Y * 8)
+#define CANNY_PIPE_BITS_BYTES (2 * CT_Y * 8 + 16)   /* class bit-rows + the candidate count */
 
 template <int RT>
 __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
@@ -324,7 +384,10 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
     float* sM = sV;                               // magnitude tile (f32) over the dead vertical-pass buffer
     uint16_t* sQ = (uint16_t*)(sM + (CT_Y + 2) * (CT_X + 2));      // 4 wave queues of 512 candidates
     stp_u64* sBits = (stp_u64*)(smem + canny_pipe_smem_bytes(R));   // class bit-rows
+    int* sQn = (int*)(sBits + 2 * CT_Y);                            // candidates in the queue
     const int tid = threadIdx.x, nt = blockDim.x;
+    if (tid < 2 * CT_Y) sBits[tid] = 0ull;
+    if (tid == 64) *sQn = 0;
     if (tid < 2 * R + 1) sW[tid] = gw[tid];
     canny_p1b(tid, nt, T, R, gw, sB);            // bleed-over factors depend on the tile geometry only
     __syncthreads();
@@ -334,6 +397,22 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
     if (!xin) canny_p1c<R>(tid, nt, T, sW, sB, sBB);
     __syncthreads();
     const size_t img0 = ((size_t)fl * nlev + lev) * nb;
+    // in-image extents of the three passes' work items: the same for all images of the tile, so each thread decodes
+    // its items once (a 400-pixel frame leaves 19 of its 91 tiles mostly outside the image: their idle waves skip
+    // the passes instead of filtering zeros)
+    constexpr int GWc = CT_X + 2 * R + 4, NG1 = (CT_Y + 4) / ((R <= 8) ? CT_VRUN : CT_VRUN / 2);
+    constexpr int NR1 = (GWc * NG1 + 255) / 256;
+    constexpr int NR2 = ((CT_Y + 4) * ((CT_X + 4 + CT_HRUN_R(R) - 1) / CT_HRUN_R(R)) + 255) / 256;
+    int it1[NR1], it2[NR2];
+    stp_p3walk W3;
+    {
+        const stp_cgeo G = ct_geo<R>(T);
+#pragma unroll
+        for (int k = 0; k < NR1; k++) it1[k] = ct_p1_decode<R>(G, tid + 256 * k);
+#pragma unroll
+        for (int k = 0; k < NR2; k++) it2[k] = ct_p2_decode<R>(G, tid + 256 * k);
+        W3 = ct_p3_walk(G, tid, 256);
+    }
     // the min/max cell this lane looks at (the same for all images): the cells overlapping the tile's input
     // window [ty0-R-2, ty0+CT_Y+R+2) x [tx0-R-2, tx0+CT_X+R+2) clipped to the image, at most 8 x 7
     int cell_off = -1;
@@ -362,17 +441,33 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
                 continue;
             }
         }
-        if (yin && xin) canny_p1_blk_g<R, true, true>(tid, nt, T, sW, gimg, sV);
-        else if (yin) canny_p1_blk_g<R, true>(tid, nt, T, sW, gimg, sV);
-        else canny_p1_blk_g<R, false>(tid, nt, T, sW, gimg, sV);
+#pragma unroll
+        for (int k = 0; k < NR1; k++) {               // this thread's vertical-pass items (decoded once per workgroup)
+            int it = it1[k];
+            asm volatile("" : "+v"(it));              // opaque per image: everything derived from the item (row masks, addresses)
+                                                      // is recomputed here instead of being hoisted out of the image loop into
+                                                      // dozens of spilled scalar registers
+            if (it >= 0) {
+                if (it >> 16) canny_p1_zero<R>(it & 255, (it >> 8) & 255, sV);
+                else if (yin) canny_p1_item<R, true>(T, it & 255, (it >> 8) & 255, sW, gimg, sV);
+                else canny_p1_item<R, false>(T, it & 255, (it >> 8) & 255, sW, gimg, sV);
+            }
+        }
         __syncthreads();
 #if defined(STP_ABLATE_CANNY_P1)      /* timing-only build: vertical pass only */
         if (tid == 0) low[img * (STP_FRAME_MAX * STP_NW)] = (stp_u64)sV[70];
         __syncthreads();
         continue;
 #endif
-        if (xin) canny_p2_blk<R, true>(tid, nt, T, sW, sV, sB, sBB, sS, fd);
-        else canny_p2_blk<R, false>(tid, nt, T, sW, sV, sB, sBB, sS, fd);
+#pragma unroll
+        for (int k = 0; k < NR2; k++) {
+            int it = it2[k];
+            asm volatile("" : "+v"(it));
+            if (it >= 0) {
+                if (xin) canny_p2_item<R, true>(T, it & 255, it >> 8, sW, sV, sB, sBB, sS, fd);
+                else canny_p2_item<R, false>(T, it & 255, it >> 8, sW, sV, sB, sBB, sS, fd);
+            }
+        }
         __syncthreads();
 #if defined(STP_ABLATE_CANNY_P12)     /* timing-only build: Gaussian passes only */
         if (tid == 0) low[img * (STP_FRAME_MAX * STP_NW)] = (stp_u64)sS[70];
@@ -383,10 +478,21 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
             canny_p3_ring(tid, nt, T, sS);
             __syncthreads();
         }
-        canny_p3_in(tid, nt, sS, sM);
+        canny_p3_collect(tid, T, W3, sS, sM, sQ, sQn);
         __syncthreads();
-        canny_nms_pack(tid, T, sS, sM, sQ, sBits, low + img * (STP_FRAME_MAX * STP_NW), high + img * (STP_FRAME_MAX * STP_NW));
+        canny_nms_queue(tid, T, sS, sM, sQ, *sQn, sBits);
         __syncthreads();     // sM / sQ alias sV: the NMS must be done before the next vertical pass writes it
+        if (tid < CT_Y) {    // the tile's class words of this image; the thread clears the two words it has read (the
+                             // next image's candidates arrive two barriers later)
+            const int y = T.ty0 + tid;
+            const stp_u64 lo = sBits[tid], hi = sBits[CT_Y + tid];
+            sBits[tid] = 0ull; sBits[CT_Y + tid] = 0ull;
+            if (y < S) {
+                low[img * (STP_FRAME_MAX * STP_NW) + y * STP_NW + (T.tx0 >> 6)] = lo;
+                high[img * (STP_FRAME_MAX * STP_NW) + y * STP_NW + (T.tx0 >> 6)] = hi;
+            }
+        }
+        if (tid == 64) *sQn = 0;
     }
 }
 
