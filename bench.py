@@ -141,9 +141,20 @@ def spawn_ranks(n, argv):
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    # poll: when one rank dies the others would wait for it in the next collective until their own time-out, so the
+    # rest is terminated (never re-launched) and the run reports the failure at once
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(r))
+            if r != 0:
+                for q in live:
+                    q.terminate()
     return rc
 
 
@@ -181,29 +192,52 @@ def main():
     rehearse_reduce = False
     if rehearse:
         local_rank = 0
+    comm, comm_note, pg = 'none', 'single process', None
     if world > 1:
         import torch.distributed as dist
+        import datetime
+        import threading
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if rehearse:
-            dist.init_process_group('gloo', rank=rank, world_size=world)
-        else:
-            # the group only carries the barrier and the max-over-ranks time (the path has no data collective): RCCL
-            # when it comes up, gloo otherwise -- a rank that cannot join must not cost the whole measurement
+        # The path has no data collective; the group only carries the barrier and the max-over-ranks time.  A gloo group
+        # comes up first and is the control plane; RCCL is then probed on a group of its own (one all_reduce under a
+        # watchdog) and every rank reports its outcome over gloo, so the choice is made COLLECTIVELY: RCCL carries the
+        # timing scalars iff it worked on every rank, gloo otherwise -- and the JSON line says which (`config.comm`).
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        ok, note = 0, 'rehearsal on one device: gloo only'
+        if not rehearse:
             torch.cuda.set_device(local_rank)
-            try:
-                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-                probe = torch.zeros(1, device='cuda')
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-            except Exception as e:      # noqa: BLE001
-                print('bench.py: RCCL group failed (%s); using gloo for the timing scalars' % str(e)[:120], file=sys.stderr, flush=True)
+            box = {}
+
+            def _probe():
                 try:
-                    dist.destroy_process_group()
-                except Exception:       # noqa: BLE001
-                    pass
-                os.environ['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29500')) + 1)
-                dist.init_process_group('gloo', rank=rank, world_size=world)
-                rehearse_reduce = True
+                    g = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=120))
+                    t = torch.ones(1, device=torch.device('cuda', local_rank))
+                    dist.all_reduce(t, group=g)
+                    torch.cuda.synchronize()
+                    box['pg'], box['sum'] = g, float(t.item())
+                except Exception as e:      # noqa: BLE001
+                    box['err'] = str(e)[:160]
+            th = threading.Thread(target=_probe, daemon=True)
+            th.start()
+            th.join(90)
+            if th.is_alive():
+                note = 'RCCL probe timed out on rank %d' % rank
+            elif 'err' in box:
+                note = 'RCCL probe failed on rank %d: %s' % (rank, box['err'])
+            elif int(box.get('sum', 0)) != world:
+                note = 'RCCL probe summed %s over %d ranks' % (box.get('sum'), world)
+            else:
+                ok, note, pg = 1, 'RCCL all_reduce over %d ranks' % world, box['pg']
+        flags = [None] * world
+        dist.all_gather_object(flags, (ok, note))
+        if all(f[0] for f in flags):
+            comm, comm_note = 'nccl', note
+        else:
+            comm, pg = 'gloo', None
+            comm_note = '; '.join(sorted({f[1] for f in flags if not f[0]}))
+            if rank == 0:
+                print('bench.py: timing scalars over gloo (%s)' % comm_note, file=sys.stderr, flush=True)
+        rehearse_reduce = comm == 'gloo'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     rdev = 'cpu' if (rehearse or rehearse_reduce) else 'cuda'      # where the timing scalars are reduced
@@ -300,7 +334,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=pg)        # pg: the RCCL group when every rank's probe succeeded, else None = gloo
         torch.cuda.synchronize()
         ctx.synchronize()
 
@@ -318,15 +352,19 @@ def main():
     dt, total_px, total_rec, rank_ms = dt_rank, contact_px, nrec, [dt_rank / args.steps * 1e3]
     if world > 1:
         tmax = torch.tensor([dt_rank], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=pg)
         dt = float(tmax.item())
         tsum = torch.tensor([contact_px, float(nrec)], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM, group=pg)
         total_px, total_rec = float(tsum[0].item()), int(tsum[1].item())
         allt = [torch.zeros(1, dtype=torch.float64, device=rdev) for _ in range(world)]
-        dist.all_gather(allt, torch.tensor([dt_rank / args.steps * 1e3], dtype=torch.float64, device=rdev))
+        dist.all_gather(allt, torch.tensor([dt_rank / args.steps * 1e3], dtype=torch.float64, device=rdev), group=pg)
         rank_ms = [float(t.item()) for t in allt]
     value = total_px * args.steps / dt / 1e6
+    devnames = [torch.cuda.get_device_name(local_rank)]
+    if world > 1:
+        devnames = [None] * world
+        dist.all_gather_object(devnames, '%d:%s' % (local_rank, torch.cuda.get_device_name(local_rank)))
 
     if rank == 0:
         image_px = contact_px * 6                                   # this rank, per step
@@ -337,7 +375,9 @@ def main():
         pmc = _load_pmc('genome' if not args.bins and args.workload == 'genome' else
                         'chr16' if not args.bins else 'bins%d' % args.bins)
         traffic, valu = None, None
-        if pmc and dom in pmc.get('kernels', {}):
+        # counter-derived figures only when the committed counters were collected on the sources of THIS library
+        pmc_fresh = bool(pmc) and pmc.get('src_sha') == hip.source_hash()
+        if pmc_fresh and dom in pmc.get('kernels', {}):
             k = pmc['kernels'][dom]
             if k.get('fetch_kb') is not None and k.get('write_kb') is not None:
                 # per launch of the dominant kernel: FETCH_SIZE doubled (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE
@@ -352,7 +392,9 @@ def main():
                         'source': pmc.get('tag')}
         roof = {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                'traffic_source': (pmc.get('tag') if traffic is not None else None),
+                'traffic_source': (pmc.get('tag') if traffic is not None else
+                                   ('stale: %s was collected on other kernel sources' % pmc.get('tag')) if pmc and not pmc_fresh else None),
+                'limiter': ('fp64_valu' if valu and valu['frac'] > ach / HBM_PEAK_GBS else 'hbm'),
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4), 'launches_per_step': d['launches'] / args.steps,
                 'alg_bytes_per_launch': d['alg_bytes'] / d['launches'],
                 'fp64_valu': valu,
@@ -375,6 +417,7 @@ def main():
                           'sharding': 'contiguous (chromosome x frame) spans of equal frame count, one process per GPU, '
                                       'no collective on the data path',
                           'rank_ms_per_step': [round(t, 3) for t in rank_ms], 'setup_s': round(setup_s, 1),
+                          'comm': comm, 'comm_note': comm_note, 'devices': devnames,
                           'library': hip.LIB_PATH},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
@@ -384,6 +427,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(band_h, hw, st, en, [float(m) for m in Ms[ci]],
                                                '%s (%d bins, %d frames) of the same genome' % (names[ci], nbins[ci], len(st)))
             del band_h
+            out['cpu_baseline']['reference_python'] = reference_python_figure()
         else:
             out['cpu_baseline'] = None
         if world == 1 and not args.no_e2e and not args.no_score:
@@ -391,7 +435,9 @@ def main():
         print(json.dumps(out), flush=True)
     hb.close()
     if world > 1:
-        dist.barrier()
+        dist.barrier()                    # gloo control group
+        if comm == 'gloo' and not rehearse:
+            os._exit(0)                   # a failed / hung RCCL probe must not hold the exit
         dist.destroy_process_group()
 
 
@@ -429,6 +475,33 @@ class _DeviceSelector:
 
     def row_nonzero(self, region, region2=None):
         return (self._block(region, region2) > 0).any(dim=1).cpu().numpy()
+
+
+def reference_python_figure():
+    """The reference's own rate, measured in the BUILD container (the reference's files never travel to the GPU box):
+    wall times stored with the config-size fixture tests/golden/e2e_chr16.npz (oracle/refharness/gen_golden.py chr16 --
+    the unmodified reference, numcores = 8, chr16-size chromosome, maxpixel 0.95-0.99 = BASELINE.json configs[1])."""
+    try:
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', 'e2e_chr16.npz'))
+        T = dict(zip([str(k) for k in g['time_keys']], [float(v) for v in g['time_s']]))
+        px = 0.0                                  # contact-px of one level: sum of S^2 over the 99 frames
+        from stripenn_amd import synth
+        nb = -(-int(g['sizes'][0]) // int(g['resol']))
+        nanb = synth.SynthChrom(nb, int(g['seed0'])).nan_bins
+        for i in range(-(-nb // 200)):
+            a, b = (0 if i == 0 else i * 200 - 100), min((i + 1) * 200 + 99, nb - 1)
+            S = (b - a + 1) - int(((nanb >= a) & (nanb <= b)).sum())
+            px += float(S) * S
+        ext = sum(T['extract%d' % i] for i in range(5))
+        return {'value': round(5 * px / ext / 1e6, 3), 'unit': 'contact-Mpx/s', 'cores': int(g['core']), 'kind': 'reference',
+                'where': 'build container (%s), NOT this box' % str(g['host']),
+                'sample': 'the five extract calls (StripeSearch of 99 frames + RemoveRedundant + pvalue per level) of the '
+                          'unmodified reference on the chr16-size chromosome: %.1f s; whole compute incl. quantile, '
+                          'expected values and background: %.1f s = %.3f contact-Mpx/s'
+                          % (ext, T['config1_total'], 5 * px / T['config1_total'] / 1e6),
+                'source': 'tests/golden/e2e_chr16.npz (time_keys / time_s)'}
+    except Exception as e:      # noqa: BLE001 -- the figure is informative; its absence must not cost the line
+        return {'value': None, 'error': str(e)[:120]}
 
 
 def _load_pmc(workload):

@@ -85,6 +85,19 @@ def gray(g, b, bf=3):
     return out
 
 
+def gray_alt(g, b, bf=3, box_fma=False, order=0):
+    """so_gray_alt: the grey image under the deterministic arithmetic alternatives of a real OpenCV build
+    (tools/cv2_ambiguity.py only)."""
+    S = g.shape[0]
+    out = np.empty((S, S), dtype=np.float32)
+    L = lib()
+    L.so_gray_alt.argtypes = [np.ctypeslib.ndpointer(np.float64, flags='C'), C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                              np.ctypeslib.ndpointer(np.float32, flags='C')]
+    L.so_gray_alt.restype = None
+    L.so_gray_alt(np.ascontiguousarray(g), S, float(b), int(bf), int(bool(box_fma)), int(order), out)
+    return out
+
+
 def canny(gray_img, gw, gr, debug=False):
     S = gray_img.shape[0]
     edges = np.zeros((S, S), dtype=np.uint8)
@@ -373,3 +386,16 @@ def nearest_from_pixels(bin1, bin2, count, weight, lo, nrows):
     off = j > i
     np.minimum.at(left, j[off], (j - i)[off])
     return right, left
+
+
+# ------------------------------------------------------------------ seeimage
+def window_rgb(A, M):
+    """seeimage.py:78-85: the float RGB image the reference hands to imshow (values in [0, 1], NaN where A is NaN):
+    red = 1, green = blue = clip((255 * (M - A) / M) / 255, 0, 1) with negatives zeroed first."""
+    A = np.asarray(A, dtype=np.float64)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        blue = 255 * (M - A) / M
+        blue[np.where(blue < 0)] = 0
+        plane = blue / 255
+    img = np.stack([np.ones_like(plane), plane, plane], axis=-1)
+    return np.clip(img, a_min=0, a_max=1)

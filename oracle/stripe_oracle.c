@@ -109,6 +109,45 @@ SO_API void so_gray(const double* g, int S, double b, int bf, float* gray)
     free(adj);
 }
 
+/* so_gray with the DETERMINISTIC alternatives a real OpenCV build may use for the two unpinned calls (cv2 is absent;
+ * oracle/refharness/standins/cv2.py is the specification) -- for tools/cv2_ambiguity.py only, never a parity target:
+ *   box   != 0: cv.filter2D accumulates with a fused multiply-add, acc = fma(k, px, acc) (an -mfma / AVX2 build);
+ *   order == 1: RGB2GRAY as fma(B, cb, fma(G, cg, R * cr));  order == 2: fma(R, cr, fma(G, cg, B * cb)). */
+SO_API void so_gray_alt(const double* g, int S, double b, int bf, int box, int order, float* gray)
+{
+    double k = (1.0 - 0.0) / (b - 0.0);
+    double kv = 1.0 / (double)(bf * bf);
+    int a = bf / 2;
+    double* adj = (double*)malloc(sizeof(double) * (size_t)S * S);
+    for (int64_t i = 0; i < (int64_t)S * S; i++) adj[i] = so_bright(g[i], b, k);
+    double radj = 1.0 * (1.0 - 0.0) + 0.0;
+    double rb = 0.0;
+    for (int t = 0; t < bf * bf; t++) rb = box ? fma(kv, radj, rb) : rb + kv * radj;
+    if (rb < 0.0) rb = 0.0;
+    if (rb > 1.0) rb = 1.0;
+    float r32 = (float)rb;
+    for (int y = 0; y < S; y++) {
+        for (int x = 0; x < S; x++) {
+            double acc = 0.0;
+            for (int ky = 0; ky < bf; ky++) {
+                int yy = so_reflect101(y + ky - a, S);
+                for (int kx = 0; kx < bf; kx++) {
+                    int xx = so_reflect101(x + kx - a, S);
+                    acc = box ? fma(kv, adj[(int64_t)yy * S + xx], acc) : acc + kv * adj[(int64_t)yy * S + xx];
+                }
+            }
+            if (acc < 0.0) acc = 0.0;
+            if (acc > 1.0) acc = 1.0;
+            float g32 = (float)acc, v;
+            if (order == 1) v = fmaf(g32, 0.114f, fmaf(g32, 0.587f, r32 * 0.299f));
+            else if (order == 2) v = fmaf(r32, 0.299f, fmaf(g32, 0.587f, g32 * 0.114f));
+            else { v = r32 * 0.299f; v = v + g32 * 0.587f; v = v + g32 * 0.114f; }
+            gray[(int64_t)y * S + x] = v;
+        }
+    }
+    free(adj);
+}
+
 /* ------------------------------------------------------------------ */
 /* scipy 1.7.1 NI_Correlate1D, symmetric odd kernel, mode='constant' cval=0:
  *   o = x[0]*w[0]; for k = r..1: o += (x[-k] + x[+k]) * w[k]      (outermost tap first) */

@@ -491,60 +491,204 @@ __global__ __launch_bounds__(256) void k_stripe_mean(stp_bandref B, const stp_re
 }
 
 // ---------------------------------------------------------------------------------------------
-// StripeSearch's medpixel = np.quantile(submat[submat > 0], 0.5) (getStripe.py:885): exact order
-// statistics over the frame's positive pixels (positive doubles order like their bit patterns).
-// out[f*3 + {0,1,2}] = a[k0], a[k1], N with k0 = (N-1)/2, k1 = N/2 (numpy's lerp is done on the host).
-//   pass A (inside k_frame_compact's walk): N and the min / max key;  pass B: 8192-bin histogram of the top 13 bits of (key - min)
-//   (range-normalised digits spread the pixels over the bins: no same-address LDS atomics pile-up);
-//   when the selected bin holds <= STP_MED_CAP keys (continuous data: a few dozen) pass C gathers them
-//   into LDS, tracks the smallest key of the higher bins, and ranks are counted in LDS.  Heavily
-//   duplicated data (integer counts) keeps refining 13 bits per pass and ends with a <=/successor pass.
-// One wave walks one frame row at a time (coalesced 512 B segments of the band, no index division).
+// Frame preparation, one workgroup per frame, ONE kernel:
+//   * zero-column removal (getStripe.py:809-821): one lane per column walks the rows in order, so the column sum has
+//     numpy's axis-0 order; consecutive lanes read consecutive band addresses (coalesced, eight row loads in flight);
+//     ballot + prefix give the compaction map nz and S;
+//   * StripeSearch's medpixel = np.quantile(submat[submat > 0], 0.5) (getStripe.py:885): exact order statistics over
+//     the frame's positive pixels (positive doubles order like their bit patterns).  The SAME walk counts them, tracks
+//     the min / max key and fills an 8192-bin histogram of range-normalised digits; the range is estimated beforehand
+//     from eight sampled rows (2 % of the frame) -- it only has to spread the pixels over the bins (no same-address
+//     LDS-atomic pile-up), exactness never depends on it: keys outside the estimate fall into the two end bins.
+//     A second pass gathers the keys of the bin that holds the rank (continuous data: a few dozen) into LDS, tracks the
+//     smallest key of the higher bins, and ranks are counted in LDS.
+//     med[f*3 + {0,1,2}] = a[k0], a[k1], N with k0 = (N-1)/2, k1 = N/2 (numpy's lerp is done on the host).
+//   Two passes over the frame instead of the four of k_frame_compact + k_medpixel (count / min / max, histogram, gather)
+//   that this kernel replaces.  Heavily duplicated data (integer counts) or a selected bin with more than STP_MED_CAP
+//   keys falls back to the general radix select: 13 bits of (key - min) per further pass, then a <= / successor pass.
 #define STP_MED_BINS 8192
 #define STP_MED_CAP 1024
-__global__ __launch_bounds__(1024) void k_medpixel(stp_bandref B, const int32_t* __restrict__ fstart,
-                                                    const int32_t* __restrict__ fn0,
-                                                    const unsigned long long* __restrict__ fstat,
-                                                    double* __restrict__ out)
+#define STP_PREP_NT 512
+__global__ __launch_bounds__(STP_PREP_NT) void k_frame_prep(stp_bandref B, const int32_t* __restrict__ fstart,
+                                                            const int32_t* __restrict__ fn0, int32_t* __restrict__ S_out,
+                                                            int16_t* __restrict__ nz_out, double* __restrict__ med, int keep_all)
 {
+    constexpr int NT = STP_PREP_NT, NWV = NT / 64, BPT = STP_MED_BINS / NT;
     __shared__ unsigned int hist[STP_MED_BINS];
-    __shared__ unsigned int part[1024];
+    __shared__ unsigned int part[NT];
     __shared__ unsigned long long cand[STP_MED_CAP];
-    __shared__ unsigned long long s_prefix, s_hi, s_key[2];
-    __shared__ unsigned int s_k, s_le, s_cnt, s_m;
+    __shared__ unsigned long long s_hi, s_key[2], s_n, s_mn, s_mx;
+    __shared__ unsigned int s_k, s_le, s_cnt, s_m, s_bin;
+    __shared__ int s_wave[NWV];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t st = fstart[f];
     const int n0 = fn0[f];
+    for (int i = tid; i < STP_MED_BINS; i += NT) hist[i] = 0;
+    if (tid == 0) { s_le = 0; s_hi = ~0ull; s_m = 0; s_key[0] = s_key[1] = ~0ull; s_n = 0; s_mn = ~0ull; s_mx = 0; }
+    __syncthreads();
+    const double* p = B.d + st * (int64_t)B.W + (tid + B.hw);          // column tid of row 0 of the frame
+    // ---- range estimate from eight sampled rows
+    {
+        unsigned long long mn = ~0ull, mx = 0;
+        if (tid < n0) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = p[(int64_t)(((2 * q + 1) * n0) >> 4) * (B.W - 1)];
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (v[q] > 0.0) {
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(v[q]);
+                    mn = key < mn ? key : mn; mx = key > mx ? key : mx;
+                }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+            mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+        }
+        if (lane == 0 && mx) { atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
+    }
+    __syncthreads();
+    const unsigned long long smin = s_mx ? s_mn : 0ull;
+    int shift1;
+    {
+        const unsigned long long range = s_mx ? (s_mx - s_mn) : 0ull;
+        const int hb = 64 - __clzll((long long)(range | 1ull));          // bits of the sampled range (>= 1)
+        shift1 = hb > 13 ? hb - 13 : 0;
+    }
+    auto digit1 = [&](unsigned long long key) -> unsigned int {          // monotone in key: bin order = key order
+        if (key <= smin) return 0u;
+        const unsigned long long d = (key - smin) >> shift1;
+        return d < (unsigned long long)(STP_MED_BINS - 1) ? (unsigned int)d : (unsigned int)(STP_MED_BINS - 1);
+    };
+    __syncthreads();                                                      // everyone has read the estimate
+    if (tid == 0) { s_mn = ~0ull; s_mx = 0; }
+    // ---- pass 1: column sums + count / min / max + histogram
+    double sum = 0.0;
+    unsigned long long cnt = 0, mn = ~0ull, mx = 0;
+    if (tid < n0) {
+        for (int r0 = 0; r0 < n0; r0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = (r0 + q < n0) ? p[(int64_t)(r0 + q) * (B.W - 1)] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                double x = v[q];
+                if (x > 0.0) {
+                    const unsigned long long key = (unsigned long long)__double_as_longlong(x);
+                    cnt++; mn = key < mn ? key : mn; mx = key > mx ? key : mx;
+                    atomicAdd(&hist[digit1(key)], 1u);
+                }
+                if (x != x) x = 0.0;
+                if (r0 + q < n0) sum += x;
+            }
+        }
+    }
+    const bool flag = (tid < n0) && (keep_all || sum != 0.0);
+    const unsigned long long bal = __ballot(flag);
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o);
+        const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+    }
+    if (lane == 0) s_wave[wave] = __popcll(bal);
+    __syncthreads();                                                      // (also orders the reset of s_mn / s_mx)
+    if (lane == 0 && cnt) { atomicAdd(&s_n, cnt); atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
+    {
+        int base = 0, total = 0;
+        for (int i = 0; i < NWV; i++) {
+            if (i < wave) base += s_wave[i];
+            total += s_wave[i];
+        }
+        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (flag) nz_out[f * STP_FRAME_MAX + pos] = (int16_t)tid;
+        if (tid == 0) S_out[f] = (keep_all || total > 10) ? total : 0;   // getStripe.py:818
+    }
+    __syncthreads();
+    const unsigned int N = (unsigned int)s_n;
+    if (N == 0) {
+        if (tid == 0) { med[f * 3] = NAN; med[f * 3 + 1] = NAN; med[f * 3 + 2] = 0.0; }
+        return;
+    }
+    const unsigned long long kmin = s_mn, kmax = s_mx;
+    const unsigned int k0 = (N - 1) / 2, k1 = N / 2;
+    // one wave walks one frame row at a time (coalesced 512 B segments of the band, no index division)
     auto scan = [&](auto&& fn) {
-        for (int r = wave; r < n0; r += 16) {
-            const double* p = B.d + (st + r) * (int64_t)B.W + (B.hw - r);
+        for (int r = wave; r < n0; r += NWV) {
+            const double* q0 = B.d + (st + r) * (int64_t)B.W + (B.hw - r);
             double v[7];                        // the whole row (<= 400 pixels) in flight before any use
 #pragma unroll
-            for (int q = 0; q < 7; q++) { const int c = lane + 64 * q; v[q] = c < n0 ? p[c] : 0.0; }
+            for (int q = 0; q < 7; q++) { const int c = lane + 64 * q; v[q] = c < n0 ? q0[c] : 0.0; }
 #pragma unroll
             for (int q = 0; q < 7; q++)
                 if (v[q] > 0.0) fn((unsigned long long)__double_as_longlong(v[q]));
         }
     };
-    if (tid == 0) { s_le = 0; s_hi = ~0ull; s_m = 0; s_key[0] = s_key[1] = ~0ull; }
-    __syncthreads();
-    // pass A (count, min and max key of the positive pixels) was done by k_frame_compact
-    const unsigned int N = (unsigned int)fstat[f * 3];
-    if (N == 0) {
-        if (tid == 0) { out[f * 3] = NAN; out[f * 3 + 1] = NAN; out[f * 3 + 2] = 0.0; }
+    // bin of rank k in the current histogram: BPT bins per lane -> partial sums -> inclusive scan -> locate
+    auto find_bin = [&](unsigned int k) {
+        unsigned int mine = 0;
+        for (int b = 0; b < BPT; b++) mine += hist[tid * BPT + b];
+        part[tid] = mine;
+        __syncthreads();
+        for (int o = 1; o < NT; o <<= 1) {
+            unsigned int v = (tid >= o) ? part[tid - o] : 0;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        const unsigned int incl = part[tid], excl = incl - mine;
+        if (excl <= k && k < incl) {              // exactly one lane
+            unsigned int acc = excl;
+            int d = tid * BPT;
+            for (;; d++) { if (acc + hist[d] > k) break; acc += hist[d]; }
+            s_k = k - acc; s_cnt = hist[d]; s_bin = (unsigned int)d;
+        }
+        __syncthreads();
+    };
+    // ranks k, k + (k1 - k0) among the m gathered keys of the selected bin; s_hi = smallest key of any higher bin
+    auto finish_gathered = [&](unsigned int k) {
+        const unsigned int m = s_m < STP_MED_CAP ? s_m : STP_MED_CAP;
+        for (unsigned int t = tid; t < m; t += NT) {
+            const unsigned long long x = cand[t];
+            unsigned int lo = 0, le = 0;
+            for (unsigned int j = 0; j < m; j++) { const unsigned long long y = cand[j]; lo += (y < x); le += (y <= x); }
+            const unsigned int ka = k, kb = k + (k1 - k0);
+            if (lo <= ka && ka < le) s_key[0] = x;          // equal keys write the same value
+            if (lo <= kb && kb < le) s_key[1] = x;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            med[f * 3] = __longlong_as_double((long long)s_key[0]);
+            med[f * 3 + 1] = __longlong_as_double((long long)((k + (k1 - k0) < m) ? s_key[1] : s_hi));
+            med[f * 3 + 2] = (double)N;
+        }
+    };
+    find_bin(k0);
+    if (s_cnt <= STP_MED_CAP) {
+        // ---- pass 2 (common case): gather the selected bin
+        const unsigned int sel = s_bin, k = s_k;
+        unsigned long long hi_mn = ~0ull;
+        scan([&](unsigned long long key) {
+            const unsigned int b = digit1(key);
+            if (b == sel) { const unsigned int slot = atomicAdd(&s_m, 1u); if (slot < STP_MED_CAP) cand[slot] = key; }
+            else if (b > sel && key < hi_mn) hi_mn = key;
+        });
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long a = __shfl_xor(hi_mn, o); hi_mn = a < hi_mn ? a : hi_mn; }
+        if (lane == 0 && hi_mn != ~0ull) atomicMin(&s_hi, hi_mn);
+        __syncthreads();
+        finish_gathered(k);
         return;
     }
-    const unsigned long long kmin = fstat[f * 3 + 1];
-    const unsigned int k0 = (N - 1) / 2, k1 = N / 2;
+    // ---- general radix select on (key - kmin), 13 bits per pass (heavily duplicated data)
     unsigned int k = k0;
     unsigned long long prefix = 0;              // in the (key - kmin) domain
-    const unsigned long long range = fstat[f * 3 + 2] - kmin;
+    const unsigned long long range = kmax - kmin;
     const int hb = range ? 64 - __clzll((long long)range) : 0;
     int width = hb < 13 ? hb : 13, shift = hb - width;
     bool gathered = false;
     while (width > 0) {
         const int hs = shift + width;           // hs <= 63 here except possibly the very first pass
-        for (int i = tid; i < STP_MED_BINS; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < STP_MED_BINS; i += NT) hist[i] = 0;
         __syncthreads();
         const unsigned long long pfx_hi = hs >= 64 ? 0ull : (prefix >> hs);
         const unsigned int dmask = (1u << width) - 1u;
@@ -554,37 +698,15 @@ __global__ __launch_bounds__(1024) void k_medpixel(stp_bandref B, const int32_t*
             if (hi == pfx_hi) atomicAdd(&hist[(unsigned int)(rel >> shift) & dmask], 1u);
         });
         __syncthreads();
-        // parallel scan: 8 bins per lane -> partial sums -> inclusive scan -> locate the bin of rank k
-        unsigned int mine = 0;
-        for (int b = 0; b < 8; b++) mine += hist[tid * 8 + b];
-        part[tid] = mine;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            unsigned int v = (tid >= o) ? part[tid - o] : 0;
-            __syncthreads();
-            part[tid] += v;
-            __syncthreads();
-        }
-        const unsigned int incl = part[tid], excl = incl - mine;
-        if (excl <= k && k < incl) {              // exactly one lane
-            unsigned int acc = excl;
-            int d = tid * 8;
-            for (;; d++) { if (acc + hist[d] > k) break; acc += hist[d]; }
-            s_k = k - acc;
-            s_cnt = hist[d];
-            s_prefix = prefix | ((unsigned long long)d << shift);
-        }
-        __syncthreads();
-        k = s_k; prefix = s_prefix;
-        const unsigned int cnt = s_cnt;
-        __syncthreads();
+        find_bin(k);
+        k = s_k; prefix |= ((unsigned long long)s_bin << shift);
+        const unsigned int cntb = s_cnt;
         if (shift == 0) break;
-        if (cnt <= STP_MED_CAP) { gathered = true; break; }
+        if (cntb <= STP_MED_CAP) { gathered = true; break; }
         width = shift < 13 ? shift : 13;
         shift -= width;
     }
     if (gathered) {
-        // pass C: keys of the selected bin -> LDS; smallest key of any higher bin = successor fallback
         const unsigned long long sel = prefix >> shift;
         unsigned long long hi_mn = ~0ull;
         scan([&](unsigned long long key) {
@@ -595,37 +717,23 @@ __global__ __launch_bounds__(1024) void k_medpixel(stp_bandref B, const int32_t*
         for (int o = 32; o > 0; o >>= 1) { const unsigned long long a = __shfl_xor(hi_mn, o); hi_mn = a < hi_mn ? a : hi_mn; }
         if (lane == 0 && hi_mn != ~0ull) atomicMin(&s_hi, hi_mn);
         __syncthreads();
-        const unsigned int m = s_m < STP_MED_CAP ? s_m : STP_MED_CAP;
-        if ((unsigned int)tid < m) {
-            const unsigned long long x = cand[tid];
-            unsigned int lo = 0, le = 0;
-            for (unsigned int j = 0; j < m; j++) { const unsigned long long y = cand[j]; lo += (y < x); le += (y <= x); }
-            const unsigned int ka = k, kb = k + (k1 - k0);
-            if (lo <= ka && ka < le) s_key[0] = x;          // equal keys write the same value
-            if (lo <= kb && kb < le) s_key[1] = x;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            out[f * 3] = __longlong_as_double((long long)s_key[0]);
-            out[f * 3 + 1] = __longlong_as_double((long long)((k + (k1 - k0) < m) ? s_key[1] : s_hi));
-            out[f * 3 + 2] = (double)N;
-        }
+        finish_gathered(k);
         return;
     }
     const unsigned long long key0 = kmin + prefix;
     unsigned int le = 0;
-    unsigned long long mn = ~0ull;
+    unsigned long long mnk = ~0ull;
     scan([&](unsigned long long key) {
         if (key <= key0) le++;
-        else if (key < mn) mn = key;
+        else if (key < mnk) mnk = key;
     });
     atomicAdd(&s_le, le);
-    atomicMin(&s_hi, mn);
+    atomicMin(&s_hi, mnk);
     __syncthreads();
     if (tid == 0) {
         const unsigned long long key1 = (s_le > k1) ? key0 : s_hi;
-        out[f * 3] = __longlong_as_double((long long)key0);
-        out[f * 3 + 1] = __longlong_as_double((long long)key1);
-        out[f * 3 + 2] = (double)N;
+        med[f * 3] = __longlong_as_double((long long)key0);
+        med[f * 3 + 1] = __longlong_as_double((long long)key1);
+        med[f * 3 + 2] = (double)N;
     }
 }

@@ -16,67 +16,7 @@
 // device kernels
 // ============================================================================================
 
-// K0: zero-column removal of every frame (getStripe.py:809-821).  One workgroup per frame,
-// one lane per column; rows are walked sequentially so the column sum has numpy's axis-0
-// order (eight row loads in flight at a time); consecutive lanes read consecutive band addresses
-// (coalesced).  The same walk yields the count and the min / max bit pattern of the frame's positive
-// pixels (fstat[f*3 + {0,1,2}]), which is k_medpixel's first radix-select pass.
-__global__ __launch_bounds__(512) void k_frame_compact(const double* __restrict__ band, int W, int hw,
-                                                        const int32_t* __restrict__ fstart,
-                                                        const int32_t* __restrict__ fn0, int32_t* __restrict__ S_out,
-                                                        int16_t* __restrict__ nz_out,
-                                                        unsigned long long* __restrict__ fstat, int keep_all)
-{
-    __shared__ int s_wave[8];
-    __shared__ unsigned long long s_n, s_mn, s_mx;
-    const int f = blockIdx.x, c = threadIdx.x;
-    const int64_t st = fstart[f];
-    const int n0 = fn0[f];
-    if (c == 0) { s_n = 0; s_mn = ~0ull; s_mx = 0; }
-    double sum = 0.0;
-    unsigned long long cnt = 0, mn = ~0ull, mx = 0;
-    if (c < n0) {
-        const double* p = band + st * (int64_t)W + (c + hw);
-        for (int r0 = 0; r0 < n0; r0 += 8) {
-            double v[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = (r0 + q < n0) ? p[(int64_t)(r0 + q) * (W - 1)] : 0.0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                double x = v[q];
-                if (x > 0.0) {
-                    const unsigned long long key = (unsigned long long)__double_as_longlong(x);
-                    cnt++; mn = key < mn ? key : mn; mx = key > mx ? key : mx;
-                }
-                if (x != x) x = 0.0;
-                if (r0 + q < n0) sum += x;
-            }
-        }
-    }
-    const bool flag = (c < n0) && (keep_all || sum != 0.0);
-    const unsigned long long bal = __ballot(flag);
-    const int lane = c & 63, wv = c >> 6;
-    for (int o = 32; o > 0; o >>= 1) {
-        cnt += __shfl_xor(cnt, o);
-        const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
-        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
-    }
-    if (lane == 0) s_wave[wv] = __popcll(bal);
-    __syncthreads();
-    if (lane == 0 && cnt) { atomicAdd(&s_n, cnt); atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
-    int base = 0, total = 0;
-    for (int i = 0; i < 8; i++) {
-        if (i < wv) base += s_wave[i];
-        total += s_wave[i];
-    }
-    const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-    if (flag) nz_out[f * STP_FRAME_MAX + pos] = (int16_t)c;
-    __syncthreads();
-    if (c == 0) {
-        S_out[f] = (keep_all || total > 10) ? total : 0;   // getStripe.py:818
-        fstat[f * 3] = s_n; fstat[f * 3 + 1] = s_mn; fstat[f * 3 + 2] = s_mx;
-    }
-}
+// (frame preparation -- zero-column removal and medpixel of every frame -- is k_frame_prep in stp_score.h)
 
 // K-A: image build + brightness + mean blur + grey for all brightness levels of one tile.
 template <int AMAX>
@@ -929,10 +869,18 @@ struct stp_frames {
     std::vector<double> h_med;
 };
 
+// Grow-only workspace shared by the searches of a context.  Several searches may be in flight on the context's stream
+// and their queued kernels read these buffers, so a buffer is released only after the stream has drained -- waited
+// for explicitly here (not left to hipFree's implicit device synchronisation).  Growth is rare: the chunk size is
+// fixed (<= 3 072 images), so after the first full-size search of a context nothing grows again.
 static hipError_t ws_get(stp_ctx* ctx, int slot, size_t bytes, void** out)
 {
     if (ctx->ws_bytes[slot] < bytes) {
-        if (ctx->ws[slot]) (void)hipFree(ctx->ws[slot]);
+        if (ctx->ws[slot]) {
+            hipError_t es = hipStreamSynchronize(ctx->stream);
+            if (es != hipSuccess) return es;
+            (void)hipFree(ctx->ws[slot]);
+        }
         ctx->ws[slot] = nullptr; ctx->ws_bytes[slot] = 0;
         hipError_t e = hipMalloc(&ctx->ws[slot], bytes);
         if (e != hipSuccess) return e;
@@ -1073,7 +1021,13 @@ int stp_ctx_create(int device_ordinal, stp_ctx** out)
     }
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return STP_E_HIP; }
     ctx->own_stream = true;
-    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return STP_E_HIP; }
+    {
+        // frame preparation feeds the next search and the score kernels are small: the auxiliary stream runs at the
+        // highest priority, so its kernels get compute units as soon as the chain's workgroups retire
+        int plo = 0, phi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+        if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, phi) != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return STP_E_HIP; }
+    }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
     *out = ctx;
@@ -1216,28 +1170,21 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
     FRCHK(hipMemcpyAsync(fr->d_n0, fr->h_n0.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->aux));
     FRCHK(hipMemsetAsync(fr->d_nz, 0, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), ctx->aux));
     double* d_med = nullptr;
-    unsigned long long* d_fstat = nullptr;
     FRCHK(pool_alloc(ctx, (size_t)n * 3 * sizeof(double), (void**)&d_med));
     {
-        hipError_t ea = pool_alloc(ctx, (size_t)n * 3 * sizeof(unsigned long long), (void**)&d_fstat);
-        if (ea != hipSuccess) pool_release(ctx, d_med, (size_t)n * 3 * sizeof(double));
-        FRCHK(ea);
-    }
-    {
+        // zero-column removal + medpixel (two order statistics per frame by radix select, numpy's lerp on the host) in
+        // one kernel: the frame is read twice (walk + gather) instead of four times
         double bytes = 0;
         for (int i = 0; i < n; i++) bytes += 8.0 * fr->h_n0[i] * fr->h_n0[i];
-        prof_scope ps(ctx, "frame_compact", bytes, ctx->aux);
-        hipLaunchKernelGGL(k_frame_compact, dim3(n), dim3(512), 0, ctx->aux, band->d, band->W, band->hw, fr->d_start,
-                           fr->d_n0, fr->d_S, fr->d_nz, d_fstat, (flags & STP_FRAMES_KEEP_ALL) ? 1 : 0);
-    }
-    FRCHK(hipGetLastError());
-    {
-        // medpixel: two order statistics per frame by radix select, numpy's lerp on the host
-        double bytes = 0;
-        for (int i = 0; i < n; i++) bytes += 8.0 * fr->h_n0[i] * fr->h_n0[i];
-        prof_scope ps(ctx, "medpixel", bytes, ctx->aux);
+        prof_scope ps(ctx, "frame_prep", bytes, ctx->aux);
         stp_bandref B{band->d, band->nrows, band->W, band->hw};
-        hipLaunchKernelGGL(k_medpixel, dim3(n), dim3(1024), 0, ctx->aux, B, fr->d_start, fr->d_n0, d_fstat, d_med);
+        hipLaunchKernelGGL(k_frame_prep, dim3(n), dim3(STP_PREP_NT), 0, ctx->aux, B, fr->d_start, fr->d_n0, fr->d_S, fr->d_nz, d_med,
+                           (flags & STP_FRAMES_KEEP_ALL) ? 1 : 0);
+    }
+    {
+        hipError_t el = hipGetLastError();
+        if (el != hipSuccess) pool_release(ctx, d_med, (size_t)n * 3 * sizeof(double));
+        FRCHK(el);
     }
     std::vector<double> hm((size_t)n * 3);
     hipError_t e1 = hipMemcpyAsync(hm.data(), d_med, hm.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->aux);
@@ -1246,7 +1193,6 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
                                               hipMemcpyDeviceToHost, ctx->aux);
     if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->aux);
     pool_release(ctx, d_med, (size_t)n * 3 * sizeof(double));
-    pool_release(ctx, d_fstat, (size_t)n * 3 * sizeof(unsigned long long));
     FRCHK(e1);
     for (int i = 0; i < n; i++) {
         const double a = hm[3 * i], b = hm[3 * i + 1], N = hm[3 * i + 2];
@@ -1522,7 +1468,7 @@ struct stp_search {
     int nlev = 0, rcap = STP_RCAP, nchunks = 0;
     void* d_out = nullptr; size_t out_bytes = 0;
     long long* d_tot = nullptr; size_t tot_bytes = 0;
-    void* pin = nullptr; size_t pin_bytes = 0, guess = 0;
+    void* pin = nullptr; size_t pin_bytes = 0, guess = 0, rec_off = 64;   // pinned: totals | parameters | records
     hipEvent_t done = nullptr;
     long long n = -1;                 // records, once known
 };
@@ -1563,9 +1509,36 @@ static int search_enqueue(stp_ctx* ctx, stp_search* s)
     double* dM = (double*)pPar;
     double* dB = dM + n_levels;
     double* dW = dB + nb;
-    HIPCHK(hipMemcpyAsync(dM, s->M.data(), n_levels * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(dB, prm->bright, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(dW, prm->gauss_w, nwt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // the parameters travel from the search's own pinned buffer (a copy from pageable memory could block the host
+    // behind the searches already queued): [64, 64 + phdr) of s->pin, the totals come back into [0, 16)
+    const size_t npar = (size_t)(n_levels + nb + nwt);
+    const size_t phdr = (npar * sizeof(double) + 63) / 64 * 64;
+    s->guess = std::min((size_t)fr->n * ipf * (size_t)rcap, (size_t)ctx->rec_guess);
+    {
+        const size_t pb = 64 + phdr + std::max(s->guess, (size_t)1024) * sizeof(stp_stripe_rec);
+        if (s->pin_bytes < pb) {
+            if (s->pin) (void)hipHostFree(s->pin);
+            s->pin = nullptr; s->pin_bytes = 0;
+            for (size_t i = 0; i < ctx->pin_free.size(); i++)
+                if (ctx->pin_free[i].first >= pb) {
+                    s->pin = ctx->pin_free[i].second; s->pin_bytes = ctx->pin_free[i].first;
+                    ctx->pin_free[i] = ctx->pin_free.back(); ctx->pin_free.pop_back();
+                    break;
+                }
+            if (!s->pin) {
+                HIPCHK(hipHostMalloc(&s->pin, pb, hipHostMallocDefault));
+                s->pin_bytes = pb;
+            }
+        }
+    }
+    s->rec_off = 64 + phdr;
+    {
+        double* hp = (double*)((char*)s->pin + 64);
+        memcpy(hp, s->M.data(), n_levels * sizeof(double));
+        memcpy(hp + n_levels, prm->bright, nb * sizeof(double));
+        memcpy(hp + n_levels + nb, prm->gauss_w, nwt * sizeof(double));
+        HIPCHK(hipMemcpyAsync(dM, hp, npar * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
     // output of the whole batch: every image may fill its slots
     const size_t ocap = (size_t)fr->n * ipf * (size_t)rcap;
     if (s->out_bytes < ocap * sizeof(stp_stripe_rec)) {
@@ -1600,26 +1573,10 @@ static int search_enqueue(stp_ctx* ctx, stp_search* s)
     }
     // the count travels with as many records as the previous search of this context produced (+25 %): one round trip
     // in the common case
-    s->guess = std::min(ocap, (size_t)ctx->rec_guess);
-    const size_t pb = 64 + std::max(s->guess, (size_t)1024) * sizeof(stp_stripe_rec);
-    if (s->pin_bytes < pb) {
-        if (s->pin) (void)hipHostFree(s->pin);
-        s->pin = nullptr; s->pin_bytes = 0;
-        for (size_t i = 0; i < ctx->pin_free.size(); i++)
-            if (ctx->pin_free[i].first >= pb) {
-                s->pin = ctx->pin_free[i].second; s->pin_bytes = ctx->pin_free[i].first;
-                ctx->pin_free[i] = ctx->pin_free.back(); ctx->pin_free.pop_back();
-                break;
-            }
-        if (!s->pin) {
-            HIPCHK(hipHostMalloc(&s->pin, pb, hipHostMallocDefault));
-            s->pin_bytes = pb;
-        }
-    }
-    s->guess = std::min(s->guess, (s->pin_bytes - 64) / sizeof(stp_stripe_rec));
+    s->guess = std::min(s->guess, (s->pin_bytes - s->rec_off) / sizeof(stp_stripe_rec));
     HIPCHK(hipMemcpyAsync(s->pin, s->d_tot + 2 * s->nchunks, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     if (s->guess)
-        HIPCHK(hipMemcpyAsync((char*)s->pin + 64, s->d_out, s->guess * sizeof(stp_stripe_rec), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync((char*)s->pin + s->rec_off, s->d_out, s->guess * sizeof(stp_stripe_rec), hipMemcpyDeviceToHost, ctx->stream));
     if (!s->done) HIPCHK(hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
     HIPCHK(hipEventRecord(s->done, ctx->stream));
     s->n = -1;
@@ -1682,7 +1639,7 @@ int stp_stripe_search_fetch(stp_ctx* ctx, stp_search* s, stp_stripe_rec* out, in
     if (rc == STP_OK && n > cap) rc = set_err(ctx, STP_E_CAPACITY, "output capacity too small for " + std::to_string(n) + " records");
     if (rc == STP_OK && n > 0) {
         const size_t have = std::min((size_t)n, s->guess);
-        memcpy(out, (char*)s->pin + 64, have * sizeof(stp_stripe_rec));
+        memcpy(out, (char*)s->pin + s->rec_off, have * sizeof(stp_stripe_rec));
         if ((size_t)n > have) {
             hipError_t e = hipMemcpyAsync(out + have, (stp_stripe_rec*)s->d_out + have, ((size_t)n - have) * sizeof(stp_stripe_rec),
                                           hipMemcpyDeviceToHost, ctx->stream);

@@ -137,13 +137,34 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources the library is built from: profiles/pmc_current.json records it,
+    and bench.py prints counter-derived figures only when the counters were collected on these same sources."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    for f in sorted(glob.glob(os.path.join(_HERE, 'csrc', '*.h')) + glob.glob(os.path.join(_HERE, 'csrc', '*.hip')) +
+                    glob.glob(os.path.join(root, 'include', '*.h'))):
+        with open(f, 'rb') as fh:
+            h.update(os.path.basename(f).encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
 def count_column(count):
-    """(contiguous array, STP_COUNT_* code) of a pixels/count column: float64 columns travel as they are, anything
-    else as int32."""
+    """(contiguous array, STP_COUNT_* code) of a pixels/count column: one of the two types the C ABI takes.  int32
+    travels as it is; every float column and every integer column with a value outside the int32 range travels as
+    float64 (exact below 2^53) -- nothing is truncated or wrapped on the way to the device."""
     c = np.asarray(count)
-    if c.dtype == np.float64:
-        return np.ascontiguousarray(c), 1
-    return np.ascontiguousarray(c, dtype=np.int32), 0
+    if c.dtype == np.int32:
+        return np.ascontiguousarray(c), 0
+    if c.dtype.kind == 'f':
+        return np.ascontiguousarray(c, dtype=np.float64), 1
+    if c.dtype.kind in 'iub':
+        if c.size and (int(c.min()) < -2**31 or int(c.max()) > 2**31 - 1):
+            return np.ascontiguousarray(c, dtype=np.float64), 1
+        return np.ascontiguousarray(c, dtype=np.int32), 0
+    raise TypeError('pixels/count must be an integer or floating-point column, not %s' % c.dtype)
 
 
 class Context:

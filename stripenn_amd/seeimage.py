@@ -2,8 +2,8 @@
 (reference: seeimage.py:32-97).  Both steps run on the device: the whole-chromosome quantile that sets the
 saturation level goes through the backend's exact select like `compute` does, and the window is coloured from the
 resident band by the image-build arithmetic of StripeSearch (stp_window_plane: getStripe.py:889-895, red = 1,
-green = blue = clip((255 * (M - A) / M) / 255, 0, 1)); matplotlib only draws the array.  `window_rgb` is the same
-arithmetic in numpy (what the reference's lines 78-85 compute), kept as the checker of the GPU test."""
+green = blue = clip((255 * (M - A) / M) / 255, 0, 1)); matplotlib only draws the array.  (The numpy restatement of the reference's
+lines 78-85 that checks the kernel lives with the test infrastructure, not in the product.)"""
 import sys
 
 import numpy as np
@@ -11,17 +11,6 @@ import numpy as np
 from . import getStripe
 from .io import open_matrix
 from .stripenn import resolve_norm
-
-
-def window_rgb(A, M):
-    """The float RGB image the reference hands to imshow (values in [0, 1], NaN where A is NaN)."""
-    A = np.asarray(A, dtype=np.float64)
-    with np.errstate(invalid='ignore', divide='ignore'):
-        blue = 255 * (M - A) / M
-        blue[np.where(blue < 0)] = 0
-        plane = blue / 255
-    img = np.stack([np.ones_like(plane), plane, plane], axis=-1)
-    return np.clip(img, a_min=0, a_max=1)
 
 
 def seeimage(cool, position, maxpixel, norm, out, slow, seed, backend=None, device=0):

