@@ -181,10 +181,16 @@ class getStripe:
         res = {}
         chrom_names = list(coolinfo.chromsizes.keys())
         chridx = sorted(c for c in range(len(chrom_names)) if chrom_names[c] in ChrList)
-        for ci in chridx:
+        for pos, ci in enumerate(chridx):
             CHROM = chrom_names[ci]
             nb = self._nbins(CHROM)
             size = int(self.chromnames2sizes[str(CHROM)])
+            if hasattr(self.unbalLib, 'prefetch') and pos + 1 < len(chridx):
+                # a table read lazily from a .cool file fetches the NEXT chromosome's pixel columns on a host thread
+                # while this one is packed, selected and (later) searched
+                nxt = str(chrom_names[chridx[pos + 1]])
+                if nxt not in self._bands:
+                    self.unbalLib.prefetch(nxt)
             sel = self.backend.select_open()
             try:
                 if hasattr(self.unbalLib, 'chrom_pixels'):

@@ -58,7 +58,7 @@ def open_matrix(cool):
             table = pixels.PixelTable.load(spec)
         else:
             path, _, group = spec.partition('::')
-            table = pixels.PixelTable.from_cool(path, group or None)
+            table = pixels.CoolTable(path, group.lstrip('/') or None)          # lazy: pixel columns stay in the file
         return pixel_matrix(table)
     try:
         import cooler
@@ -70,5 +70,5 @@ def open_matrix(cool):
                               'without them)' % cool) from e
         from . import pixels
         path, _, group = str(cool).partition('::')
-        return pixel_matrix(pixels.PixelTable.from_cool(path, group.lstrip('/') or None))
+        return pixel_matrix(pixels.CoolTable(path, group.lstrip('/') or None))      # lazy: pixel columns stay in the file
     return cooler.Cooler(cool)

@@ -85,6 +85,12 @@ class PixelTable:
         a, b = np.searchsorted(self.bin1_id, [g0, g1], side='left')
         return int(a), int(b)
 
+    def count_nonnegative(self):
+        return len(self.count) == 0 or self.count.min() >= 0
+
+    def prefetch(self, chrom):
+        """(in-memory table: nothing to read ahead)"""
+
     def chrom_pixels(self, chrom):
         """cis pixels of one chromosome (views, global bin ids) + its first bin and bin count."""
         lo, hi = self.chrom_bins(chrom)
@@ -151,6 +157,107 @@ class PixelTable:
         return cls(names, sizes, resol, off, np.concatenate(b1), np.concatenate(b2), np.concatenate(cn), weights)
 
 
+class CoolTable:
+    """cooler's tables read LAZILY from the .cool file / .mcool resolution group (h5py): what replaces
+    `cooler.Cooler(cool)` + `matrix(balance=norm)` (stripenn.py:80, 118) when cooler is absent, at real file sizes.
+
+    Only the small tables are read at once (chromosome names / lengths, `indexes/chrom_offset`, `indexes/bin1_offset`,
+    the balancing columns of `bins`).  The pixel columns stay in the file: `rows_slice` is cooler's own index look-up
+    (`bin1_offset`, no search over a column), `bin1_id` / `bin2_id` / `count` are sliceable views that read what is
+    asked for, and `chrom_pixels` reads ONE chromosome's rows in pieces of `chunk` pixels, keeping the cis pixels only
+    (trans pixels are dropped piece by piece, never accumulated).  `prefetch(chrom)` starts that read on a host thread
+    (h5py releases the GIL inside HDF5's read / inflate), so the next chromosome's columns arrive while the device
+    packs and searches the current one: the host holds at most two chromosomes' cis columns.
+    Same interface as PixelTable as far as PixelSelector and the facade use it."""
+
+    def __init__(self, path, group=None, chunk=1 << 22):
+        import h5py
+        self._h5 = h5py.File(path, 'r')
+        g = self._h5[group] if group else self._h5
+        self._g = g
+        self.chromnames = [c.decode() if isinstance(c, bytes) else str(c) for c in g['chroms/name'][:]]
+        self.chromsizes = np.asarray(g['chroms/length'][:], dtype=np.int64)
+        self.binsize = int(g.attrs['bin-size'])
+        self.chrom_offset = np.asarray(g['indexes/chrom_offset'][:], dtype=np.int64)
+        self.bin1_offset = np.asarray(g['indexes/bin1_offset'][:], dtype=np.int64)
+        self.weights = {k: np.ascontiguousarray(g['bins'][k][:], dtype=np.float64)
+                        for k in g['bins'].keys() if k not in ('chrom', 'start', 'end')}
+        self.bin1_id, self.bin2_id, self.count = g['pixels/bin1_id'], g['pixels/bin2_id'], g['pixels/count']
+        self.chunk = int(chunk)
+        self.max_read = 0            # largest single read of a pixel column, in pixels (tests)
+        self._ahead = {}             # chrom -> (thread, result box)
+        self._nonneg = None
+        if len(self.bin1_offset) != int(self.chrom_offset[-1]) + 1:
+            raise ValueError('indexes/bin1_offset must have one entry per bin plus one')
+
+    close = lambda self: self._h5.close()                                                  # noqa: E731
+    chrom_index = PixelTable.chrom_index
+    chrom_bins = PixelTable.chrom_bins
+    weight = PixelTable.weight
+
+    def rows_slice(self, g0, g1):
+        n = len(self.bin1_offset) - 1
+        return int(self.bin1_offset[min(max(int(g0), 0), n)]), int(self.bin1_offset[min(max(int(g1), 0), n)])
+
+    def count_nonnegative(self):
+        """no negative count anywhere (decides whether a zero row sum means an empty row): one pass over pixels/count
+        in pieces, cached."""
+        if self._nonneg is None:
+            ok, n = True, self.count.shape[0]
+            for a in range(0, n, self.chunk):
+                if np.asarray(self.count[a:min(a + self.chunk, n)]).min(initial=0) < 0:
+                    ok = False
+                    break
+            self._nonneg = ok
+        return self._nonneg
+
+    def _read_cis(self, chrom):
+        lo, hi = self.chrom_bins(chrom)
+        a, b = self.rows_slice(lo, hi)
+        p1, p2, pc = [], [], []
+        for x in range(a, b, self.chunk):
+            y = min(x + self.chunk, b)
+            self.max_read = max(self.max_read, y - x)
+            b2 = np.asarray(self.bin2_id[x:y])
+            keep = b2 < hi                                   # cis pixels of this piece (pixels are sorted by bin1 only)
+            if keep.all():
+                p1.append(np.asarray(self.bin1_id[x:y])); p2.append(b2); pc.append(np.asarray(self.count[x:y]))
+            else:
+                p1.append(np.asarray(self.bin1_id[x:y])[keep]); p2.append(b2[keep]); pc.append(np.asarray(self.count[x:y])[keep])
+        cat = lambda parts, dt: np.ascontiguousarray(np.concatenate(parts)) if parts else np.zeros(0, dt)   # noqa: E731
+        return (np.asarray(cat(p1, np.int64), dtype=np.int64), np.asarray(cat(p2, np.int64), dtype=np.int64),
+                _counts(cat(pc, np.int32)), lo, hi - lo)
+
+    def prefetch(self, chrom):
+        """Start reading the chromosome's cis pixels on a host thread (at most one read ahead is kept)."""
+        import threading
+        chrom = str(chrom)
+        if chrom in self._ahead or chrom not in self.chromnames:
+            return
+        for k in list(self._ahead):                          # an unused older read-ahead is dropped
+            self._ahead.pop(k)[0].join()
+        box = {}
+
+        def work():
+            try:
+                box['r'] = self._read_cis(chrom)
+            except BaseException as e:      # noqa: BLE001 -- re-raised by chrom_pixels on the caller's thread
+                box['e'] = e
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        self._ahead[chrom] = (th, box)
+
+    def chrom_pixels(self, chrom):
+        chrom = str(chrom)
+        if chrom in self._ahead:
+            th, box = self._ahead.pop(chrom)
+            th.join()
+            if 'e' in box:
+                raise box['e']
+            return box['r']
+        return self._read_cis(chrom)
+
+
 def pixel_values(count, weight, bin1, bin2):
     """cooler's balanced value of each stored pixel: count * (b[bin1] * b[bin2]) (`arr * np.outer(bias1, bias2)`),
     b being the multiplicative bias (PixelTable.weight); raw counts when weight is None."""
@@ -171,7 +278,8 @@ class PixelSelector:
         self.resol = table.binsize
         self.nfetch = 0
         self._nonneg = None          # no negative count / weight anywhere: row sums are zero iff all pixels are
-        self._pos = None
+        self._cheap = None
+        self._wpos = None
 
     def _extent(self, region):
         region = str(region)
@@ -191,6 +299,10 @@ class PixelSelector:
         b1, b2, cn, lo, n = self.table.chrom_pixels(chrom)
         return dict(bin1=b1, bin2=b2, count=cn, weight=self.w, lo=lo, nrows=n)
 
+    def prefetch(self, chrom):
+        """Hint: `chrom_pixels(chrom)` comes next (a lazily read table starts the read on a host thread)."""
+        self.table.prefetch(chrom)
+
     def fetch(self, region, region2=None):
         self.nfetch += 1
         n1, r0, r1 = self._extent(region)
@@ -205,32 +317,26 @@ class PixelSelector:
         if self._nonneg is None:
             t = self.table
             with np.errstate(invalid='ignore'):
-                self._nonneg = bool((len(t.count) == 0 or t.count.min() >= 0) and
-                                    (self.w is None or not np.any(self.w < 0)))
+                self._nonneg = bool(t.count_nonnegative() and (self.w is None or not np.any(self.w < 0)))
         return self._nonneg
 
-    def _positive(self):
-        """value > 0 for every stored pixel (NaN from a masked bin compares False): one byte per pixel, formed once
-        in 16 M-pixel pieces so that no whole-table float array ever exists on the host."""
-        if self._pos is None:
-            t = self.table
-            n = len(t.count)
-            pos = np.empty(n, dtype=bool)
-            w = self.w
+    def _positive(self, a, b):
+        """value > 0 for the stored pixels [a, b) (NaN from a masked bin compares False), formed for the slice a
+        query needs: no whole-table array ever exists on the host (a lazily read .cool table has none to offer)."""
+        t = self.table
+        w = self.w
+        cnt = np.asarray(t.count[a:b])
+        if w is None:
+            return cnt > 0
+        if self._cheap is None:
             # (count * w1) * w2 > 0  <=>  count > 0 and w1 > 0 and w2 > 0, unless the product underflows to 0:
             # impossible while every positive weight is >= 1e-100 (counts are >= 1); otherwise form the products
-            cheap = w is None or not np.any((w > 0) & (w < 1e-100))
-            wpos = None if w is None else (w > 0)                    # NaN (masked bin) -> False
-            for a in range(0, n, 1 << 24):
-                b = min(a + (1 << 24), n)
-                if w is None:
-                    pos[a:b] = t.count[a:b] > 0
-                elif cheap:
-                    pos[a:b] = (t.count[a:b] > 0) & wpos[t.bin1_id[a:b]] & wpos[t.bin2_id[a:b]]
-                else:
-                    pos[a:b] = pixel_values(t.count[a:b], w, t.bin1_id[a:b], t.bin2_id[a:b]) > 0
-            self._pos = pos
-        return self._pos
+            self._cheap = not np.any((w > 0) & (w < 1e-100))
+            self._wpos = w > 0                                       # NaN (masked bin) -> False
+        b1, b2 = np.asarray(t.bin1_id[a:b]), np.asarray(t.bin2_id[a:b])
+        if self._cheap:
+            return (cnt > 0) & self._wpos[b1] & self._wpos[b2]
+        return pixel_values(cnt, w, b1, b2) > 0
 
     def row_nonzero(self, region, region2=None):
         """Which rows of `fetch(region, region2)` have a non-zero sum after NaN -> 0 (what nulldist's pools
@@ -246,16 +352,15 @@ class PixelSelector:
         lo, _ = t.chrom_bins(n1)
         R0, R1, C0, C1 = r0 + lo, r1 + lo, c0 + lo, c1 + lo
         hit = np.zeros(r1 - r0, dtype=bool)
-        pos = self._positive()
         a, b = t.rows_slice(R0, R1)                 # stored pixels: bin1 in the rows, bin2 in the columns
-        b2 = t.bin2_id[a:b]
-        ok = pos[a:b] & (b2 < C1)
+        b2 = np.asarray(t.bin2_id[a:b])
+        ok = self._positive(a, b) & (b2 < C1)
         if C0 > R0:                                  # (bin2 >= bin1 >= R0 covers the lower bound otherwise)
             ok &= b2 >= C0
-        hit[t.bin1_id[a:b][ok] - R0] = True
+        hit[np.asarray(t.bin1_id[a:b])[ok] - R0] = True
         a, b = t.rows_slice(C0, min(C1, R1))        # mirror images: bin2 in the rows, bin1 (<= bin2 < R1) in the columns
-        b2 = t.bin2_id[a:b]
-        ok = pos[a:b] & (b2 >= R0) & (b2 < R1)
+        b2 = np.asarray(t.bin2_id[a:b])
+        ok = self._positive(a, b) & (b2 >= R0) & (b2 < R1)
         hit[b2[ok] - R0] = True
         return hit
 
@@ -279,10 +384,10 @@ class PixelSelector:
         # stored pixels (bin1 in rows, bin2 in cols), then their mirror images (bin2 in rows, bin1 in cols)
         for (A0, A1, B0, B1, mirror) in ((R0, R1, C0, C1, False), (C0, C1, R0, R1, True)):
             a, b = t.rows_slice(A0, A1)
-            b1 = t.bin1_id[a:b]; b2 = t.bin2_id[a:b]
+            b1 = np.asarray(t.bin1_id[a:b]); b2 = np.asarray(t.bin2_id[a:b])
             keep = (b2 >= B0) & (b2 < B1)
             b1, b2 = b1[keep], b2[keep]
-            v = pixel_values(t.count[a:b][keep], self.w, b1, b2)
+            v = pixel_values(np.asarray(t.count[a:b])[keep], self.w, b1, b2)
             if mirror:
                 out[b2 - R0, b1 - C0] = v
             else:
