@@ -839,6 +839,8 @@ struct stp_ctx {
     size_t pool_bytes = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t io = nullptr;              // band packing and the quantile's order-statistic select: PCIe uploads of the pixel
+                                           // table and streaming kernels that must not queue behind the searches in flight
     hipStream_t aux = nullptr;             // frame compaction / medpixel and the per-stripe score kernels: small kernels
                                            // with a host round trip each, which must not queue behind (and thereby
                                            // drain) the searches in flight on `stream`
@@ -1028,6 +1030,9 @@ int stp_ctx_create(int device_ordinal, stp_ctx** out)
         (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
         if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, phi) != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return STP_E_HIP; }
     }
+    if (hipStreamCreateWithFlags(&ctx->io, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->aux); (void)hipStreamDestroy(ctx->stream); delete ctx; return STP_E_HIP;
+    }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
     *out = ctx;
@@ -1048,6 +1053,7 @@ void stp_ctx_destroy(stp_ctx* ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    if (ctx->io) { (void)hipStreamSynchronize(ctx->io); (void)hipStreamDestroy(ctx->io); }
     delete ctx;
 }
 
@@ -1274,34 +1280,34 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
         (void)hipFree(d); delete b;
         return set_err(ctx, STP_E_NOMEM, "hipMalloc(band nearest-pixel table) failed");
     }
-    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)near, 0x7FFFFFFF, (size_t)nrows * 2, ctx->stream);
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)near, 0x7FFFFFFF, (size_t)nrows * 2, ctx->io);
     if (e == hipSuccess && nch) e = b1.alloc(ctx, (size_t)nch * sizeof(int64_t));
     if (e == hipSuccess && nch) e = b2.alloc(ctx, (size_t)nch * sizeof(int64_t));
     if (e == hipSuccess && nch) e = bc.alloc(ctx, (size_t)nch * csz);
     if (e == hipSuccess && weight) e = bw.alloc(ctx, (size_t)nrows * sizeof(double));
     if (e == hipSuccess && weight)
-        e = hipMemcpyAsync(bw.p, weight + lo, (size_t)nrows * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(bw.p, weight + lo, (size_t)nrows * sizeof(double), hipMemcpyHostToDevice, ctx->io);
     if (e == hipSuccess && weight) {
-        prof_scope ps(ctx, "band_init", (double)bytes);
-        hipLaunchKernelGGL(k_band_init, dim3(256 * 16), dim3(256), 0, ctx->stream, (const double*)bw.p, nrows, b->W, hw, d);
+        prof_scope ps(ctx, "band_init", (double)bytes, ctx->io);
+        hipLaunchKernelGGL(k_band_init, dim3(256 * 16), dim3(256), 0, ctx->io, (const double*)bw.p, nrows, b->W, hw, d);
         e = hipGetLastError();
     } else if (e == hipSuccess) {
-        e = hipMemsetAsync(d, 0, bytes, ctx->stream);
+        e = hipMemsetAsync(d, 0, bytes, ctx->io);
     }
     for (int64_t p0 = 0; e == hipSuccess && p0 < npix; p0 += CH) {
         const int64_t n = npix - p0 < CH ? npix - p0 : CH;
-        e = hipMemcpyAsync(b1.p, bin1 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(b2.p, bin2 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(bc.p, count + (size_t)p0 * csz, (size_t)n * csz, hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(b1.p, bin1 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->io);
+        if (e == hipSuccess) e = hipMemcpyAsync(b2.p, bin2 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->io);
+        if (e == hipSuccess) e = hipMemcpyAsync(bc.p, count + (size_t)p0 * csz, (size_t)n * csz, hipMemcpyHostToDevice, ctx->io);
         if (e != hipSuccess) break;
         {
-            prof_scope ps(ctx, "band_pack", (double)n * 36.0);    // 20 B of table read + two 8 B cells written
+            prof_scope ps(ctx, "band_pack", (double)n * 36.0, ctx->io);    // 20 B of table read + two 8 B cells written
             const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 64);
             if (count_type == STP_COUNT_F64)
-                hipLaunchKernelGGL(k_band_pack<double>, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)b1.p, (const int64_t*)b2.p,
+                hipLaunchKernelGGL(k_band_pack<double>, dim3(grid), dim3(256), 0, ctx->io, (const int64_t*)b1.p, (const int64_t*)b2.p,
                                    (const double*)bc.p, n, weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d, near);
             else
-                hipLaunchKernelGGL(k_band_pack<int32_t>, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)b1.p, (const int64_t*)b2.p,
+                hipLaunchKernelGGL(k_band_pack<int32_t>, dim3(grid), dim3(256), 0, ctx->io, (const int64_t*)b1.p, (const int64_t*)b2.p,
                                    (const int32_t*)bc.p, n, weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d, near);
         }
         e = hipGetLastError();
@@ -1311,13 +1317,13 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
             double* vals = nullptr;
             e = hipMalloc((void**)&vals, (size_t)n * 2 * sizeof(double));
             if (e == hipSuccess) {
-                prof_scope ps(ctx, "select_pixels", 36.0 * n);
+                prof_scope ps(ctx, "select_pixels", 36.0 * n, ctx->io);
                 if (count_type == STP_COUNT_F64)
-                    hipLaunchKernelGGL(k_sel_pixel_values<double>, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)b1.p,
+                    hipLaunchKernelGGL(k_sel_pixel_values<double>, dim3(sel_grid(n)), dim3(256), 0, ctx->io, (const int64_t*)b1.p,
                                        (const int64_t*)b2.p, (const double*)bc.p, (long long)n, weight ? (const double*)bw.p : nullptr,
                                        (long long)nrows, vals, (long long)lo);
                 else
-                    hipLaunchKernelGGL(k_sel_pixel_values<int32_t>, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)b1.p,
+                    hipLaunchKernelGGL(k_sel_pixel_values<int32_t>, dim3(sel_grid(n)), dim3(256), 0, ctx->io, (const int64_t*)b1.p,
                                        (const int64_t*)b2.p, (const int32_t*)bc.p, (long long)n, weight ? (const double*)bw.p : nullptr,
                                        (long long)nrows, vals, (long long)lo);
                 e = hipGetLastError();
@@ -1325,9 +1331,9 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
                 sel->npos = -1;
             }
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the staging buffers are reused
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->io);      // the staging buffers are reused
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->io);
     if (e != hipSuccess) {
         (void)hipFree(d); (void)hipFree(near); delete b;
         return set_err(ctx, e == hipErrorOutOfMemory ? STP_E_NOMEM : STP_E_HIP, std::string("band pack: ") + hipGetErrorString(e));
@@ -1778,13 +1784,13 @@ int stp_diag_sums(stp_ctx* ctx, const stp_band* band, double* part_sum, int64_t*
     HIPCHK(bs.alloc(ctx, n * sizeof(double)));
     HIPCHK(bc.alloc(ctx, n * sizeof(long long)));
     {
-        prof_scope ps(ctx, "diag_sums", 8.0 * 400.0 * (double)band->nrows);
-        hipLaunchKernelGGL(k_diag_sums, dim3(n400), dim3(448), 0, ctx->stream, bref(band), (double*)bs.p, (long long*)bc.p);
+        prof_scope ps(ctx, "diag_sums", 8.0 * 400.0 * (double)band->nrows, ctx->aux);
+        hipLaunchKernelGGL(k_diag_sums, dim3(n400), dim3(448), 0, ctx->aux, bref(band), (double*)bs.p, (long long*)bc.p);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(part_sum, bs.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(part_cnt, bc.p, n * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpyAsync(part_sum, bs.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipMemcpyAsync(part_cnt, bc.p, n * sizeof(long long), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipStreamSynchronize(ctx->aux));
     return STP_OK;
 }
 
@@ -1810,29 +1816,29 @@ int stp_null_windows(stp_ctx* ctx, const stp_band* band, const double* unit_matr
     if (unit_matrix) {
         const size_t mb = (size_t)samples[0].nrow * samples[0].ncol * sizeof(double);
         HIPCHK(bD.alloc(ctx, mb));
-        HIPCHK(hipMemcpyAsync(bD.p, unit_matrix, mb, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(bD.p, unit_matrix, mb, hipMemcpyHostToDevice, ctx->aux));
     }
     HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_null_sample)));
     HIPCHK(bO.alloc(ctx, 4 * tn * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(bS.p, samples, (size_t)n * sizeof(stp_null_sample), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(bS.p, samples, (size_t)n * sizeof(stp_null_sample), hipMemcpyHostToDevice, ctx->aux));
     double* o = (double*)bO.p;
     {
-        prof_scope ps(ctx, "null_windows", 8.0 * (3.0 * bs) * (800.0 + bs) * n);
+        prof_scope ps(ctx, "null_windows", 8.0 * (3.0 * bs) * (800.0 + bs) * n, ctx->aux);
         if (bs * bs <= 128)
-            hipLaunchKernelGGL(k_null_windows<false>, dim3(n), dim3(256), 0, ctx->stream, bref(band),
+            hipLaunchKernelGGL(k_null_windows<false>, dim3(n), dim3(256), 0, ctx->aux, bref(band),
                                (const double*)(unit_matrix ? bD.p : nullptr), (const stp_null_sample*)bS.p, n, bs, o, o + tn,
                                o + 2 * tn, o + 3 * tn);
         else
-            hipLaunchKernelGGL(k_null_windows<true>, dim3(n), dim3(256), 0, ctx->stream, bref(band),
+            hipLaunchKernelGGL(k_null_windows<true>, dim3(n), dim3(256), 0, ctx->aux, bref(band),
                                (const double*)(unit_matrix ? bD.p : nullptr), (const stp_null_sample*)bS.p, n, bs, o, o + tn,
                                o + 2 * tn, o + 3 * tn);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(lu, o, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ru, o + tn, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ld, o + 2 * tn, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(rd, o + 3 * tn, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpyAsync(lu, o, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipMemcpyAsync(ru, o + tn, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipMemcpyAsync(ld, o + 2 * tn, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipMemcpyAsync(rd, o + 3 * tn, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
+    HIPCHK(hipStreamSynchronize(ctx->aux));
     return STP_OK;
 }
 
@@ -1848,7 +1854,7 @@ int stp_background_upload(stp_ctx* ctx, const double* lu, const double* ru, cons
     bg->ncol = ncol;
     const double* src[4] = {lu, ru, ld, rd};
     for (int t = 0; t < 4; t++) {
-        hipError_t e = hipMemcpyAsync(bg->d + t * tn, src[t], tn * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = hipMemcpyAsync(bg->d + t * tn, src[t], tn * sizeof(double), hipMemcpyHostToDevice, ctx->aux);
         if (e != hipSuccess) { (void)hipFree(bg->d); delete bg; return set_err(ctx, STP_E_HIP, "background upload failed"); }
     }
     if (ncol > STP_BG_MAXCOL) { (void)hipFree(bg->d); delete bg; return set_err(ctx, STP_E_UNSUPPORTED, "background tables wider than 2048 columns"); }
@@ -1858,12 +1864,12 @@ int stp_background_upload(stp_ctx* ctx, const double* lu, const double* ru, cons
         return set_err(ctx, STP_E_NOMEM, "hipMalloc(sorted background)");
     }
     {
-        prof_scope ps(ctx, "bg_sort", 16.0 * 4 * tn);
-        hipLaunchKernelGGL(k_bg_sort, dim3(4 * STP_NDIAG), dim3(512), 0, ctx->stream, (const double*)bg->d, ncol, bg->sorted,
+        prof_scope ps(ctx, "bg_sort", 16.0 * 4 * tn, ctx->aux);
+        hipLaunchKernelGGL(k_bg_sort, dim3(4 * STP_NDIAG), dim3(512), 0, ctx->aux, (const double*)bg->d, ncol, bg->sorted,
                            bg->nvalid);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->aux));
     *out = bg;
     return STP_OK;
 }
@@ -2072,8 +2078,8 @@ int stp_select_append(stp_ctx* ctx, stp_select* s, const double* values_host, in
     HIPCHK(hipSetDevice(ctx->device));
     double* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, (size_t)n * sizeof(double)));
-    hipError_t e = hipMemcpyAsync(d, values_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipError_t e = hipMemcpyAsync(d, values_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->io);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->io);
     if (e != hipSuccess) { (void)hipFree(d); return set_err(ctx, STP_E_HIP, "select append: upload failed"); }
     s->chunks.push_back(std::make_pair(d, (long long)n));
     s->npos = -1;
@@ -2103,28 +2109,28 @@ int stp_select_append_pixels_ex(stp_ctx* ctx, stp_select* s, const int64_t* bin1
     HIPCHK(dc.alloc(ctx, (size_t)nch * csz));
     if (weight) {
         HIPCHK(dw.alloc(ctx, (size_t)nbins_total * sizeof(double)));
-        HIPCHK(hipMemcpyAsync(dw.p, weight, (size_t)nbins_total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(dw.p, weight, (size_t)nbins_total * sizeof(double), hipMemcpyHostToDevice, ctx->io));
     }
     for (int64_t p0 = 0; p0 < npix; p0 += CH) {
         const int64_t n = npix - p0 < CH ? npix - p0 : CH;
         double* out = nullptr;
         HIPCHK(hipMalloc((void**)&out, (size_t)n * 2 * sizeof(double)));
-        hipError_t e = hipMemcpyAsync(d1.p, bin1 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d2.p, bin2 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(dc.p, count + (size_t)p0 * csz, (size_t)n * csz, hipMemcpyHostToDevice, ctx->stream);
+        hipError_t e = hipMemcpyAsync(d1.p, bin1 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->io);
+        if (e == hipSuccess) e = hipMemcpyAsync(d2.p, bin2 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->io);
+        if (e == hipSuccess) e = hipMemcpyAsync(dc.p, count + (size_t)p0 * csz, (size_t)n * csz, hipMemcpyHostToDevice, ctx->io);
         if (e == hipSuccess) {
-            prof_scope ps(ctx, "select_pixels", 36.0 * n);
+            prof_scope ps(ctx, "select_pixels", 36.0 * n, ctx->io);
             if (count_type == STP_COUNT_F64)
-                hipLaunchKernelGGL(k_sel_pixel_values<double>, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)d1.p,
+                hipLaunchKernelGGL(k_sel_pixel_values<double>, dim3(sel_grid(n)), dim3(256), 0, ctx->io, (const int64_t*)d1.p,
                                    (const int64_t*)d2.p, (const double*)dc.p, (long long)n, weight ? (const double*)dw.p : nullptr,
                                    (long long)nbins_total, out, 0ll);
             else
-                hipLaunchKernelGGL(k_sel_pixel_values<int32_t>, dim3(sel_grid(n)), dim3(256), 0, ctx->stream, (const int64_t*)d1.p,
+                hipLaunchKernelGGL(k_sel_pixel_values<int32_t>, dim3(sel_grid(n)), dim3(256), 0, ctx->io, (const int64_t*)d1.p,
                                    (const int64_t*)d2.p, (const int32_t*)dc.p, (long long)n, weight ? (const double*)dw.p : nullptr,
                                    (long long)nbins_total, out, 0ll);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // the staging buffers are reused
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->io);      // the staging buffers are reused
         if (e != hipSuccess) { (void)hipFree(out); return set_err(ctx, STP_E_HIP, std::string("select append pixels: ") + hipGetErrorString(e)); }
         s->chunks.push_back(std::make_pair(out, (long long)(2 * n)));
         s->npos = -1;
@@ -2145,16 +2151,16 @@ int stp_select_count(stp_ctx* ctx, stp_select* s, int64_t* n_positive)
     if (!ctx || !s || !n_positive) return STP_E_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     if (s->npos < 0) {
-        HIPCHK(hipMemsetAsync(s->state, 0, sizeof(stp_sel_state), ctx->stream));
+        HIPCHK(hipMemsetAsync(s->state, 0, sizeof(stp_sel_state), ctx->io));
         for (auto& c : s->chunks) {
-            prof_scope ps(ctx, "select_count", 8.0 * c.second);
-            hipLaunchKernelGGL(k_sel_count, dim3(sel_grid(c.second)), dim3(256), 0, ctx->stream, (const double*)c.first, c.second,
+            prof_scope ps(ctx, "select_count", 8.0 * c.second, ctx->io);
+            hipLaunchKernelGGL(k_sel_count, dim3(sel_grid(c.second)), dim3(256), 0, ctx->io, (const double*)c.first, c.second,
                                &s->state->k);
         }
         HIPCHK(hipGetLastError());
         unsigned long long k = 0;
-        HIPCHK(hipMemcpyAsync(&k, &s->state->k, sizeof(k), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpyAsync(&k, &s->state->k, sizeof(k), hipMemcpyDeviceToHost, ctx->io));
+        HIPCHK(hipStreamSynchronize(ctx->io));
         s->npos = (long long)k;
     }
     *n_positive = s->npos;
@@ -2172,20 +2178,20 @@ int stp_select_ranks(stp_ctx* ctx, stp_select* s, const int64_t* ranks, int32_t 
     for (int r = 0; r < nranks; r++) {
         if (ranks[r] < 0 || ranks[r] >= np) return set_err(ctx, STP_E_ARG, "rank outside [0, n_positive)");
         unsigned long long init[2] = {0ull, (unsigned long long)ranks[r]};
-        HIPCHK(hipMemsetAsync(s->state, 0, sizeof(stp_sel_state), ctx->stream));
-        HIPCHK(hipMemcpyAsync(s->state, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(s->state, 0, sizeof(stp_sel_state), ctx->io));
+        HIPCHK(hipMemcpyAsync(s->state, init, sizeof(init), hipMemcpyHostToDevice, ctx->io));
         for (int pass = 0; pass < 5; pass++) {
             for (auto& c : s->chunks) {
-                prof_scope ps(ctx, "select_hist", 8.0 * c.second);
-                hipLaunchKernelGGL(k_sel_hist, dim3(sel_grid(c.second)), dim3(256), 0, ctx->stream, (const double*)c.first,
+                prof_scope ps(ctx, "select_hist", 8.0 * c.second, ctx->io);
+                hipLaunchKernelGGL(k_sel_hist, dim3(sel_grid(c.second)), dim3(256), 0, ctx->io, (const double*)c.first,
                                    c.second, shifts[pass], widths[pass], pass, s->state);
             }
-            hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(1024), 0, ctx->stream, s->state, shifts[pass]);
+            hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(1024), 0, ctx->io, s->state, shifts[pass]);
         }
         HIPCHK(hipGetLastError());
         unsigned long long key = 0;
-        HIPCHK(hipMemcpyAsync(&key, &s->state->prefix, sizeof(key), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemcpyAsync(&key, &s->state->prefix, sizeof(key), hipMemcpyDeviceToHost, ctx->io));
+        HIPCHK(hipStreamSynchronize(ctx->io));
         memcpy(&out[r], &key, sizeof(double));
     }
     return STP_OK;

@@ -102,6 +102,10 @@ class getStripe:
         self._frames = {}
         self._search_cache = {}
         self.timing = {}
+        # eager_search (set by the single-process `compute` driver): the StripeSearch of a chromosome is enqueued as soon
+        # as its maxpixel quantiles are known, so the device searches chromosome i while the host uploads and packs the
+        # pixel columns of chromosome i + 1 (the packer and the select run on a stream of their own)
+        self.eager_search = False
 
     # ------------------------------------------------------------------ band management
     def _nbins(self, chrom):
@@ -213,6 +217,11 @@ class getStripe:
                 res[CHROM] = quantile_linear(lambda ranks: self.backend.select_ranks(sel, ranks), n, quantile)
             finally:
                 self.backend.select_close(sel)
+            if self.eager_search and str(CHROM) in self._bands and hasattr(self.backend, 'stripe_search_begin'):
+                mine = [str(c) for c in self.chromnames]
+                if str(CHROM) in mine:
+                    k = mine.index(str(CHROM))
+                    self._search_begin(self.chromnames[k], k, res[CHROM])
         return res
 
     def getQuantile_slow(self, coolinfo, ChrList, quantile):
@@ -510,10 +519,8 @@ class getStripe:
     @staticmethod
     def _groups(df):
         """[(chromosome, row indices in table order)], chromosomes in order of first appearance."""
-        names = [str(c) for c in df['chr'].tolist()]
-        codes = {}
-        code = np.fromiter((codes.setdefault(c, len(codes)) for c in names), dtype=np.int64, count=len(names))
-        return [(c, np.nonzero(code == k)[0]) for c, k in codes.items()]
+        code, uniq = pd.factorize(np.asarray(df['chr'].astype(str)), sort=False)      # codes in order of first appearance
+        return [(str(c), np.nonzero(code == k)[0]) for k, c in enumerate(uniq)]
 
     # ------------------------------------------------------------------ observed mean (score only)
     def getMean(self, df, mask='0'):
@@ -819,9 +826,7 @@ class getStripe:
         n = df.shape[0]
         if n == 0:
             return df
-        chrs = np.asarray(df['chr'])
-        codes = {}
-        code = np.array([codes.setdefault(c, len(codes)) for c in chrs.tolist()], dtype=np.int64)
+        code = pd.factorize(np.asarray(df['chr']), sort=False)[0].astype(np.int64)
         num = np.asarray(df['num'], dtype=np.int64)
         span = int(num.max() - num.min()) + 3
         key = code * span + (num - num.min())

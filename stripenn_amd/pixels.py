@@ -95,11 +95,16 @@ class PixelTable:
         """cis pixels of one chromosome (views, global bin ids) + its first bin and bin count."""
         lo, hi = self.chrom_bins(chrom)
         a, b = self.rows_slice(lo, hi)
-        b2 = self.bin2_id[a:b]
-        if len(b2) and b2.max() >= hi:                       # drop trans pixels
-            keep = b2 < hi
-            return self.bin1_id[a:b][keep], b2[keep], self.count[a:b][keep], lo, hi - lo
-        return self.bin1_id[a:b], b2, self.count[a:b], lo, hi - lo
+        b1, b2 = self.bin1_id[a:b], self.bin2_id[a:b]
+        # trans pixels?  Pixels are sorted by (bin1, bin2), so the largest bin2 of a row is its LAST pixel: looking at
+        # the row ends (one look-up per bin) answers it without a pass over the whole column
+        if len(b2):
+            ends = np.searchsorted(b1, np.arange(lo + 1, hi + 1), side='left') - 1
+            ends = ends[ends >= 0]
+            if b2[ends].max() >= hi:                         # drop trans pixels
+                keep = b2 < hi
+                return b1[keep], b2[keep], self.count[a:b][keep], lo, hi - lo
+        return b1, b2, self.count[a:b], lo, hi - lo
 
     # ------------------------------------------------------------------ I/O
     def save(self, path, compressed=False):

@@ -148,6 +148,7 @@ def compute(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalu
     resol = Lib.binsize
     obj = getStripe.getStripe(unbalLib, resol, minH, maxW, canny, all_chromnames, chromnames, all_chromsizes, chromsizes,
                               core, bfilter, seed, backend=backend, device=device)
+    obj.eager_search = True      # searches start while the quantile loop is still uploading the next chromosomes
     print('1. Maximum pixel value calculation ...')
     if slow:
         print('1.1 Slowly estimating Maximum pixel values...')
