@@ -6,6 +6,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include <new>
 #include "../../include/stripenn_hip.h"
 #include "stp_phases.h"
@@ -915,7 +916,7 @@ static void pool_release(stp_ctx* ctx, void* p, size_t bytes)
 {
     if (!p) return;
     const size_t r = pool_round(bytes ? bytes : 1);
-    if (ctx->pool_bytes + r > ((size_t)1 << 30)) { (void)hipFree(p); return; }   // keep at most 1 GiB idle
+    if (ctx->pool_bytes + r > ((size_t)4 << 30)) { (void)hipFree(p); return; }   // keep at most 4 GiB idle (of 288)
     ctx->pool_free.push_back(std::make_pair(r, p));
     ctx->pool_bytes += r;
 }
@@ -1242,7 +1243,7 @@ struct dev_buf {                      // per-call device buffer, recycled throug
 };
 
 struct stp_select {
-    std::vector<std::pair<double*, long long>> chunks;   // device buffers
+    std::vector<std::pair<double*, long long>> chunks;   // device buffers (from the context's pool), number of values
     long long npos = -1;                                 // cached count of positive values
     stp_sel_state* state = nullptr;
 };
@@ -1272,6 +1273,9 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
     double* d = nullptr;
     const size_t bytes = (size_t)nrows * b->W * sizeof(double);
     if (hipMalloc((void**)&d, bytes) != hipSuccess) { delete b; return set_err(ctx, STP_E_NOMEM, "hipMalloc(band) failed"); }
+    // (measured and dropped in round 3: two pinned staging sets filled by eight host threads, 40 MB pieces, DMA of piece
+    //  k beside the host copy of piece k + 1 -- 0.34 s for the 5.3 GB of the mm10-size table against 0.26 s for the
+    //  runtime's own pageable path below, which already pipelines its staging)
     const int64_t CH = (int64_t)1 << 23;                 // pixels per staged chunk (160 MB of table columns)
     const int64_t nch = npix < CH ? npix : CH;
     dev_buf b1, b2, bc, bw;
@@ -1315,7 +1319,7 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
             // the same staged columns also feed the quantile's order-statistic select (values as the dense symmetric
             // matrix holds them: off-diagonal pixels twice), so the table crosses PCIe once
             double* vals = nullptr;
-            e = hipMalloc((void**)&vals, (size_t)n * 2 * sizeof(double));
+            e = pool_alloc(ctx, (size_t)n * 2 * sizeof(double), (void**)&vals);
             if (e == hipSuccess) {
                 prof_scope ps(ctx, "select_pixels", 36.0 * n, ctx->io);
                 if (count_type == STP_COUNT_F64)
@@ -2066,7 +2070,7 @@ void stp_select_free(stp_ctx* ctx, stp_select* s)
 {
     if (!s) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    for (auto& c : s->chunks) (void)hipFree(c.first);
+    for (auto& c : s->chunks) { if (ctx) pool_release(ctx, c.first, (size_t)c.second * sizeof(double)); else (void)hipFree(c.first); }
     if (s->state) (void)hipFree(s->state);
     delete s;
 }
@@ -2077,10 +2081,10 @@ int stp_select_append(stp_ctx* ctx, stp_select* s, const double* values_host, in
     if (n == 0) return STP_OK;
     HIPCHK(hipSetDevice(ctx->device));
     double* d = nullptr;
-    HIPCHK(hipMalloc((void**)&d, (size_t)n * sizeof(double)));
+    HIPCHK(pool_alloc(ctx, (size_t)n * sizeof(double), (void**)&d));
     hipError_t e = hipMemcpyAsync(d, values_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->io);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->io);
-    if (e != hipSuccess) { (void)hipFree(d); return set_err(ctx, STP_E_HIP, "select append: upload failed"); }
+    if (e != hipSuccess) { pool_release(ctx, d, (size_t)n * sizeof(double)); return set_err(ctx, STP_E_HIP, "select append: upload failed"); }
     s->chunks.push_back(std::make_pair(d, (long long)n));
     s->npos = -1;
     return STP_OK;
@@ -2114,7 +2118,7 @@ int stp_select_append_pixels_ex(stp_ctx* ctx, stp_select* s, const int64_t* bin1
     for (int64_t p0 = 0; p0 < npix; p0 += CH) {
         const int64_t n = npix - p0 < CH ? npix - p0 : CH;
         double* out = nullptr;
-        HIPCHK(hipMalloc((void**)&out, (size_t)n * 2 * sizeof(double)));
+        HIPCHK(pool_alloc(ctx, (size_t)n * 2 * sizeof(double), (void**)&out));
         hipError_t e = hipMemcpyAsync(d1.p, bin1 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->io);
         if (e == hipSuccess) e = hipMemcpyAsync(d2.p, bin2 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->io);
         if (e == hipSuccess) e = hipMemcpyAsync(dc.p, count + (size_t)p0 * csz, (size_t)n * csz, hipMemcpyHostToDevice, ctx->io);
@@ -2131,7 +2135,7 @@ int stp_select_append_pixels_ex(stp_ctx* ctx, stp_select* s, const int64_t* bin1
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->io);      // the staging buffers are reused
-        if (e != hipSuccess) { (void)hipFree(out); return set_err(ctx, STP_E_HIP, std::string("select append pixels: ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) { pool_release(ctx, out, (size_t)n * 2 * sizeof(double)); return set_err(ctx, STP_E_HIP, std::string("select append pixels: ") + hipGetErrorString(e)); }
         s->chunks.push_back(std::make_pair(out, (long long)(2 * n)));
         s->npos = -1;
     }
@@ -2151,15 +2155,16 @@ int stp_select_count(stp_ctx* ctx, stp_select* s, int64_t* n_positive)
     if (!ctx || !s || !n_positive) return STP_E_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     if (s->npos < 0) {
+        // the first radix pass (top digit of every positive value); its histogram stays on the device for the ranks
         HIPCHK(hipMemsetAsync(s->state, 0, sizeof(stp_sel_state), ctx->io));
         for (auto& c : s->chunks) {
-            prof_scope ps(ctx, "select_count", 8.0 * c.second, ctx->io);
-            hipLaunchKernelGGL(k_sel_count, dim3(sel_grid(c.second)), dim3(256), 0, ctx->io, (const double*)c.first, c.second,
-                               &s->state->k);
+            prof_scope ps(ctx, "select_hist", 8.0 * c.second, ctx->io);
+            hipLaunchKernelGGL(k_sel_hist0, dim3(sel_grid(c.second)), dim3(256), 0, ctx->io, (const double*)c.first, c.second, s->state);
         }
+        hipLaunchKernelGGL(k_sel_count, dim3(1), dim3(1024), 0, ctx->io, s->state);
         HIPCHK(hipGetLastError());
         unsigned long long k = 0;
-        HIPCHK(hipMemcpyAsync(&k, &s->state->k, sizeof(k), hipMemcpyDeviceToHost, ctx->io));
+        HIPCHK(hipMemcpyAsync(&k, &s->state->count, sizeof(k), hipMemcpyDeviceToHost, ctx->io));
         HIPCHK(hipStreamSynchronize(ctx->io));
         s->npos = (long long)k;
     }
@@ -2173,26 +2178,37 @@ int stp_select_ranks(stp_ctx* ctx, stp_select* s, const int64_t* ranks, int32_t 
     int64_t np = 0;
     int rc = stp_select_count(ctx, s, &np);
     if (rc) return rc;
-    static const int shifts[5] = {51, 38, 25, 12, 0};
-    static const int widths[5] = {13, 13, 13, 13, 12};
-    for (int r = 0; r < nranks; r++) {
+    for (int r = 0; r < nranks; r++)
         if (ranks[r] < 0 || ranks[r] >= np) return set_err(ctx, STP_E_ARG, "rank outside [0, n_positive)");
-        unsigned long long init[2] = {0ull, (unsigned long long)ranks[r]};
-        HIPCHK(hipMemsetAsync(s->state, 0, sizeof(stp_sel_state), ctx->io));
-        HIPCHK(hipMemcpyAsync(s->state, init, sizeof(init), hipMemcpyHostToDevice, ctx->io));
-        for (int pass = 0; pass < 5; pass++) {
+    static bool lds_set = false;
+    if (!lds_set) {       // up to 16 histograms of 8 KB in dynamic LDS
+        (void)hipFuncSetAttribute((const void*)k_sel_hist, hipFuncAttributeMaxDynamicSharedMemorySize, STP_SEL_MAXR * STP_SEL_BINS * 4);
+        lds_set = true;
+    }
+    // all ranks of a batch descend together: one sweep over the data per pass, one host round trip per batch
+    for (int r0 = 0; r0 < nranks; r0 += STP_SEL_MAXR) {
+        const int R = nranks - r0 < STP_SEL_MAXR ? nranks - r0 : STP_SEL_MAXR;
+        struct { unsigned long long prefix[STP_SEL_MAXR], k[STP_SEL_MAXR]; int group[STP_SEL_MAXR]; int nranks, ngroups;
+                 unsigned long long gprefix[STP_SEL_MAXR]; } init;
+        memset(&init, 0, sizeof(init));
+        for (int r = 0; r < R; r++) init.k[r] = (unsigned long long)ranks[r0 + r];
+        init.nranks = R; init.ngroups = 1;
+        static_assert(offsetof(stp_sel_state, hist0) == sizeof(init), "select state header layout");
+        HIPCHK(hipMemcpyAsync(s->state, &init, sizeof(init), hipMemcpyHostToDevice, ctx->io));
+        hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(1024), 0, ctx->io, s->state, 0);          // first pass: the kept histogram
+        for (int pass = 1; pass < STP_SEL_PASSES; pass++) {
             for (auto& c : s->chunks) {
                 prof_scope ps(ctx, "select_hist", 8.0 * c.second, ctx->io);
-                hipLaunchKernelGGL(k_sel_hist, dim3(sel_grid(c.second)), dim3(256), 0, ctx->io, (const double*)c.first,
-                                   c.second, shifts[pass], widths[pass], pass, s->state);
+                hipLaunchKernelGGL(k_sel_hist, dim3(sel_grid(c.second)), dim3(512), (size_t)R * STP_SEL_BINS * 4, ctx->io,
+                                   (const double*)c.first, c.second, pass, R, s->state);
             }
-            hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(1024), 0, ctx->io, s->state, shifts[pass]);
+            hipLaunchKernelGGL(k_sel_pick, dim3(1), dim3(1024), 0, ctx->io, s->state, pass);
         }
         HIPCHK(hipGetLastError());
-        unsigned long long key = 0;
-        HIPCHK(hipMemcpyAsync(&key, &s->state->prefix, sizeof(key), hipMemcpyDeviceToHost, ctx->io));
+        unsigned long long keys[STP_SEL_MAXR];
+        HIPCHK(hipMemcpyAsync(keys, s->state->prefix, R * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->io));
         HIPCHK(hipStreamSynchronize(ctx->io));
-        memcpy(&out[r], &key, sizeof(double));
+        memcpy(out + r0, keys, R * sizeof(double));
     }
     return STP_OK;
 }
