@@ -260,3 +260,117 @@ def launch_compute(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores
     args = (cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, slow, bfilter, seed, True)
     mp.spawn(_worker, args=(gpus, port, args), nprocs=gpus, join=True)
     return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Persistent ranks: start-up (Python, torch, the gloo group, HIP context, workspaces: ~3 s per process) is paid ONCE
+# for any number of `compute` runs -- one GPU finishes the mm10-size genome in under a second, so a fresh set of
+# processes per run (launch_compute) can never pay off; a pool that stays alive across the samples of a study can.
+def _pool_worker(rank, world, port, jobs, results, backend_factory):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('gloo', rank=rank, world_size=world)   # host objects only
+    backend = None
+    try:
+        if backend_factory is not None:
+            backend = backend_factory(rank)
+        else:
+            from .backend import HipBackend
+            backend = HipBackend(rank)                             # raises without the HIP library / device: no fallback
+        results.put(('ready', rank, os.getpid()))
+        while True:
+            job = jobs.get()
+            if job is None:
+                break
+            t0 = time.time()
+            try:
+                sharded_compute(rank, world, *job, prepared=True, backend_factory=lambda r: backend)
+                results.put(('done', rank, os.getpid(), time.time() - t0))
+            except BaseException as e:      # noqa: BLE001 -- reported to the parent, which closes the pool
+                results.put(('error', rank, os.getpid(), repr(e)))
+                break
+    finally:
+        if backend is not None and hasattr(backend, 'close'):
+            backend.close()
+        try:
+            dist.destroy_process_group()
+        except Exception:      # noqa: BLE001
+            pass
+
+
+class ComputePool:
+    """`gpus` rank processes that stay alive: `pool.compute(...)` (the arguments of stripenn.compute) may be called any
+    number of times; every call is one sharded_compute over the same ranks, HIP contexts and workspaces."""
+
+    def __init__(self, gpus, backend_factory=None, start_timeout=300):
+        import socket
+        import torch.multiprocessing as mp
+        ctx = mp.get_context('spawn')
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        self.world = int(gpus)
+        self.results = ctx.Queue()
+        self.jobs = [ctx.Queue() for _ in range(self.world)]
+        self.procs = [ctx.Process(target=_pool_worker, args=(r, self.world, port, self.jobs[r], self.results, backend_factory),
+                                  daemon=True) for r in range(self.world)]
+        for p in self.procs:
+            p.start()
+        self.pids = {}
+        for msg in self._collect('ready', start_timeout):
+            self.pids[msg[1]] = msg[2]
+
+    def _collect(self, kind, timeout):
+        import queue
+        got, deadline = [], time.time() + timeout
+        while len(got) < self.world:
+            try:
+                msg = self.results.get(timeout=0.5)
+            except queue.Empty:
+                dead = [r for r, p in enumerate(self.procs) if not p.is_alive()]
+                if dead or time.time() > deadline:
+                    self.close(kill=True)
+                    raise RuntimeError('compute pool: rank(s) %s ended or timed out while waiting for %r' % (dead, kind))
+                continue
+            if msg[0] == 'error':
+                self.close(kill=True)
+                raise RuntimeError('compute pool: rank %d failed: %s' % (msg[1], msg[3]))
+            if msg[0] == kind:
+                got.append(msg)
+        return got
+
+    def compute(self, cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, slow, bfilter, seed, force=True,
+                timeout=3600):
+        """One `compute` run on the pool's ranks; returns the slowest rank's seconds.  The output directory is prepared
+        here, in the parent (the reference's overwrite prompt needs a terminal)."""
+        from .stripenn import addlog, makeOutDir
+        if out[-1] != '/':
+            out += '/'
+        makeOutDir(out, force)
+        addlog(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, bfilter)
+        job = (cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, slow, bfilter, seed, True)
+        for q in self.jobs:
+            q.put(job)
+        msgs = self._collect('done', timeout)
+        assert {m[1]: m[2] for m in msgs} == self.pids, 'a rank was replaced between runs'
+        return max(m[3] for m in msgs)
+
+    def close(self, kill=False):
+        for q in self.jobs:
+            try:
+                q.put(None)
+            except Exception:      # noqa: BLE001
+                pass
+        for p in self.procs:
+            p.join(0.1 if kill else 30)
+            if p.is_alive():
+                p.terminate()
+        self.procs = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -91,3 +91,35 @@ def test_sharded_world1_equals_unsharded_driver(tmp_path):
                          backend=OracleBackend())
     for name in ('result_unfiltered.tsv', 'result_filtered.tsv'):
         assert open(os.path.join(out, 'w1_c2', name)).read() == open(os.path.join(out, 'plain', name)).read()
+
+
+def test_persistent_pool_serves_several_runs(tmp_path):
+    """shard.ComputePool: two rank processes (gloo, oracle backend) stay alive across three `compute` runs with
+    different parameters; every run writes the TSVs of the corresponding single-process run, byte for byte, and the
+    same two processes served them all (start-up paid once)."""
+    import contextlib, io
+    import shard_worker
+    from oracle_backend import OracleBackend
+    from stripenn_amd import stripenn
+    a = shard_worker.ARGS
+    runs = [dict(maxpixel='0.95,0.98', numcores=2, canny=2.0), dict(maxpixel='0.97', numcores=2, canny=2.5),
+            dict(maxpixel='0.95,0.98', numcores=1, canny=2.0)]
+    with shard.ComputePool(2, backend_factory=shard_worker._factory) as pool:
+        pids = dict(pool.pids)
+        assert len(set(pids.values())) == 2 and os.getpid() not in pids.values()
+        for k, r in enumerate(runs):
+            out = os.path.join(str(tmp_path), 'pool%d' % k)
+            secs = pool.compute(shard_worker.COOL, out, a['norm'], a['chrom'], r['canny'], a['minL'], a['maxW'], r['maxpixel'],
+                                r['numcores'], a['pvalue'], a['mask'], a['slow'], a['bfilter'], a['seed'])
+            assert secs > 0 and pool.pids == pids
+    for k, r in enumerate(runs):
+        ref = os.path.join(str(tmp_path), 'ref%d' % k)
+        with contextlib.redirect_stdout(io.StringIO()):
+            stripenn.compute(shard_worker.COOL, ref, a['norm'], a['chrom'], r['canny'], a['minL'], a['maxW'], r['maxpixel'],
+                             r['numcores'], a['pvalue'], a['mask'], a['slow'], a['bfilter'], a['seed'], force=True,
+                             backend=OracleBackend())
+        for name in ('result_unfiltered.tsv', 'result_filtered.tsv'):
+            got = open(os.path.join(str(tmp_path), 'pool%d' % k, name)).read()
+            assert got == open(os.path.join(ref, name)).read(), (k, name)
+            assert name != 'result_unfiltered.tsv' or len(got.splitlines()) > 5
+        assert 'gpus: 2' in open(os.path.join(str(tmp_path), 'pool%d' % k, 'stripenn.log')).read()
