@@ -67,8 +67,10 @@ int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_
  *   with |bin2 - bin1| > halfwidth are skipped; value = count * (bias[bin1] * bias[bin2]) (cooler's dense
  *   read multiplies the count block by np.outer(bias1, bias2); NaN gives NaN), or (double)count when
  *   weight == NULL; `weight` is the MULTIPLICATIVE bias: the caller passes 1 / w for cooler's divisive
- *   columns (KR, VC, SQRT_VC); each pixel is written at (i, j) and mirrored at (j, i); cells without a
- *   pixel stay 0.  weight has nbins_total entries (global bin ids).  No dense intermediate exists. */
+ *   columns (KR, VC, SQRT_VC); each pixel is written at (i, j) and mirrored at (j, i); a cell without a
+ *   stored pixel is the count 0 times the same product -- 0, or NaN along the whole row and column of a bin
+ *   whose bias is NaN (cooler multiplies the DENSE block, so an unbalanced bin is NaN everywhere) -- and 0
+ *   outside the chromosome.  weight has nbins_total entries (global bin ids).  No dense intermediate exists. */
 int stp_band_pack(stp_ctx* ctx, const int64_t* bin1_id, const int64_t* bin2_id, const int32_t* count, int64_t npix,
                   const double* weight, int64_t nbins_total, int64_t bin_lo, int64_t nrows, int32_t halfwidth,
                   stp_band** out);
@@ -255,7 +257,8 @@ int stp_window_plane(stp_ctx* ctx, const stp_band* band, int64_t row0, int32_t n
  * The host streams the chromosome in row strips (`stp_select_append`; non-positive and NaN entries
  * are ignored, exactly like `mat[mat > 0]`), so the dense chromosome (12 GB for chr1 at 5 kb) never
  * exists; `stp_select_ranks` returns the exact order statistics a[rank] (0-based, ascending) by
- * radix select; numpy's interpolation between them is applied by the caller (stripenn_amd/getStripe.py). */
+ * radix select -- all ranks of a call descend together: one sweep over the values per 11-bit digit, one host round
+ * trip per 16 ranks; numpy's interpolation between them is applied by the caller (stripenn_amd/getStripe.py). */
 int stp_select_create(stp_ctx* ctx, stp_select** out);
 int stp_select_append(stp_ctx* ctx, stp_select* sel, const double* values_host, int64_t n);
 /* Append the balanced values of cooler pixels (bin1_id <= bin2_id, count; value = count * (bias[bin1] * bias[bin2]), or
