@@ -168,15 +168,28 @@ __device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double
 }
 
 // k_canny_pipe: magnitudes in 2 x 2 blocks (ct_sobel_blk2) and, in the same walk, collection of the pixels whose
-// magnitude reaches the low threshold (the only ones that can get a class) into ONE workgroup-wide LDS queue: per
-// block position a ballot, one LDS atomic of the wave's first lane for the base, a 16-bit entry per candidate.
-// Order in the queue is irrelevant: the classes are OR-ed into the bit rows.
-__device__ __forceinline__ void canny_p3_collect(int tid, stp_tile T, stp_p3walk W, const double* sS, float* sM, uint16_t* sQ,
+// magnitude reaches the low threshold (the only ones that can get a class) into ONE workgroup-wide LDS queue.  Per
+// round a lane holds four magnitudes; which of them may be candidates at all is decided per block ROW and block COLUMN
+// (two range tests each against the tile's candidate window, computed once per workgroup: tile interior and image
+// interior), the four ballots share ONE LDS atomic of the wave's first lane, and a candidate's slot is the running
+// popcount of the ballots before it.  Order in the queue is irrelevant: the classes are OR-ed into the bit rows.
+struct stp_cwin { int y0, ny, x0, nx; };          // candidate window in magnitude-tile coordinates
+__device__ __forceinline__ stp_cwin canny_cand_window(stp_tile T)
+{
+    stp_cwin C;                                   // pixel (Y, X) of the magnitude tile = image (ty0 + Y - 1, tx0 + X - 1)
+    C.y0 = max(1, 2 - T.ty0); C.ny = min(CT_Y, T.S - 1 - T.ty0) - C.y0 + 1;
+    C.x0 = max(1, 2 - T.tx0); C.nx = min(CT_X, T.S - 1 - T.tx0) - C.x0 + 1;
+    if (C.ny < 0) C.ny = 0;
+    if (C.nx < 0) C.nx = 0;
+    return C;
+}
+__device__ __forceinline__ void canny_p3_collect(int tid, stp_cwin C, stp_p3walk W, const double* sS, float* sM, uint16_t* sQ,
                                                  int* sQn)
 {
     const int lane = tid & 63;
     int r = W.r0, c = W.c0;
     const int rounds = (W.n + 255) >> 8;                    // workgroup-uniform
+    const float thr = (float)(0.1 - 1e-6);
     for (int k = 0; k < rounds; k++) {
         const bool act = tid + 256 * k < W.n;
         float m[4] = {0.f, 0.f, 0.f, 0.f};
@@ -187,25 +200,24 @@ __device__ __forceinline__ void canny_p3_collect(int tid, stp_tile T, stp_p3walk
             float* o = sM + W.moff + y * (CT_X + 2) + x;
             o[0] = m[0]; o[1] = m[1]; o[CT_X + 2] = m[2]; o[CT_X + 3] = m[3];
         }
-        // tile coordinates of the block's first pixel; a block shifted back at an odd extent repeats one row / column
-        // of its neighbour: those pixels are not collected twice
-        const int ty = y + W.my_lo - 1, tx = x + W.mx_lo - 1;
-        const bool dupr = y != 2 * r, dupc = x != 2 * c;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int py = ty + (q >> 1), px = tx + (q & 1);
-            const int Y = T.ty0 + py, X = T.tx0 + px;
-            bool cand = act && (unsigned)py < (unsigned)CT_Y && (unsigned)px < (unsigned)CT_X && Y >= 1 && X >= 1 && Y < T.S - 1 &&
-                        X < T.S - 1 && m[q] >= (float)(0.1 - 1e-6);
-            if ((q >> 1) == 0 && dupr) cand = false;
-            if ((q & 1) == 0 && dupc) cand = false;
-            const stp_u64 bal = __ballot(cand);
-            if (bal) {                                       // wave-uniform
-                int base = 0;
-                if (lane == 0) base = atomicAdd(sQn, __popcll(bal));
-                base = __shfl(base, 0);
-                if (cand) sQ[base + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)((py << 6) | px);
-            }
+        // a block shifted back at an odd extent repeats one row / column of its neighbour: not collected twice
+        const int Y = y + W.my_lo, X = x + W.mx_lo;
+        const bool r0 = act && (unsigned)(Y - C.y0) < (unsigned)C.ny && y == 2 * r, r1 = act && (unsigned)(Y + 1 - C.y0) < (unsigned)C.ny;
+        const bool c0 = (unsigned)(X - C.x0) < (unsigned)C.nx && x == 2 * c, c1 = (unsigned)(X + 1 - C.x0) < (unsigned)C.nx;
+        const bool q0 = r0 && c0 && m[0] >= thr, q1 = r0 && c1 && m[1] >= thr, q2 = r1 && c0 && m[2] >= thr, q3 = r1 && c1 && m[3] >= thr;
+        const stp_u64 b0 = __ballot(q0), b1 = __ballot(q1), b2 = __ballot(q2), b3 = __ballot(q3);
+        const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+        if (n0 + n1 + n2 + n3) {                             // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(sQn, n0 + n1 + n2 + n3);
+            base = __shfl(base, 0);
+            const stp_u64 lt = (1ull << lane) - 1ull;
+            const int e = (Y - 1) * 64 + (X - 1);             // (row << 6 | column) of the block's first pixel in tile coordinates
+                                                              // (a halo row / column gives -1: only the in-tile neighbours are stored)
+            if (q0) sQ[base + __popcll(b0 & lt)] = (uint16_t)e;
+            if (q1) sQ[base + n0 + __popcll(b1 & lt)] = (uint16_t)(e + 1);
+            if (q2) sQ[base + n0 + n1 + __popcll(b2 & lt)] = (uint16_t)(e + 64);
+            if (q3) sQ[base + n0 + n1 + n2 + __popcll(b3 & lt)] = (uint16_t)(e + 65);
         }
         c += W.dc; r += W.dr;
         if (c >= W.nbw) { c -= W.nbw; r++; }
@@ -354,6 +366,7 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
         for (int k = 0; k < NR2; k++) it2[k] = ct_p2_decode<R>(G, tid + 256 * k);
         W3 = ct_p3_walk(G, tid, 256);
     }
+    const stp_cwin CW = canny_cand_window(T);
     // the min/max cell this lane looks at (the same for all images): the cells overlapping the tile's input
     // window [ty0-R-2, ty0+CT_Y+R+2) x [tx0-R-2, tx0+CT_X+R+2) clipped to the image, at most 8 x 7
     int cell_off = -1;
@@ -419,8 +432,13 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
             canny_p3_ring(tid, nt, T, sS);
             __syncthreads();
         }
-        canny_p3_collect(tid, T, W3, sS, sM, sQ, sQn);
+        canny_p3_collect(tid, CW, W3, sS, sM, sQ, sQn);
         __syncthreads();
+#if defined(STP_ABLATE_CANNY_P123)    /* timing-only build: everything but the NMS over the queue */
+        if (tid == 64) *sQn = 0;
+        __syncthreads();
+        continue;
+#endif
         canny_nms_queue(tid, T, sS, sM, sQ, *sQn, sBits);
         __syncthreads();     // sM / sQ alias sV: the NMS must be done before the next vertical pass writes it
         if (tid < CT_Y) {    // the tile's class words of this image; the thread clears the two words it has read (the

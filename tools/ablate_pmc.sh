@@ -1,8 +1,9 @@
-# VALU instruction counts of k_canny_pipe per phase: timing-only ablation builds + one PMC pass each.
+# VALU instruction counts of k_canny_pipe per phase (vertical pass; + horizontal pass; + magnitudes and candidate
+# collection; whole kernel): timing-only ablation builds + one PMC pass each.
 # Run on the GPU box from the repo root: bash tools/ablate_pmc.sh
 make -s -C stripenn_amd/csrc ablate
 R=$(pwd); cd /tmp; export TMPDIR=/tmp
-for l in libstp_ablate_p1 libstp_ablate_p12 libstripenn_hip; do
+for l in libstp_ablate_p1 libstp_ablate_p12 libstp_ablate_p123 libstripenn_hip; do
   PYTHONPATH=$R STP_LIB=$R/stripenn_amd/$l.so timeout 200 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU -d $R/gpurun_out/abl_$l -o pmc -- python3 $R/tools/probe_chain.py > $R/gpurun_out/abl_$l.log 2>&1
   python3 - <<PY
 import csv,glob
