@@ -52,6 +52,7 @@ class PixelTable:
             raise ValueError('chrom_offset must have one entry per chromosome plus one')
         if not (len(self.bin1_id) == len(self.bin2_id) == len(self.count)):
             raise ValueError('pixel columns differ in length')
+        self._trans = {}              # chromosome -> does its row range hold trans pixels (asked once per chromosome)
         if len(self.bin1_id) and (np.any(np.diff(self.bin1_id) < 0) or np.any(self.bin1_id > self.bin2_id)):
             raise ValueError('pixels must be sorted by bin1_id and upper-triangular (bin1_id <= bin2_id)')
 
@@ -99,9 +100,12 @@ class PixelTable:
         # trans pixels?  Pixels are sorted by (bin1, bin2), so the largest bin2 of a row is its LAST pixel: looking at
         # the row ends (one look-up per bin) answers it without a pass over the whole column
         if len(b2):
-            ends = np.searchsorted(b1, np.arange(lo + 1, hi + 1), side='left') - 1
-            ends = ends[ends >= 0]
-            if b2[ends].max() >= hi:                         # drop trans pixels
+            trans = self._trans.get(chrom)
+            if trans is None:
+                ends = np.searchsorted(b1, np.arange(lo + 1, hi + 1), side='left') - 1
+                ends = ends[ends >= 0]
+                trans = self._trans[chrom] = bool(b2[ends].max() >= hi)
+            if trans:                                        # drop trans pixels
                 keep = b2 < hi
                 return b1[keep], b2[keep], self.count[a:b][keep], lo, hi - lo
         return b1, b2, self.count[a:b], lo, hi - lo

@@ -6,7 +6,7 @@ import pandas as pd
 
 from . import getStripe
 from .io import open_matrix
-from .stripenn import resolve_norm
+from .stripenn import resolve_norm, write_tsv
 
 
 def _halfwidth_for(table, resol):
@@ -59,5 +59,5 @@ def getScore(cool, coordinates, norm, numcores, seed, out, mask='0', device=0, b
     table.insert(table.shape[1], 'O_Sum_added', SUM, True)
     table.insert(table.shape[1], 'O/E_Mean_added', MEANOE, True)
     table.insert(table.shape[1], 'O/E_Total_added', TOTALOE, True)
-    table.to_csv(out, sep='\t', header=True, index=False)
+    write_tsv(table, out)
     return table

@@ -114,7 +114,7 @@ def sharded_compute(rank, world, cool, out, norm, chrom, canny, minL, maxW, maxp
     prepared=True: the output directory and log were written by the launcher (launch_compute)."""
     from . import getStripe
     from .io import open_matrix
-    from .stripenn import (RESULT_COLUMNS, addlog, finish_tables, makeOutDir, resolve_norm, select_chromosomes)
+    from .stripenn import (RESULT_COLUMNS, addlog, finish_tables, makeOutDir, resolve_norm, select_chromosomes, write_tsv)
     np.seterr(divide='ignore', invalid='ignore')
     comm = _Comm(rank, world)
     if out[-1] != '/':
@@ -217,8 +217,8 @@ def sharded_compute(rank, world, cool, out, norm, chrom, canny, minL, maxW, maxp
         merged = merged.drop(columns=['_stripiness'])
         result_table, res_filter = finish_tables(merged, stri, pvalue)
         if write:
-            result_table.to_csv(out + 'result_unfiltered.tsv', sep='\t', header=True, index=False)
-            res_filter.to_csv(out + 'result_filtered.tsv', sep='\t', header=True, index=False)
+            write_tsv(result_table, out + 'result_unfiltered.tsv')
+            write_tsv(res_filter, out + 'result_filtered.tsv')
             with open(out + 'stripenn.log', 'a') as f:
                 f.write('gpus: %d\n' % world)
                 for g in sorted(gathered, key=lambda g: g[0]):
