@@ -129,18 +129,29 @@ def write_tsv(df, path):
             elif a.dtype.kind in 'iu':
                 cols.append(list(map(str, a.tolist())))
             elif a.dtype.kind == 'O':
-                out = []
-                for x in a.tolist():
-                    if x is None or (isinstance(x, float) and x != x):
-                        out.append('')
-                    elif isinstance(x, (str, int, float)) and not isinstance(x, bool):
-                        t = repr(float(x)) if isinstance(x, float) else str(x)
-                        if isinstance(x, str) and any(ch in x for ch in '\t"\n\r'):
-                            raise ValueError('field needs quoting')
-                        out.append(t)
-                    else:
-                        raise ValueError('unsupported cell type %r' % type(x))
-                cols.append(out)
+                kind = pd.api.types.infer_dtype(a, skipna=False)
+                if kind == 'string':
+                    out = a.tolist()
+                    blob = '\x00'.join(out)
+                    if '\t' in blob or '"' in blob or '\n' in blob or '\r' in blob:
+                        raise ValueError('field needs quoting')
+                    cols.append(out)
+                elif kind == 'integer':
+                    cols.append(list(map(str, a.tolist())))
+                elif kind == 'floating':
+                    cols.append(['' if x != x else repr(x) for x in a.astype(np.float64).tolist()])
+                else:                                     # mixed cells: one by one
+                    out = []
+                    for x in a.tolist():
+                        if x is None or (isinstance(x, float) and x != x):
+                            out.append('')
+                        elif isinstance(x, (str, int, float)) and not isinstance(x, bool):
+                            if isinstance(x, str) and any(ch in x for ch in '\t"\n\r'):
+                                raise ValueError('field needs quoting')
+                            out.append(repr(float(x)) if isinstance(x, float) else str(x))
+                        else:
+                            raise ValueError('unsupported cell type %r' % type(x))
+                    cols.append(out)
             else:
                 raise ValueError('unsupported column dtype %s' % a.dtype)
         if any(any(ch in str(c) for ch in '\t"\n\r') for c in df.columns):
