@@ -342,48 +342,77 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
     for (int b = 0; b < 3; b++)
         for (int c = tid; c < CW; c += nt) keepc[b][c] = 0;
     __syncthreads();
+    // (whether o / e is NaN needs no division when e is finite and positive: then it is NaN exactly when o is)
+    auto oe_alive = [&](int b, int r, int c) -> bool {
+        const bool masked = (c >= s.mcol0[b] && c <= s.mcol1[b]) || (r >= s.mrow0 && r <= s.mrow1);
+        if (masked) return false;
+        const double o = band_at(B, s.row0 + r, s.col0[b] + c);
+        int idx = (s.ex0[b] + c) - (s.ey0 + r);
+        if (idx < 0) idx = -idx;
+        if (idx >= 400) idx = 399;
+        const double e = ex[idx] + .00000001;
+        if (e > 0.0 && e < INFINITY) return o == o;
+        const double v = o / e;
+        return v == v;
+    };
     for (int b = 0; b < 3; b++) {
         const int w = s.col1[b] - s.col0[b];
         for (int i = tid; i < w * h; i += nt) {
             const int r = i / w, c = i - r * w;
-            const double v = oe(b, r, c);
-            if (v == v) keepc[b][c] = 1;
+            if (oe_alive(b, r, c)) keepc[b][c] = 1;
         }
     }
     __syncthreads();
-    // the rows dead columns delete (:713-733), compaction of kept columns / rows
-    if (tid == 0) {
-        int anydel = 0, status = 0;
-        for (int b = 0; b < 3; b++) {
+    // the rows dead columns delete (:713-733), compaction of kept columns / rows.  Ordered compactions by ballot:
+    // wave b takes column block b (a chunk's writes never pass its reads: in place), then wave 0 the rows.
+    __shared__ int s_anydel, s_status;
+    if (tid == 0) { s_anydel = 0; s_status = 0; s_tot = 0.0; }
+    __syncthreads();
+    {
+        const int lane = tid & 63, wv = tid >> 6, nwv = nt >> 6;
+        for (int b = wv; b < 3; b += nwv) {
             const int w = s.col1[b] - s.col0[b];
-            int n = 0;
-            for (int c = 0; c < w; c++) {
-                if (keepc[b][c]) keepc[b][n++] = (int16_t)c;
-                else {
+            int base = 0;
+            for (int c0 = 0; c0 < w; c0 += 64) {
+                const int c = c0 + lane;
+                const bool in = c < w;
+                const bool alive = in && keepc[b][c] != 0;
+                const unsigned long long bal = __ballot(alive);
+                __builtin_amdgcn_wave_barrier();
+                if (alive) keepc[b][base + __popcll(bal & ((1ull << lane) - 1ull))] = (int16_t)c;
+                if (in && !alive) {
                     int rd = s.mirror ? (h - 1 - c) : c;
-                    if (rd < -h || rd >= h) status = 1;          // np.delete: index out of bounds (IndexError)
+                    if (rd < -h || rd >= h) s_status = 1;           // np.delete: index out of bounds (IndexError)
                     if (rd < 0) rd += h;
-                    if (rd >= 0 && rd < h) { rowdel[rd] = 1; anydel = 1; }
+                    if (rd >= 0 && rd < h) { rowdel[rd] = 1; s_anydel = 1; }
                 }
+                base += __popcll(bal);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            nkc[b] = n;
+            if (lane == 0) nkc[b] = base;
         }
-        int n = h;
-        if (anydel) {
-            n = 0;
-            for (int r = 0; r < h; r++) if (!rowdel[r]) keepr[n++] = (int16_t)r;
-        }
-        nkr = anydel ? n : -h;       // negative: identity map, filled in parallel below
-        s_tot = 0.0;
-        out_status[blockIdx.x] = status;
     }
     __syncthreads();
-    if (nkr < 0) {
+    if (tid == 0) out_status[blockIdx.x] = s_status;
+    if (s_anydel) {
+        if (tid < 64) {
+            const int lane = tid;
+            int base = 0;
+            for (int r0 = 0; r0 < h; r0 += 64) {
+                const int r = r0 + lane;
+                const bool keep = r < h && !rowdel[r];
+                const unsigned long long bal = __ballot(keep);
+                if (keep) keepr[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int16_t)r;
+                base += __popcll(bal);
+            }
+            if (lane == 0) nkr = base;
+        }
+    } else {
         for (int r = tid; r < h; r += nt) keepr[r] = (int16_t)r;
-        __syncthreads();
         if (tid == 0) nkr = h;
-        __syncthreads();
     }
+    __syncthreads();
     const int hk = nkr;
     // row means after nantozero (:739-745), numpy pairwise order over the kept columns
     for (int it = tid; it < 3 * hk; it += nt) {
@@ -428,21 +457,52 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
     __syncthreads();
     const int nd = hk - 2 > 0 ? hk - 2 : 0;
     double med = 0.0;
-    // np.nanmedian(centerm): compact the non-NaN values into rowm[1] (left means are no longer needed)
-    __shared__ int s_nm;
-    if (tid == 0) {
-        int n = 0;
-        for (int q = 0; q < hk; q++) { double v = rowm[0][q]; if (v == v) rowm[1][n++] = v; }
-        s_nm = n;
+    // np.nanmedian(centerm): the non-NaN values into rowm[1] (left means are no longer needed; the median does not
+    // depend on their order)
+    __shared__ int s_nm, s_ndk;
+    __shared__ double s_acc[8];
+    if (tid == 0) s_nm = 0;
+    __syncthreads();
+    for (int q = tid; q < hk; q += nt) {
+        const double v = rowm[0][q];
+        if (v == v) rowm[1][atomicAdd(&s_nm, 1)] = v;
+    }
+    // diff = [x for x in diff if x >= 0 or x < 0] in order, into rowm[2] (right means are no longer needed)
+    if (tid < 64) {
+        const int lane = tid;
+        int base = 0;
+        for (int q0 = 0; q0 < nd; q0 += 64) {
+            const int q = q0 + lane;
+            const double v = q < nd ? diff[q] : NAN;
+            const bool keep = v == v;
+            const unsigned long long bal = __ballot(keep);
+            if (keep) rowm[2][base + __popcll(bal & ((1ull << lane) - 1ull))] = v;
+            base += __popcll(bal);
+        }
+        if (lane == 0) s_ndk = base;
     }
     __syncthreads();
     if (s_nm > 0) med = block_median(rowm[1], s_nm, s_res);
     else med = NAN;
+    // np.mean(diff): numpy's pairwise sum; up to 128 values it is eight stride-8 partial sums combined in a fixed tree plus
+    // the tail in order -- the partial sums by eight lanes, everything else (and longer lists) by one thread
+    const int n = s_ndk;
+    const double* dk = rowm[2];
+    if (n >= 8 && n <= 128 && tid < 8) {
+        double r = dk[tid];
+        for (int i = 8; i < n - (n % 8); i += 8) r += dk[i + tid];
+        s_acc[tid] = r;
+    }
+    __syncthreads();
     if (tid == 0) {
-        // diff = [x for x in diff if x >= 0 or x < 0]; np.mean(diff)
-        int n = 0;
-        for (int q = 0; q < nd; q++) { double v = diff[q]; if (v == v) diff[n++] = v; }
-        double avg = stp_pw<true>([&](int64_t k) { return diff[k]; }, 0, n, s_stk) / (double)n;
+        double sum;
+        if (n >= 8 && n <= 128) {
+            sum = ((s_acc[0] + s_acc[1]) + (s_acc[2] + s_acc[3])) + ((s_acc[4] + s_acc[5]) + (s_acc[6] + s_acc[7]));
+            for (int i = n - (n % 8); i < n; i++) sum += dk[i];
+        } else {
+            sum = stp_pw<true>([&](int64_t k) { return dk[k]; }, 0, n, s_stk);
+        }
+        const double avg = sum / (double)n;
         out_g[blockIdx.x] = med * avg;
         const int nc = nkc[0];
         // every centre column deleted (a mask covering the whole stripe width): np.sum over the empty block is 0.0,
