@@ -210,6 +210,7 @@ def main():
 
             def _probe():
                 try:
+                    torch.cuda.set_device(local_rank)          # (the current device is a per-thread setting)
                     g = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=120))
                     t = torch.ones(1, device=torch.device('cuda', local_rank))
                     dist.all_reduce(t, group=g)
