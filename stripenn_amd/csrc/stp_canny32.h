@@ -1,0 +1,376 @@
+// stp_canny32.h -- phases of k_canny_f32: the Canny class map decided from an all-f32 evaluation of the chain
+// (Gaussian passes, bleed-over scaling, Sobel, magnitude) wherever the decision is provably the reference's, and
+// from the reference's own f64 arithmetic, pixel by pixel, wherever it is not.
+//
+// Why: k_canny_pipe reproduces every intermediate of skimage's canny (_canny.py:53-280 over scipy's f64-accumulating
+// correlate1d) bit for bit -- ~95 FP64 instructions per pixel at 4 cycles per wave-instruction, the kernel's limiter.
+// What the caller consumes, though, is only the CLASS of a pixel (none / low / high); the intermediates need to
+// be exact only where a comparison is close.  f32 instructions issue at twice the FP64 rate and need no widening.
+//
+// Error budget (u = 2^-24, the relative error bound of one f32 rounding; g = largest grey value the tile's input
+// window holds, taken from k_gray's per-cell maxima; grey values and Gaussian weights are >= 0, so every partial
+// sum is bounded by the final one and the bounds below are relative to sums of non-negative terms):
+//   vertical pass     Va = w'[R] x0, then Va = fma(RN(x[-k] + x[k]), w'[R-k], Va), w' = RN32(w): a term passes through
+//                     at most 10 roundings (weight, pair sum or centre product, <= 8 accumulations):
+//                     |Va - Tv| <= 10.01 u Tv  (Tv the real-number sum); the reference's V = RN32(f64 sum) has
+//                     |V - Tv| <= 1.001 u Tv, so |Va - V| <= 11.01 u Tv.
+//   horizontal pass   |Ha - Th(Va)| <= 10.01 u Th(Va), Th(|Va - V|) <= 11.01 u T2, |H - Th(V)| <= 1.001 u T2
+//                     (T2 the real 2-D sum):  |Ha - H| <= 22.1 u T2, and T2 <= g * bleed (the same weights summed
+//                     over the in-image taps), so |Ha - H| / bleed <= 22.1 u g at borders too.
+//   scaling           Sa = RN32(Ha * rb), rb = RN32(1 / (bleed + eps)): two more roundings:
+//                     E_S = |Sa - S| <= 24.2 u g   (the reference's f64 quotient adds 2^-53).           used: 25 u g
+//   Sobel             d = RN32(s1 - s2): 2 E_S + u g;  t = RN32(dm + dp): 4 E_S + 4 u g;  j = RN32(2 d0 + t):
+//                     E_G = 8 E_S + 10 u g + u |j| ... <= 212 u g  (|j| <= 4 g; the reference's f64 Sobel adds ~2^-50)
+//   magnitude         |hypot(ia, ja) - hypot(i, j)| <= sqrt(2) E_G; f32 evaluation: fma + product (2 u of the sum of
+//                     squares -> u of the root) + v_sqrt_f32 (1 ulp <= 2 u): 3.1 u m, m <= 5.66 g:
+//                     E_M <= (300 + 17.6) u g                                                             used: 320 u g
+//   interpolation     w = num / den: |wa - w| <= 2 E_G / (den - E_G) + 4 u (v_rcp_f32 1 ulp + product);
+//                     l = c2 w + c1 (1 - w): |la - l| <= E_M + |wa - w| (|c2a - c1a| + 2 E_M) + 3 u max(c) (17 u g)
+//   A comparison l <= m is taken from the f32 values when |la - ma| > 2 E_M + 17 u g + |wa - w| (...); m >= 0.1 / 0.2
+//   when |ma - thr| > E_M; the sector (signs of i, j and |i| vs |j|) when |ia|, |ja| > E_G and ||ia| - |ja|| > 2 E_G.
+//   Everything else ("uncertain": ~1e-4 of the pixels of noisy data, every edge pixel of a synthetic step) is
+//   resolved by c32_res_*: the reference's arithmetic on the 5 x 5 smoothed values around the pixel, recomputed
+//   from the grey image in the exact order (stp_gauss_exact), glibc's hypot, the literal tests.
+#pragma once
+
+#define C32_SP (CT_X + 6)          /* pitch (floats) of the f32 smoothed tile: even (aligned pairs), 6 mod 64 banks per row */
+#define C32_EG_U 213.0f            /* bounds in units of u * g (rounded up; the products below add an absolute slack) */
+#define C32_EM_U 321.0f
+#define C32_T0_U 662.0f            /* 2 E_M + 17 */
+
+struct stp_w32 { float w[CT_RMAX + 1]; };     // RN32 of the Gaussian weights, w[R] the centre: a kernel argument (SGPRs)
+
+struct stp_c32tol { float Eg, Em, T0, thr; };
+STP_HD stp_c32tol c32_tol(float gmax)
+{
+    stp_c32tol t;
+    const float su = gmax * 5.9604644775390625e-08f;      // g * 2^-24 (exact scaling)
+    t.Eg = fmaf(C32_EG_U, su, 1e-8f);
+    t.Em = fmaf(C32_EM_U, su, 2e-8f);                      // the slack also covers 0.1f / 0.2f vs the f64 thresholds (< 3e-9)
+    t.T0 = fmaf(C32_T0_U, su, 4e-8f);
+    t.thr = 0.1f - t.Em - 1e-8f;                           // below it the exact magnitude is < 0.1: no class
+    return t;
+}
+
+// ---- vertical pass, one item (column xx of the tile window, VRUN output rows from yy0): as canny_p1_item ----
+template <int R, bool YIN>
+STP_HD void c32_p1_item(stp_tile T, int xx, int yy0, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
+{
+    constexpr int VRUN = (R <= 8) ? CT_VRUN : CT_VRUN / 2;
+    const int x = T.tx0 - R - 2 + xx;
+    float raw[VRUN + 2 * R];
+    const float* col = gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + x;    // guard bytes around the grey images: see canny_p1_item
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < VRUN + 2 * R; k++) raw[k] = col[k * STP_PITCH];
+    if (!YIN) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int k = 0; k < VRUN + 2 * R; k++) {
+            const int y = T.ty0 - R - 2 + yy0 + k;
+            if ((unsigned)y >= (unsigned)T.S) raw[k] = 0.0f;
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int q = 0; q < VRUN; q++) {
+        float a = raw[q + R] * W.w[R];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int k = R; k >= 1; k--) a = fmaf(raw[q + R - k] + raw[q + R + k], W.w[R - k], a);
+        if (!YIN) {
+            const int y = T.ty0 - 2 + yy0 + q;
+            if (!(y >= 0 && y < T.S)) a = 0.0f;
+        }
+        sVT[xx * CT_VP + yy0 + q] = a;
+    }
+}
+template <int R, bool YIN>
+STP_HD void c32_p1_blk(int tid, int nt, stp_tile T, stp_cgeo G, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
+{
+    for (int i = tid;; i += nt) {
+        const int it = ct_p1_decode<R>(G, i);
+        if (it < 0) break;
+        if (it >> 16) canny_p1_zero<R>(it & 255, (it >> 8) & 255, sVT);
+        else c32_p1_item<R, YIN>(T, it & 255, (it >> 8) & 255, W, gimg, sVT);
+    }
+}
+
+// reciprocal bleed-over tables (f32): sRB[yy] for an interior column of tile row yy, sRBB[yy * 2R + q] for the border
+// columns (q as in canny_p1c).  From the f64 factors the exact path uses; geometry only.
+template <int R>
+STP_HD void c32_rb_tables(int tid, int nt, stp_tile T, const double* w, const double* sB, float* sRB, float* sRBB, bool xin)
+{
+    const int VH = CT_Y + 4;
+    for (int i = tid; i < VH; i += nt) sRB[i] = (float)(1.0 / (sB[VH + i] + DBL_EPSILON));
+    if (xin) return;
+    for (int i = tid; i < VH * 2 * R; i += nt) {
+        const int yy = i / (2 * R), q = i - yy * (2 * R);
+        const int x = q < R ? q : T.S - R + (q - R);
+        float v = 0.0f;
+        if (x >= 0 && x < T.S) v = (float)(1.0 / (stp_bleed_h(sB[yy], x, T.S, R, w) + DBL_EPSILON));
+        sRBB[i] = v;
+    }
+}
+
+// ---- horizontal pass + scaling, one item (tile row yy, HRUN outputs from column xx0): as canny_p2_item ----
+template <int R, bool XIN>
+STP_HD void c32_p2_item(stp_tile T, int yy, int xx0, const stp_w32& W, const float* sVT, const float* sRB, const float* sRBB,
+                        float* sS)
+{
+    constexpr int HRUN = CT_HRUN_R(R);
+    const int SW = CT_X + 4;
+    float win[HRUN + 2 * R];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < HRUN + 2 * R; k++) win[k] = sVT[(xx0 + k) * CT_VP + yy];
+    const float rbi = sRB[yy];
+    float* srow = sS + yy * C32_SP + xx0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int q = 0; q < HRUN; q++) {
+        const int xx = xx0 + q;
+        if (xx >= SW) break;
+        float a = win[q + R] * W.w[R];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int k = R; k >= 1; k--) a = fmaf(win[q + R - k] + win[q + R + k], W.w[R - k], a);
+        float s;
+        if (XIN) {
+            s = a * rbi;
+        } else {
+            const int x = T.tx0 - 2 + xx;
+            s = 0.0f;
+            if (x >= 0 && x < T.S) {
+                float rb = rbi;
+                if (x < R) rb = sRBB[yy * 2 * R + x];
+                else if (x + R >= T.S) rb = sRBB[yy * 2 * R + R + (x - (T.S - R))];
+                s = a * rb;
+            }
+        }
+        srow[q] = s;
+    }
+}
+template <int R, bool XIN>
+STP_HD void c32_p2_blk(int tid, int nt, stp_tile T, stp_cgeo G, const stp_w32& W, const float* sVT, const float* sRB,
+                       const float* sRBB, float* sS)
+{
+    for (int i = tid;; i += nt) {
+        const int it = ct_p2_decode<R>(G, i);
+        if (it < 0) break;
+        c32_p2_item<R, XIN>(T, it & 255, it >> 8, W, sVT, sRB, sRBB, sS);
+    }
+}
+
+// the one-pixel ring around the image (see canny_p3_ring), f32 tile
+STP_HD void c32_p3_ring(int tid, int nt, stp_tile T, float* sS)
+{
+    const int VH = CT_Y + 4, SW = CT_X + 4;
+    const int y0 = T.ty0 - 2, x0 = T.tx0 - 2;
+    for (int i = tid; i < 2 * SW + 2 * VH; i += nt) {
+        int y, x;
+        if (i < 2 * SW) { y = (i < SW) ? -1 : T.S; x = x0 + (i < SW ? i : i - SW); }
+        else { const int j = i - 2 * SW; x = (j < VH) ? -1 : T.S; y = y0 + (j < VH ? j : j - VH); }
+        const int yy = y - y0, xx = x - x0;
+        if (yy < 0 || yy >= VH || xx < 0 || xx >= SW) continue;
+        const int cy = y < 0 ? 0 : (y > T.S - 1 ? T.S - 1 : y), cx = x < 0 ? 0 : (x > T.S - 1 ? T.S - 1 : x);
+        const int sy = cy - y0, sx = cx - x0;
+        if (sy < 0 || sy >= VH || sx < 0 || sx >= SW) continue;
+        sS[yy * C32_SP + xx] = sS[sy * C32_SP + sx];
+    }
+}
+
+STP_HD float c32_sqrt(float q)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(q);
+#else
+    return sqrtf(q);
+#endif
+}
+STP_HD float c32_rcp(float d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(d);
+#else
+    return 1.0f / d;
+#endif
+}
+// f32 Sobel sums of the pixel at `c` (plain offsets: the ring holds the replicated edge)
+STP_HD void c32_sobel(const float* c, float* is, float* js)
+{
+    const float s00 = c[-C32_SP - 1], s01 = c[-C32_SP], s02 = c[-C32_SP + 1], s10 = c[-1], s12 = c[1], s20 = c[C32_SP - 1],
+                s21 = c[C32_SP], s22 = c[C32_SP + 1];
+    *js = fmaf(s12 - s10, 2.0f, (s02 - s00) + (s22 - s20));
+    *is = fmaf(s21 - s01, 2.0f, (s20 - s00) + (s22 - s02));
+}
+// four magnitudes M(yy..yy+1, xx..xx+1) from the 4 x 4 values at `c` (= S(yy, xx), see ct_sobel_blk2)
+STP_HD void c32_sobel_blk2(const float* c, float* m)
+{
+    float s[4][4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 4; r++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int q = 0; q < 4; q++) s[r][q] = c[r * C32_SP + q];
+    }
+    float H[4][2], V[2][4];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 4; r++) { H[r][0] = s[r][2] - s[r][0]; H[r][1] = s[r][3] - s[r][1]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int q = 0; q < 4; q++) { V[0][q] = s[2][q] - s[0][q]; V[1][q] = s[3][q] - s[1][q]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 2; r++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int q = 0; q < 2; q++) {
+            const float j = fmaf(H[r + 1][q], 2.0f, H[r][q] + H[r + 2][q]);
+            const float i = fmaf(V[r][q + 1], 2.0f, V[r][q] + V[r][q + 2]);
+            m[r * 2 + q] = c32_sqrt(fmaf(i, i, j * j));
+        }
+    }
+}
+// all blocks of the in-image magnitude region (CPU replay; the kernel walks the same blocks in canny32_collect)
+STP_HD void c32_p3_walk(int tid, int nt, stp_p3walk W, const float* sS, float* sM)
+{
+    int r = W.r0, c = W.c0;
+    const int soff = W.my_lo * C32_SP + W.mx_lo;
+    for (int i = tid; i < W.n; i += nt) {
+        const int y = 2 * r < W.nmh - 2 ? 2 * r : W.nmh - 2, x = 2 * c < W.nmw - 2 ? 2 * c : W.nmw - 2;
+        float m[4];
+        c32_sobel_blk2(sS + soff + y * C32_SP + x, m);
+        float* o = sM + W.moff + y * (CT_X + 2) + x;
+        o[0] = m[0]; o[1] = m[1]; o[CT_X + 2] = m[2]; o[CT_X + 3] = m[3];
+        c += W.dc; r += W.dr;
+        if (c >= W.nbw) { c -= W.nbw; r++; }
+    }
+}
+
+// Class of tile pixel (y, x) from the f32 tiles: 0 / 1 / 2, or 3 = not decidable inside the error budget.
+// Decision structure of _canny.py:193-280 as in ct_nms.
+STP_HD int c32_nms(const float* sS, const float* sM, stp_tile T, int y, int x, stp_c32tol E)
+{
+    if (y < 1 || x < 1 || y >= T.S - 1 || x >= T.S - 1) return 0;
+    const int MW = CT_X + 2;
+    const float* mp = sM + (y - (T.ty0 - 1)) * MW + (x - (T.tx0 - 1));
+    const float m0 = mp[0];
+    if (m0 < E.thr) return 0;                                            // exact magnitude < 0.1
+    if (m0 <= 0.1f + E.Em || fabsf(m0 - 0.2f) <= E.Em) return 3;         // a threshold inside the error band
+    float gi, gj;
+    c32_sobel(sS + (y - (T.ty0 - 2)) * C32_SP + (x - (T.tx0 - 2)), &gi, &gj);
+    const float ai = fabsf(gi), aj = fabsf(gj);
+    if (ai <= E.Eg || aj <= E.Eg || fabsf(ai - aj) <= 2.0f * E.Eg) return 3;      // a sign or the octant could differ
+    const bool same = (gi > 0.0f) == (gj > 0.0f), ibig = ai > aj;
+    const float num = ibig ? aj : ai, den = ibig ? ai : aj;
+    // neighbours of the "plus" side: (dy1, dx1) the axis neighbour, (dy2, dx2) the diagonal one
+    const int dy2 = same ? 1 : -1;
+    const int o1 = ibig ? dy2 * MW : 1, o2 = dy2 * MW + 1;
+    const float wq = num * c32_rcp(den), omw = 1.0f - wq;
+    const float c1p = mp[o1], c2p = mp[o2], c1m = mp[-o1], c2m = mp[-o2];
+    const float lp = fmaf(c2p, wq, c1p * omw), lm = fmaf(c2m, wq, c1m * omw);
+    const float dw = fmaf(2.0f * E.Eg, c32_rcp(den - E.Eg) * 1.000001f, 2.4e-7f);     // |wa - w| bound (4 u = 2.4e-7)
+    const float tp = fmaf(dw, fabsf(c2p - c1p) + 2.0f * E.Em, E.T0), tm = fmaf(dw, fabsf(c2m - c1m) + 2.0f * E.Em, E.T0);
+    if (fabsf(lp - m0) <= tp || fabsf(lm - m0) <= tm) return 3;
+    if (!(lp <= m0 && lm <= m0)) return 0;
+    return m0 >= 0.2f ? 2 : 1;
+}
+
+// The reference's order for one output (as stp_gauss_exact) with a compile-time radius: every tap is loaded before the
+// first use, so the 2R+1 loads of a lane are in flight together (the resolver is latency, not throughput).
+// Tap k (0 .. 2R) counts as 0 unless lo <= k <= hi (constant-mode zero padding); masked taps are not dereferenced.
+template <int R>
+STP_HD float c32_gauss_exact(const float* centre, int stride, const double* w, int lo, int hi)
+{
+    float v[2 * R + 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k <= 2 * R; k++) v[k] = (k >= lo && k <= hi) ? centre[(k - R) * stride] : 0.0f;
+    double a = (double)v[R] * w[R];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = R; k >= 1; k--) a += ((double)v[R - k] + (double)v[R + k]) * w[R - k];
+    return (float)a;
+}
+
+// ---- the exact resolver: one pixel (y, x) of the tile, interior of the image ----
+// V patch: 5 rows (y-2 .. y+2, clamped into the image: scipy's 'reflect' by one = edge replication) x (2R + 5) columns
+// x-2-R .. x+2+R of the vertical pass (0 outside the image: constant mode), element l = r * (2R+5) + c.
+template <int R>
+STP_HD float c32_res_V(stp_tile T, int y, int x, int l, const double* w, const float* __restrict__ gimg)
+{
+    constexpr int NC = 2 * R + 5;
+    const int r = l / NC, c = l - r * NC;
+    int yy = y - 2 + r;
+    yy = yy < 0 ? 0 : (yy > T.S - 1 ? T.S - 1 : yy);
+    const int xx = x - 2 - R + c;
+    if (xx < 0 || xx >= T.S) return 0.0f;
+    const int lo = yy - R < 0 ? R - yy : 0, hi = yy + R >= T.S ? R + (T.S - 1 - yy) : 2 * R;
+    return c32_gauss_exact<R>(gimg + yy * STP_PITCH + xx, STP_PITCH, w, lo, hi);
+}
+// S patch: element l = r * 5 + c is the smoothed value at (clamp(y-2+r), clamp(x-2+c)), the reference's operations
+// (canny_p2: f32 horizontal sum in the exact order, f64 quotient by bleed + eps)
+template <int R>
+STP_HD double c32_res_S(stp_tile T, int y, int x, int l, const double* w, const double* sB, const float* Vp)
+{
+    constexpr int NC = 2 * R + 5;
+    const int VH = CT_Y + 4;
+    const int r = l / 5, c = l - r * 5;
+    int yy = y - 2 + r, cx = x - 2 + c;
+    yy = yy < 0 ? 0 : (yy > T.S - 1 ? T.S - 1 : yy);
+    cx = cx < 0 ? 0 : (cx > T.S - 1 ? T.S - 1 : cx);
+    const float f = c32_gauss_exact<R>(Vp + r * NC + (cx - (x - 2 - R)), 1, w, 0, 2 * R);
+    const int yyt = yy - (T.ty0 - 2);
+    const double bl = (cx >= R && cx + R < T.S) ? sB[VH + yyt] : stp_bleed_h(sB[yyt], cx, T.S, R, w);
+    return (double)f / (bl + DBL_EPSILON);       // _canny.py:49
+}
+// magnitude (glibc hypot of the f64 Sobel sums) of pixel l = 3 * (dy + 1) + (dx + 1) of the 3 x 3 block around the
+// centre of the 5 x 5 patch (pitch 5)
+STP_HD double c32_res_mag(const double* P, int l)
+{
+    const int r = l / 3, c = l - 3 * r;
+    double is, js;
+    ct_sobel_off(P + (r + 1) * 5 + (c + 1), -5, 5, -1, 1, &is, &js);
+    return stp_hypot(is, js);
+}
+// class of the centre pixel from the patch and the nine magnitudes: ct_nms's literal branch
+STP_HD int c32_res_class(const double* P, const double* M9)
+{
+    double gi, gj;
+    ct_sobel_off(P + 12, -5, 5, -1, 1, &gi, &gj);
+    const double ai = fabs(gi), aj = fabs(gj);
+    const bool same = (gi >= 0 && gj >= 0) || (gi <= 0 && gj <= 0);
+    const bool opp = (gi <= 0 && gj >= 0) || (gi >= 0 && gj <= 0);
+    int dy1, dx1, dy2, dx2;
+    double num, den;
+    if (opp && ai >= aj) { num = aj; den = ai; dy1 = -1; dx1 = 0; dy2 = -1; dx2 = 1; }
+    else if (opp && ai <= aj) { num = ai; den = aj; dy1 = 0; dx1 = 1; dy2 = -1; dx2 = 1; }
+    else if (same && ai <= aj) { num = ai; den = aj; dy1 = 0; dx1 = 1; dy2 = 1; dx2 = 1; }
+    else if (same && ai >= aj) { num = aj; den = ai; dy1 = 1; dx1 = 0; dy2 = 1; dx2 = 1; }
+    else return 0;
+    const int o1 = dy1 * 3 + dx1, o2 = dy2 * 3 + dx2;
+    const double wq = num / den, omw = 1.0 - wq;
+    const double m = M9[4], c1p = M9[4 + o1], c2p = M9[4 + o2], c1m = M9[4 - o1], c2m = M9[4 - o2];
+    const double lp = c2p * wq + c1p * omw, lm = c2m * wq + c1m * omw;
+    if (!(m > 0.0)) return 0;
+    if (!(lp <= m && lm <= m)) return 0;
+    return (m >= 0.2) ? 2 : ((m >= 0.1) ? 1 : 0);
+}

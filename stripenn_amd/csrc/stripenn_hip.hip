@@ -10,6 +10,10 @@
 #include <new>
 #include "../../include/stripenn_hip.h"
 #include "stp_phases.h"
+#include "stp_canny32.h"
+#ifndef STP_ABLATE_C32
+#define STP_ABLATE_C32 0   /* 1..4: timing-only builds of k_canny_f32 (make ablate32), never shipped */
+#endif
 #include "stp_score.h"
 #include "stp_select.h"
 
@@ -452,6 +456,288 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
             }
         }
         if (tid == 64) *sQn = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_canny_f32 (stp_canny32.h): the same tile / image loop as k_canny_pipe with every phase in f32, the class of a
+// candidate taken from the f32 values when the error budget allows it, and the reference's f64 arithmetic on the
+// 5 x 5 neighbourhood (one wave per pixel) when it does not.  Same class words as k_canny_pipe, bit for bit.
+__device__ __forceinline__ void canny32_collect(int tid, stp_cwin C, stp_p3walk W, float thr, const float* sS, float* sM,
+                                                uint16_t* sQ, int* sQn)
+{
+    const int lane = tid & 63;
+    int r = W.r0, c = W.c0;
+    const int rounds = (W.n + 255) >> 8;                    // workgroup-uniform
+    const int soff = W.my_lo * C32_SP + W.mx_lo;
+    for (int k = 0; k < rounds; k++) {
+        const bool act = tid + 256 * k < W.n;
+        float m[4] = {0.f, 0.f, 0.f, 0.f};
+        int y = 0, x = 0;
+        if (act) {
+            y = 2 * r < W.nmh - 2 ? 2 * r : W.nmh - 2; x = 2 * c < W.nmw - 2 ? 2 * c : W.nmw - 2;
+            c32_sobel_blk2(sS + soff + y * C32_SP + x, m);
+            float* o = sM + W.moff + y * (CT_X + 2) + x;
+            o[0] = m[0]; o[1] = m[1]; o[CT_X + 2] = m[2]; o[CT_X + 3] = m[3];
+        }
+        const int Y = y + W.my_lo, X = x + W.mx_lo;
+        const bool r0 = act && (unsigned)(Y - C.y0) < (unsigned)C.ny && y == 2 * r, r1 = act && (unsigned)(Y + 1 - C.y0) < (unsigned)C.ny;
+        const bool c0 = (unsigned)(X - C.x0) < (unsigned)C.nx && x == 2 * c, c1 = (unsigned)(X + 1 - C.x0) < (unsigned)C.nx;
+        const bool q0 = r0 && c0 && m[0] >= thr, q1 = r0 && c1 && m[1] >= thr, q2 = r1 && c0 && m[2] >= thr, q3 = r1 && c1 && m[3] >= thr;
+        const stp_u64 b0 = __ballot(q0), b1 = __ballot(q1), b2 = __ballot(q2), b3 = __ballot(q3);
+        const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
+        if (n0 + n1 + n2 + n3) {                             // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(sQn, n0 + n1 + n2 + n3);
+            base = __shfl(base, 0);
+            const stp_u64 lt = (1ull << lane) - 1ull;
+            const int e = (Y - 1) * 64 + (X - 1);
+            if (q0) sQ[base + __popcll(b0 & lt)] = (uint16_t)e;
+            if (q1) sQ[base + n0 + __popcll(b1 & lt)] = (uint16_t)(e + 1);
+            if (q2) sQ[base + n0 + n1 + __popcll(b2 & lt)] = (uint16_t)(e + 64);
+            if (q3) sQ[base + n0 + n1 + n2 + __popcll(b3 & lt)] = (uint16_t)(e + 65);
+        }
+        c += W.dc; r += W.dr;
+        if (c >= W.nbw) { c -= W.nbw; r++; }
+    }
+}
+#define C32_NBMAX 8                  /* brightness images whose class words a workgroup keeps in LDS until its tile ends */
+#define C32_DCAP 192                 /* deferred (image, pixel) entries per tile; beyond it the image's pixels are settled at once */
+__device__ __forceinline__ void canny32_nms_queue(int tid, int bi, stp_tile T, stp_c32tol E, const float* sS, const float* sM,
+                                                  uint16_t* sQ, int n, stp_u64* sBits, uint16_t* sD, int* sDn)
+{
+    stp_u64* lowB = sBits;
+    stp_u64* highB = sBits + CT_Y;
+    for (int k = tid; k < n; k += 256) {
+        const int e = sQ[k], yy = e >> 6, xx = e & 63;
+        const int cls = c32_nms(sS, sM, T, T.ty0 + yy, T.tx0 + xx, E);
+        if (cls == 3) {                                              // left to canny32_resolve: at the end of the tile ...
+            const int slot = atomicAdd(sDn, 1);
+            if (slot < C32_DCAP) sD[slot] = (uint16_t)(bi << 11 | e);
+            else sQ[k] = (uint16_t)(e | 0x8000);                      // ... or, the list being full, right after this image
+        } else if (cls >= 1) {
+            atomicOr(&lowB[yy], 1ull << xx);
+            if (cls == 2) atomicOr(&highB[yy], 1ull << xx);
+        }
+    }
+}
+// one pixel, one wave: the 5 x (2R+5) vertical-pass values, the 5 x 5 smoothed values, nine magnitudes, the literal test
+template <int R>
+__device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, const double* sW, const double* sB,
+                                                const float* __restrict__ gimg, float* Vp, double* Sp, stp_u64* sBits)
+{
+    constexpr int NV = 5 * (2 * R + 5);
+    const int yy = e >> 6, xx = e & 63, y = T.ty0 + yy, x = T.tx0 + xx;
+    for (int l = lane; l < NV; l += 64) Vp[l] = c32_res_V<R>(T, y, x, l, sW, gimg);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 25) Sp[lane] = c32_res_S<R>(T, y, x, lane, sW, sB, Vp);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double* M9 = (double*)Vp;                    // the vertical-pass values are dead: nine magnitudes in their place
+    if (lane < 9) M9[lane] = c32_res_mag(Sp, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        const int cls = c32_res_class(Sp, M9);
+        if (cls >= 1) atomicOr(&sBits[yy], 1ull << xx);
+        if (cls == 2) atomicOr(&sBits[CT_Y + yy], 1ull << xx);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+#ifndef STP_C32_MINBLK
+#define STP_C32_MINBLK 5
+#endif
+#define C32_QCAP (CT_X * CT_Y)       /* candidates of a tile: at most every pixel */
+struct stp_c32_layout { size_t sB, sRB, sRBB, sS, sV, sQ, sD, sBits, sQn, total; };
+static __host__ __device__ stp_c32_layout canny32_layout(int R)
+{
+    const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
+    stp_c32_layout L;
+    size_t o = 32 * sizeof(double);                          // sW
+    L.sB = o; o += 2 * VH * sizeof(double);
+    L.sRB = o; o += (size_t)((VH + 1) & ~1) * sizeof(float);
+    L.sRBB = o; o += (size_t)VH * 2 * R * sizeof(float);
+    L.sS = o; o += (size_t)VH * C32_SP * sizeof(float);      // smoothed tile | the resolver's per-wave scratch
+    L.sV = o;                                                 // vertical-pass tile | magnitude tile + candidate queue
+    const size_t v = (size_t)(CT_P2_COLS(R) > GW ? CT_P2_COLS(R) : GW) * CT_VP * sizeof(float);
+    const size_t mq = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(float);
+    L.sQ = o + mq;
+    const size_t m = mq + C32_QCAP * sizeof(uint16_t);
+    o += ((v > m ? v : m) + 7) & ~(size_t)7;
+    L.sD = o; o += C32_DCAP * sizeof(uint16_t);
+    L.sBits = o; o += (size_t)C32_NBMAX * 2 * CT_Y * sizeof(stp_u64);
+    L.sQn = o; o += 16;
+    L.total = o;
+    return L;
+}
+#define C32_RES_WAVE_BYTES 768       /* per-wave resolver scratch inside the smoothed tile: 26 doubles, then 5 x (2R+5) floats (<= 125) */
+
+template <int RT>
+__global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
+                                                    int nf, int nlev, int nb, const double* __restrict__ gw,
+                                                    stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_w32 W32,
+                                                    const float2* __restrict__ cells)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int R = RT;
+    constexpr int TPI = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);   // 91
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int pair = xcd + 8 * (j / TPI), tile = j % TPI;
+    if (pair >= nf * nlev) return;
+    const int fl = pair / nlev, lev = pair - fl * nlev;
+    const int S = fS[f0 + fl];
+    if (S == 0) return;
+    constexpr int tpr = (STP_FRAME_MAX + CT_X - 1) / CT_X;
+    stp_tile T;
+    T.S = S; T.ty0 = (tile / tpr) * CT_Y; T.tx0 = (tile % tpr) * CT_X;
+    if (T.ty0 >= S || T.tx0 >= S) return;
+    const stp_c32_layout L = canny32_layout(R);
+    double* sW = (double*)smem;                   // f64 weights: the exact resolver and the bleed-over tables
+    double* sB = (double*)(smem + L.sB);
+    float* sRB = (float*)(smem + L.sRB);
+    float* sRBB = (float*)(smem + L.sRBB);
+    float* sS = (float*)(smem + L.sS);
+    float* sV = (float*)(smem + L.sV);
+    float* sM = sV;                               // magnitude tile over the dead vertical-pass buffer
+    uint16_t* sQ = (uint16_t*)(smem + L.sQ);
+    uint16_t* sD = (uint16_t*)(smem + L.sD);      // deferred pixels: image << 11 | tile pixel
+    stp_u64* sBits = (stp_u64*)(smem + L.sBits);  // class words of every image of this tile: [image][low | high][row]
+    int* sQn = (int*)(smem + L.sQn);
+    int* sDn = sQn + 1;
+    const int tid = threadIdx.x, nt = blockDim.x, wv = tid >> 6, lane = tid & 63;
+    float* sVp = (float*)(smem + L.sS + wv * C32_RES_WAVE_BYTES + 26 * sizeof(double));     // (used only while sS is dead)
+    double* sSp = (double*)(smem + L.sS + wv * C32_RES_WAVE_BYTES);
+    for (int i = tid; i < nb * 2 * CT_Y; i += nt) sBits[i] = 0ull;
+    if (tid == 64) { *sQn = 0; *sDn = 0; }
+    if (tid < 2 * R + 1) sW[tid] = gw[tid];
+    canny_p1b(tid, nt, T, R, gw, sB);
+    __syncthreads();
+    const bool yin = (T.ty0 - R - 2 >= 0) && (T.ty0 + CT_Y + R + 1 < S);
+    const bool xin = (T.tx0 - 2 - R >= 0) && (T.tx0 + CT_X + 1 + R < S);
+    c32_rb_tables<R>(tid, nt, T, sW, sB, sRB, sRBB, xin);
+    __syncthreads();
+    const size_t img0 = ((size_t)fl * nlev + lev) * nb;
+    constexpr int GWc = CT_X + 2 * R + 4, NG1 = (CT_Y + 4) / ((R <= 8) ? CT_VRUN : CT_VRUN / 2);
+    constexpr int NR1 = (GWc * NG1 + 255) / 256;
+    constexpr int NR2 = ((CT_Y + 4) * ((CT_X + 4 + CT_HRUN_R(R) - 1) / CT_HRUN_R(R)) + 255) / 256;
+    int it1[NR1], it2[NR2];
+    stp_p3walk W3;
+    {
+        const stp_cgeo G = ct_geo<R>(T);
+#pragma unroll
+        for (int k = 0; k < NR1; k++) it1[k] = ct_p1_decode<R>(G, tid + 256 * k);
+#pragma unroll
+        for (int k = 0; k < NR2; k++) it2[k] = ct_p2_decode<R>(G, tid + 256 * k);
+        W3 = ct_p3_walk(G, tid, 256);
+    }
+    const stp_cwin CW = canny_cand_window(T);
+    int cell_off = -1;
+    bool use_cells = cells != nullptr;
+    {
+        const int wy0 = max(T.ty0 - R - 2, 0), wy1 = min(T.ty0 + CT_Y + R + 2, S);
+        const int wx0 = max(T.tx0 - R - 2, 0), wx1 = min(T.tx0 + CT_X + R + 2, S);
+        const int r0 = wy0 / GC_CY, nr = (wy1 - 1) / GC_CY - r0 + 1, c0 = wx0 / GC_CX, nc = (wx1 - 1) / GC_CX - c0 + 1;
+        if (nr * nc > 64) use_cells = false;
+        else if (lane < nr * nc) { const int rr = lane / nc; cell_off = (r0 + rr) * GC_COLS + c0 + (lane - rr * nc); }
+    }
+    for (int bi = 0; bi < nb; bi++) {
+        const size_t img = img0 + bi;
+        const float* gimg = gray + img * (STP_PITCH * STP_PITCH);
+        stp_u64* bits = sBits + bi * 2 * CT_Y;
+        float gmax = 1.0000005f;                     // k_gray's grey values never exceed 0.299 + 0.587 + 0.114 (+ 3 roundings)
+        if (use_cells) {
+            float mn = INFINITY, mx = -INFINITY;
+            if (cell_off >= 0) { const float2 v = cells[img * (GC_ROWS * GC_COLS) + cell_off]; mn = v.x; mx = v.y; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+            if (mx - mn < STP_FLAT_RANGE) continue;  // flat window: no pixel of this tile can reach the low threshold (words stay 0)
+            gmax = mx;
+        }
+        const stp_c32tol E = c32_tol(gmax);
+#pragma unroll
+        for (int k = 0; k < NR1; k++) {
+            int it = it1[k];
+            asm volatile("" : "+v"(it));              // see k_canny_pipe
+            if (it >= 0) {
+                if (it >> 16) canny_p1_zero<R>(it & 255, (it >> 8) & 255, sV);
+                else if (yin) c32_p1_item<R, true>(T, it & 255, (it >> 8) & 255, W32, gimg, sV);
+                else c32_p1_item<R, false>(T, it & 255, (it >> 8) & 255, W32, gimg, sV);
+            }
+        }
+        __syncthreads();
+#if STP_ABLATE_C32 == 1                  /* timing-only builds: stop after the vertical pass ... */
+        if (tid == 0) low[img * (STP_FRAME_MAX * STP_NW)] = (stp_u64)sV[70];
+        __syncthreads();
+        continue;
+#endif
+#pragma unroll
+        for (int k = 0; k < NR2; k++) {
+            int it = it2[k];
+            asm volatile("" : "+v"(it));
+            if (it >= 0) {
+                if (xin) c32_p2_item<R, true>(T, it & 255, it >> 8, W32, sV, sRB, sRBB, sS);
+                else c32_p2_item<R, false>(T, it & 255, it >> 8, W32, sV, sRB, sRBB, sS);
+            }
+        }
+        __syncthreads();
+#if STP_ABLATE_C32 == 2                  /* ... after the horizontal pass ... */
+        if (tid == 0) low[img * (STP_FRAME_MAX * STP_NW)] = (stp_u64)sS[70];
+        __syncthreads();
+        continue;
+#endif
+        if (!(xin && yin)) {
+            c32_p3_ring(tid, nt, T, sS);
+            __syncthreads();
+        }
+        canny32_collect(tid, CW, W3, E.thr, sS, sM, sQ, sQn);
+        __syncthreads();
+#if STP_ABLATE_C32 == 3                  /* ... after the magnitudes and the candidate collection ... */
+        if (tid == 64) *sQn = 0;
+        __syncthreads();
+        continue;
+#endif
+        const int nq = *sQn;
+        canny32_nms_queue(tid, bi, T, E, sS, sM, sQ, nq, bits, sD, sDn);
+        __syncthreads();     // sM / sQ alias sV: the class test must be done before the next vertical pass writes it
+        if (*sDn > C32_DCAP) {                       // (workgroup-uniform; rare: plateaus, ties) the list overflowed: this image's
+                                                     // remaining pixels are flagged in the queue -- settle them now, a wave per pixel
+#if STP_ABLATE_C32 != 4
+            for (int k0 = wv * 64; k0 < nq; k0 += 256) {
+                const int e = k0 + lane < nq ? sQ[k0 + lane] : 0;
+                stp_u64 todo = __ballot((e & 0x8000) != 0);
+                while (todo) {                                           // wave-uniform
+                    const int src = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    canny32_resolve<R>(T, __shfl(e, src) & 0x7FFF, lane, sW, sB, gimg, sVp, sSp, bits);
+                }
+            }
+#endif
+            __syncthreads();
+            if (tid == 64) *sDn = C32_DCAP;
+        }
+        if (tid == 64) *sQn = 0;
+    }
+    __syncthreads();
+#if STP_ABLATE_C32 == 0
+    {                                                // the deferred pixels of all images of this tile, a wave per pixel
+        const int nd = min(*sDn, C32_DCAP);
+        for (int k = wv; k < nd; k += 4) {
+            const int d = sD[k], bi = d >> 11;
+            canny32_resolve<R>(T, d & 2047, lane, sW, sB, gray + (img0 + bi) * (STP_PITCH * STP_PITCH), sVp, sSp, sBits + bi * 2 * CT_Y);
+        }
+    }
+    __syncthreads();
+#endif
+    for (int i = tid; i < nb * CT_Y; i += nt) {      // the tile's class words of every image
+        const int bi = i / CT_Y, row = i - bi * CT_Y, y = T.ty0 + row;
+        if (y < S) {
+            const size_t o = (img0 + bi) * (STP_FRAME_MAX * STP_NW) + y * STP_NW + (T.tx0 >> 6);
+            low[o] = sBits[bi * 2 * CT_Y + row];
+            high[o] = sBits[bi * 2 * CT_Y + CT_Y + row];
+        }
     }
 }
 
@@ -1453,8 +1739,23 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         prof_scope ps(ctx, "canny", ipx * 5.0);          // stage B: 4 B read + 1 B written
         const int tiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
         const dim3 cg(tiles, (unsigned)nimg);
-        const stp_fastdiv fd = make_fastdiv(ctx, prm->gauss_w, R);
         const unsigned pgrid = (unsigned)(((nf * nlev + 7) / 8) * 8 * tiles);
+        // STP_CANNY=exact selects k_canny_pipe (every intermediate in the reference's f64 arithmetic); the default
+        // k_canny_f32 needs k_gray's per-cell grey maxima for its error budget (bfilter 3)
+        static const bool canny_exact = getenv("STP_CANNY") && strcmp(getenv("STP_CANNY"), "exact") == 0;
+        if ((R == 8 || R == 10) && p_cells && nb <= C32_NBMAX && !canny_exact) {
+            stp_w32 W32;
+            for (int k = 0; k <= CT_RMAX; k++) W32.w[k] = k <= R ? (float)prm->gauss_w[k] : 0.0f;
+            const size_t smem = canny32_layout(R).total;
+            if (R == 8)
+                hipLaunchKernelGGL(k_canny_f32<8>, dim3(pgrid), dim3(256), smem, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, d_w,
+                                   d_low, d_high, W32, (const float2*)p_cells);
+            else
+                hipLaunchKernelGGL(k_canny_f32<10>, dim3(pgrid), dim3(256), smem, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, d_w,
+                                   d_low, d_high, W32, (const float2*)p_cells);
+            HIPCHK(hipGetLastError());
+        } else {
+        const stp_fastdiv fd = make_fastdiv(ctx, prm->gauss_w, R);
         if (R == 8)
             hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES, ctx->stream, d_gray,
                                fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high, fd, (const float2*)p_cells);
@@ -1464,6 +1765,7 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         else
             hipLaunchKernelGGL(k_canny, cg, dim3(256), canny_smem_bytes(R) + CANNY_NMS_BYTES, ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
                                d_low, d_high);
+        }
     }
     HIPCHK(hipGetLastError());
     {

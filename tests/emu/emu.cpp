@@ -8,6 +8,50 @@
 #include <string.h>
 #include "../../include/stripenn_hip.h"
 #include "../../stripenn_amd/csrc/stp_phases.h"
+#include "../../stripenn_amd/csrc/stp_canny32.h"
+
+
+// k_canny_f32 of one tile: the f32 phases, the certified class test and the exact per-pixel resolver
+static long long g_c32_uncertain = 0, g_c32_candidates = 0;
+template <int R>
+static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float gmax, const double* sB, float* sV, float* sM,
+                         uint8_t* sC, bool xin, bool yin)
+{
+    const int VH = CT_Y + 4;
+    const float qnan = std::numeric_limits<float>::quiet_NaN();
+    std::vector<float> sS(VH * C32_SP, qnan), sRB(VH, qnan), sRBB(VH * 2 * R, qnan);
+    stp_w32 W;
+    for (int k = 0; k <= R; k++) W.w[k] = (float)w[k];
+    const stp_cgeo G = ct_geo<R>(T);
+    c32_rb_tables<R>(0, 1, T, w, sB, sRB.data(), sRBB.data(), xin);
+    if (yin) c32_p1_blk<R, true>(0, 1, T, G, W, gray, sV);
+    else c32_p1_blk<R, false>(0, 1, T, G, W, gray, sV);
+    if (xin) c32_p2_blk<R, true>(0, 1, T, G, W, sV, sRB.data(), sRBB.data(), sS.data());
+    else c32_p2_blk<R, false>(0, 1, T, G, W, sV, sRB.data(), sRBB.data(), sS.data());
+    if (!(xin && yin)) c32_p3_ring(0, 1, T, sS.data());
+    c32_p3_walk(0, 1, ct_p3_walk(G, 0, 1), sS.data(), sM);
+    const stp_c32tol E = c32_tol(gmax);
+    constexpr int NV = 5 * (2 * R + 5);
+    for (int i = 0; i < CT_Y * CT_X; i++) {
+        const int yy = i / CT_X, xx = i - yy * CT_X, y = T.ty0 + yy, x = T.tx0 + xx;
+        int cls = 0;
+        if (y < T.S && x < T.S) {
+            cls = c32_nms(sS.data(), sM, T, y, x, E);
+            if (y >= 1 && x >= 1 && y < T.S - 1 && x < T.S - 1 && sM[(yy + 1) * (CT_X + 2) + xx + 1] >= E.thr) g_c32_candidates++;
+            if (cls == 3) {
+                g_c32_uncertain++;
+                float Vp[NV];
+                double Sp[25];
+                for (int l = 0; l < NV; l++) Vp[l] = c32_res_V<R>(T, y, x, l, w, gray);
+                for (int l = 0; l < 25; l++) Sp[l] = c32_res_S<R>(T, y, x, l, w, sB, Vp);
+                double M9[9];
+                for (int l = 0; l < 9; l++) M9[l] = c32_res_mag(Sp, l);
+                cls = c32_res_class(Sp, M9);
+            }
+        }
+        sC[i] = (uint8_t)cls;
+    }
+}
 
 extern "C" {
 
@@ -87,6 +131,7 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
     for (int ty0 = 0; ty0 < S; ty0 += CT_Y)
         for (int tx0 = 0; tx0 < S; tx0 += CT_X) {
             stp_tile T; T.S = S; T.ty0 = ty0; T.tx0 = tx0;
+            float gmax = 1.0f;
             if (blocked && (R == 8 || R == 10)) {
                 // k_canny_pipe's flat-window rule, evaluated here straight from the grey image over the same
                 // cell-aligned window (the kernel unites k_gray's per-cell min / max): skipped tiles stay all-zero
@@ -98,6 +143,7 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
                 for (int y = Y0; y < Y1; y++)
                     for (int x = X0; x < X1; x++) { const float v = gray[y * STP_PITCH + x]; mn = std::min(mn, v); mx = std::max(mx, v); }
                 if (mx - mn < STP_FLAT_RANGE) continue;
+                gmax = mx;
             }
             canny_p0(0, 1, gray, T, R, sG.data());
             canny_p1b(0, 1, T, R, w, sB.data());
@@ -110,6 +156,12 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
                 std::fill(sV.begin(), sV.end(), std::numeric_limits<float>::quiet_NaN());
                 std::fill(sS.begin(), sS.end(), std::numeric_limits<double>::quiet_NaN());
                 std::fill(sM.begin(), sM.end(), std::numeric_limits<float>::quiet_NaN());
+            }
+            if (blocked == 2 && (R == 8 || R == 10)) {     // k_canny_f32: f32 phases, certified classes, exact resolver
+                if (R == 8) emu_tile_c32<8>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin);
+                else emu_tile_c32<10>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin);
+                canny_p5(0, 1, T, sC.data(), low, high);
+                continue;
             }
             if (R == 8 && blocked) {       // the device path for sigma 2.0 (k_canny_pipe<8>)
                 std::vector<double> sBB(VH * 16);
@@ -144,6 +196,12 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
 void emu_canny(const float* gray, int S, int R, const double* w, stp_u64* low, stp_u64* high)
 {
     emu_canny2(gray, S, R, w, low, high, 1);
+}
+void emu_canny_f32(const float* gray, int S, int R, const double* w, stp_u64* low, stp_u64* high, long long* counts /* candidates, uncertain */)
+{
+    g_c32_uncertain = 0; g_c32_candidates = 0;
+    emu_canny2(gray, S, R, w, low, high, 2);
+    if (counts) { counts[0] = g_c32_candidates; counts[1] = g_c32_uncertain; }
 }
 
 struct emu_rec { int32_t ud, x, y, w, h; double total; };

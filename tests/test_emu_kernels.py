@@ -35,6 +35,14 @@ def _unpack(words, S):
     return b[:S, :S]
 
 
+def _canny_f32(emu, full, S, R, gw):
+    """Replay of k_canny_f32 (stp_canny32.h): f32 phases, certified class test, exact per-pixel resolver.
+    Returns the class map and (candidates, pixels sent to the resolver)."""
+    low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64); cnt = np.zeros(2, np.int64)
+    emu.emu_canny_f32(_p(np.ascontiguousarray(full)), S, R, _p(gw), _p(low), _p(high), _p(cnt))
+    return _unpack(low, S).astype(np.uint8) + _unpack(high, S), cnt
+
+
 @pytest.mark.parametrize('ci', [0, 2, 4, 5])
 def test_emulated_kernels_match_oracle(emu, golden_stages, chr7, ci):
     g = golden_stages
@@ -62,6 +70,8 @@ def test_emulated_kernels_match_oracle(emu, golden_stages, chr7, ci):
         emu.emu_canny(_p(gray[bi]), S, 8, _p(gw), _p(low), _p(high))
         oe, dbg = O.canny(og, gw, 8, debug=True)
         assert np.array_equal(_unpack(low, S).astype(np.uint8) + _unpack(high, S), dbg['cls'])
+        cls32, cnt = _canny_f32(emu, gray[bi], S, 8, gw)       # k_canny_f32's phases: same classes, few exact resolutions
+        assert np.array_equal(cls32, dbg['cls']) and cnt[1] < 0.01 * cnt[0] + 50
         dbgw = np.zeros(4 * 2800, np.uint64); cols = np.zeros(1200, np.int16); recs = (ER * 128)(); sw = C.c_int(0)
         n = emu.emu_lines(_p(low), _p(high), _p(band), W, hw, C.c_int64(start), _p(nz), S, 10, 8, _p(dbgw), _p(cols), recs,
                           128, C.byref(sw))
@@ -127,6 +137,9 @@ def test_canny_ties_and_plateaus(emu, S, golden_stages):
         got = _unpack(low, S).astype(np.uint8) + _unpack(high, S)
         assert np.array_equal(got, dbg['cls']), 'plateau image %d (S=%d)' % (k, S)
         assert dbg['cls'].any()
+        cls32, cnt = _canny_f32(emu, full, S, 8, gw)            # exact ties: (nearly) every candidate goes to the resolver
+        assert np.array_equal(cls32, dbg['cls']), 'f32 path, plateau image %d (S=%d)' % (k, S)
+        assert cnt[1] > 0
 
 
 def test_generic_radius_path(emu, golden_stages):
@@ -179,6 +192,8 @@ def test_canny_sizes_radii_and_exact_fallback(emu, emu_allnear, golden_stages, S
             lib.emu_canny(_p(full), S, R, _p(gw), _p(low), _p(high))
             got = _unpack(low, S).astype(np.uint8) + _unpack(high, S)
             assert np.array_equal(got, dbg['cls']), 'image %d (S=%d, sigma %.1f)' % (k, S, sigma)
+        cls32, cnt = _canny_f32(emu, full, S, R, gw)
+        assert np.array_equal(cls32, dbg['cls']), 'f32 path, image %d (S=%d, sigma %.1f)' % (k, S, sigma)
 
 
 def test_fma_certification_random_windows(emu, golden_stages):
@@ -195,3 +210,35 @@ def test_fma_certification_random_windows(emu, golden_stages):
         assert bad == 0
         assert worst.value <= R + 1
         assert flagged.value < 100          # ~64 / 2^29 of the outputs
+
+
+@pytest.mark.parametrize('sigma,key', [(2.0, 'gw_2p0'), (2.5, 'gw_2p5')])
+def test_f32_path_on_threshold_and_octant_boundaries(emu, golden_stages, sigma, key):
+    """Adversarial inputs for k_canny_f32's error budget: ramps whose magnitude sits on the 0.1 / 0.2 thresholds
+    (8 * slope), diagonal ramps (|isobel| == |jsobel|: octant boundary), each with noise far below and around the f32
+    rounding error, and a bright image (grey near 1: the largest absolute errors).  Classes must equal the oracle's
+    whether the certified test or the exact resolver decides."""
+    gw = np.ascontiguousarray(golden_stages[key])
+    R = (len(gw) - 1) // 2
+    S = 200
+    yy, xx = np.mgrid[0:S, 0:S].astype(np.float64)
+    rng = np.random.default_rng(5)
+    imgs = []
+    for slope, amp in [(0.0125, 0.0), (0.0125, 1e-7), (0.0125, 3e-6), (0.025 / 2, 1e-5), (0.025, 1e-6), (0.0124, 2e-5)]:
+        base = 0.05 + slope * (xx % 60)                                   # saw-tooth: ramps and falling steps
+        imgs.append(base + amp * rng.standard_normal((S, S)))
+    for amp in (0.0, 1e-6, 1e-4):
+        imgs.append(0.1 + 0.00884 * ((xx + yy) % 80) / 1.0 + amp * rng.standard_normal((S, S)))       # diagonal ramp, m ~ 0.1
+        imgs.append(0.9 - 0.004 * ((xx - yy) % 50) + amp * rng.standard_normal((S, S)))
+    imgs.append(np.clip(0.97 + 0.03 * rng.standard_normal((S, S)), 0, 1))     # bright, saturating
+    imgs.append(np.clip(0.5 + 0.5 * np.sin(xx / 3.0) * np.sin(yy / 5.0), 0, 1))
+    total = np.zeros(2, np.int64)
+    for k, img in enumerate(imgs):
+        img = np.ascontiguousarray(np.clip(img, 0, 1), dtype=np.float32)
+        full = np.zeros((400, 400), np.float32)
+        full[:S, :S] = img
+        oe, dbg = O.canny(img, gw, R, debug=True)
+        cls32, cnt = _canny_f32(emu, full, S, R, gw)
+        total += cnt
+        assert np.array_equal(cls32, dbg['cls']), 'image %d (sigma %.1f): %d pixels differ' % (k, sigma, int((cls32 != dbg['cls']).sum()))
+    assert total[1] > 1000        # the inputs do reach the resolver
