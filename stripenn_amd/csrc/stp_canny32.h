@@ -19,11 +19,13 @@
 //                     over the in-image taps), so |Ha - H| / bleed <= 22.1 u g at borders too.
 //   scaling           Sa = RN32(Ha * rb), rb = RN32(1 / (bleed + eps)): two more roundings:
 //                     E_S = |Sa - S| <= 24.2 u g   (the reference's f64 quotient adds 2^-53).           used: 25 u g
-//   Sobel             d = RN32(s1 - s2): 2 E_S + u g;  t = RN32(dm + dp): 4 E_S + 4 u g;  j = RN32(2 d0 + t):
-//                     E_G = 8 E_S + 10 u g + u |j| ... <= 212 u g  (|j| <= 4 g; the reference's f64 Sobel adds ~2^-50)
+//   Sobel             row terms hd = RN32(s[x+1] - s[x-1]): 2 E_S + u g;  hs = RN32(2 s[x] + RN32(s[x-1] + s[x+1])):
+//                     4 E_S + 6 u g;  j = RN32(2 hd1 + RN32(hd0 + hd2)): 8 E_S + 10 u g;  i = RN32(hs2 - hs0):
+//                     8 E_S + 16 u g  (|i|, |j| <= 4 g; the reference's f64 Sobel adds ~2^-50).  The class test's own
+//                     Sobel sums (c32_sobel: differences first) stay below the same bound.   E_G <= 216 u g, used: 217
 //   magnitude         |hypot(ia, ja) - hypot(i, j)| <= sqrt(2) E_G; f32 evaluation: fma + product (2 u of the sum of
 //                     squares -> u of the root) + v_sqrt_f32 (1 ulp <= 2 u): 3.1 u m, m <= 5.66 g:
-//                     E_M <= (300 + 17.6) u g                                                             used: 320 u g
+//                     E_M <= (306.9 + 17.6) u g                                                           used: 325 u g
 //   interpolation     w = num / den: |wa - w| <= 2 E_G / (den - E_G) + 4 u (v_rcp_f32 1 ulp + product);
 //                     l = c2 w + c1 (1 - w): |la - l| <= E_M + |wa - w| (|c2a - c1a| + 2 E_M) + 3 u max(c) (17 u g)
 //   A comparison l <= m is taken from the f32 values when |la - ma| > 2 E_M + 17 u g + |wa - w| (...); m >= 0.1 / 0.2
@@ -34,9 +36,9 @@
 #pragma once
 
 #define C32_SP (CT_X + 6)          /* pitch (floats) of the f32 smoothed tile: even (aligned pairs), 6 mod 64 banks per row */
-#define C32_EG_U 213.0f            /* bounds in units of u * g (rounded up; the products below add an absolute slack) */
-#define C32_EM_U 321.0f
-#define C32_T0_U 662.0f            /* 2 E_M + 17 */
+#define C32_EG_U 218.0f            /* bounds in units of u * g (rounded up; the products below add an absolute slack) */
+#define C32_EM_U 326.0f
+#define C32_T0_U 670.0f            /* 2 E_M + 17 */
 
 struct stp_w32 { float w[CT_RMAX + 1]; };     // RN32 of the Gaussian weights, w[R] the centre: a kernel argument (SGPRs)
 
@@ -53,17 +55,23 @@ STP_HD stp_c32tol c32_tol(float gmax)
 }
 
 // ---- vertical pass, one item (column xx of the tile window, VRUN output rows from yy0): as canny_p1_item ----
-template <int R, bool YIN>
-STP_HD void c32_p1_item(stp_tile T, int xx, int yy0, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
+// In two halves, so that k_canny_f32 can issue the loads of the NEXT image's item before the other phases of the
+// current one (the values arrive while those run): the VRUN + 2R grey values of the column ...
+template <int R>
+STP_HD void c32_p1_load(stp_tile T, int xx, int yy0, const float* __restrict__ gimg, float* raw)
 {
     constexpr int VRUN = (R <= 8) ? CT_VRUN : CT_VRUN / 2;
-    const int x = T.tx0 - R - 2 + xx;
-    float raw[VRUN + 2 * R];
-    const float* col = gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + x;    // guard bytes around the grey images: see canny_p1_item
+    const float* col = gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + (T.tx0 - R - 2 + xx);    // guard bytes around the grey images: see canny_p1_item
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int k = 0; k < VRUN + 2 * R; k++) raw[k] = col[k * STP_PITCH];
+}
+// ... and the VRUN filtered values from them
+template <int R, bool YIN>
+STP_HD void c32_p1_compute(stp_tile T, int xx, int yy0, const stp_w32& W, float* raw, float* sVT)
+{
+    constexpr int VRUN = (R <= 8) ? CT_VRUN : CT_VRUN / 2;
     if (!YIN) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -88,6 +96,14 @@ STP_HD void c32_p1_item(stp_tile T, int xx, int yy0, const stp_w32& W, const flo
         }
         sVT[xx * CT_VP + yy0 + q] = a;
     }
+}
+template <int R, bool YIN>
+STP_HD void c32_p1_item(stp_tile T, int xx, int yy0, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
+{
+    constexpr int VRUN = (R <= 8) ? CT_VRUN : CT_VRUN / 2;
+    float raw[VRUN + 2 * R];
+    c32_p1_load<R>(T, xx, yy0, gimg, raw);
+    c32_p1_compute<R, YIN>(T, xx, yy0, W, raw, sVT);
 }
 template <int R, bool YIN>
 STP_HD void c32_p1_blk(int tid, int nt, stp_tile T, stp_cgeo G, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
@@ -211,61 +227,40 @@ STP_HD void c32_sobel(const float* c, float* is, float* js)
     *js = fmaf(s12 - s10, 2.0f, (s02 - s00) + (s22 - s20));
     *is = fmaf(s21 - s01, 2.0f, (s20 - s00) + (s22 - s02));
 }
-// four magnitudes M(yy..yy+1, xx..xx+1) from the 4 x 4 values at `c` (= S(yy, xx), see ct_sobel_blk2)
-STP_HD void c32_sobel_blk2(const float* c, float* m)
+// Magnitudes by rows.  Per smoothed row r and magnitude column X (smoothed columns X .. X+2) two terms:
+//   hd = s[X+2] - s[X]   and   hs = 2 s[X+1] + (s[X] + s[X+2]);
+// the magnitude of (Y, X) takes them from rows Y, Y+1, Y+2:  j = 2 hd1 + (hd0 + hd2),  i = hs2 - hs0.
+// A lane walking down a column keeps the terms of the two previous rows: 3 LDS reads and 9 operations per pixel.
+STP_HD void c32_row_terms(const float* s3, float* hd, float* hs)
 {
-    float s[4][4];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int r = 0; r < 4; r++) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int q = 0; q < 4; q++) s[r][q] = c[r * C32_SP + q];
-    }
-    float H[4][2], V[2][4];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int r = 0; r < 4; r++) { H[r][0] = s[r][2] - s[r][0]; H[r][1] = s[r][3] - s[r][1]; }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int q = 0; q < 4; q++) { V[0][q] = s[2][q] - s[0][q]; V[1][q] = s[3][q] - s[1][q]; }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int r = 0; r < 2; r++) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int q = 0; q < 2; q++) {
-            const float j = fmaf(H[r + 1][q], 2.0f, H[r][q] + H[r + 2][q]);
-            const float i = fmaf(V[r][q + 1], 2.0f, V[r][q] + V[r][q + 2]);
-            m[r * 2 + q] = c32_sqrt(fmaf(i, i, j * j));
-        }
-    }
+    const float a = s3[0], b = s3[1], c = s3[2];
+    *hd = c - a;
+    *hs = fmaf(b, 2.0f, a + c);
 }
-// all blocks of the in-image magnitude region (CPU replay; the kernel walks the same blocks in canny32_collect)
-STP_HD void c32_p3_walk(int tid, int nt, stp_p3walk W, const float* sS, float* sM)
+STP_HD float c32_mag(float hd0, float hd1, float hd2, float hs0, float hs2)
 {
-    int r = W.r0, c = W.c0;
-    const int soff = W.my_lo * C32_SP + W.mx_lo;
-    for (int i = tid; i < W.n; i += nt) {
-        const int y = 2 * r < W.nmh - 2 ? 2 * r : W.nmh - 2, x = 2 * c < W.nmw - 2 ? 2 * c : W.nmw - 2;
-        float m[4];
-        c32_sobel_blk2(sS + soff + y * C32_SP + x, m);
-        float* o = sM + W.moff + y * (CT_X + 2) + x;
-        o[0] = m[0]; o[1] = m[1]; o[CT_X + 2] = m[2]; o[CT_X + 3] = m[3];
-        c += W.dc; r += W.dr;
-        if (c >= W.nbw) { c -= W.nbw; r++; }
-    }
+    const float j = fmaf(hd1, 2.0f, hd0 + hd2), i = hs2 - hs0;
+    return c32_sqrt(fmaf(i, i, j * j));
+}
+// one pixel of the magnitude tile from scratch (the two halo columns of k_canny_f32; CPU replay of the whole region)
+STP_HD float c32_mag_px(const float* sS, int Y, int X)
+{
+    float hd0, hd1, hd2, hs0, hs1, hs2;
+    c32_row_terms(sS + Y * C32_SP + X, &hd0, &hs0);
+    c32_row_terms(sS + (Y + 1) * C32_SP + X, &hd1, &hs1);
+    c32_row_terms(sS + (Y + 2) * C32_SP + X, &hd2, &hs2);
+    return c32_mag(hd0, hd1, hd2, hs0, hs2);
+}
+// the in-image region of the magnitude tile (CPU replay; the kernel walks it by rows in canny32_mag_rows)
+STP_HD void c32_p3_region(stp_cgeo G, const float* sS, float* sM)
+{
+    for (int Y = G.my_lo; Y < G.my_lo + G.nmh; Y++)
+        for (int X = G.mx_lo; X < G.mx_lo + (int)G.nmw.d; X++) sM[Y * (CT_X + 2) + X] = c32_mag_px(sS, Y, X);
 }
 
 // Class of tile pixel (y, x) from the f32 tiles: 0 / 1 / 2, or 3 = not decidable inside the error budget.
 // Decision structure of _canny.py:193-280 as in ct_nms.
-STP_HD int c32_nms(const float* sS, const float* sM, stp_tile T, int y, int x, stp_c32tol E)
+STP_HD int c32_nms_E(const float* sS, const float* sM, stp_tile T, int y, int x, stp_c32tol E)
 {
     if (y < 1 || x < 1 || y >= T.S - 1 || x >= T.S - 1) return 0;
     const int MW = CT_X + 2;
@@ -290,6 +285,23 @@ STP_HD int c32_nms(const float* sS, const float* sM, stp_tile T, int y, int x, s
     if (fabsf(lp - m0) <= tp || fabsf(lm - m0) <= tm) return 3;
     if (!(lp <= m0 && lm <= m0)) return 0;
     return m0 >= 0.2f ? 2 : 1;
+}
+
+// The class test proper.  The budget above is relative to the grey values that reach the pixels involved, so a pixel the
+// tile-wide budget (g = the largest grey value of the tile's whole input window) leaves undecided gets a second look
+// with g = the largest smoothed value of its 5 x 5 neighbourhood -- which holds the 3 x 3 neighbourhoods of the pixel
+// and of the four neighbours it is compared with; every bound above is a sum over those pixels, each term relative to
+// the value it belongs to (+25 u for taking the f32 values as the scale).  Unwritten cells beyond the image ring are
+// not part of any of those sums (NaN stand-ins in the CPU replay are ignored by fmaxf; any other value only widens the budget).
+STP_HD int c32_nms(const float* sS, const float* sM, stp_tile T, int y, int x, stp_c32tol E)
+{
+    const int cls = c32_nms_E(sS, sM, T, y, x, E);
+    if (cls != 3) return cls;
+    const float* c = sS + (y - (T.ty0 - 2)) * C32_SP + (x - (T.tx0 - 2));
+    float sm = 0.0f;
+    for (int dy = -2; dy <= 2; dy++)
+        for (int dx = -2; dx <= 2; dx++) sm = fmaxf(sm, c[dy * C32_SP + dx]);
+    return c32_nms_E(sS, sM, T, y, x, c32_tol(sm * 1.00001f));
 }
 
 // The reference's order for one output (as stp_gauss_exact) with a compile-time radius: every tap is loaded before the
@@ -327,19 +339,20 @@ STP_HD float c32_res_V(stp_tile T, int y, int x, int l, const double* w, const f
     return c32_gauss_exact<R>(gimg + yy * STP_PITCH + xx, STP_PITCH, w, lo, hi);
 }
 // S patch: element l = r * 5 + c is the smoothed value at (clamp(y-2+r), clamp(x-2+c)), the reference's operations
-// (canny_p2: f32 horizontal sum in the exact order, f64 quotient by bleed + eps)
+// (canny_p2: f32 horizontal sum in the exact order, f64 quotient by bleed + eps; the bleed-over factors as canny_p1b
+// tabulates them: column factor of the row, then the row pass at the pixel's column -- at column R for every
+// interior column)
 template <int R>
-STP_HD double c32_res_S(stp_tile T, int y, int x, int l, const double* w, const double* sB, const float* Vp)
+STP_HD double c32_res_S(stp_tile T, int y, int x, int l, const double* w, const float* Vp)
 {
     constexpr int NC = 2 * R + 5;
-    const int VH = CT_Y + 4;
     const int r = l / 5, c = l - r * 5;
     int yy = y - 2 + r, cx = x - 2 + c;
     yy = yy < 0 ? 0 : (yy > T.S - 1 ? T.S - 1 : yy);
     cx = cx < 0 ? 0 : (cx > T.S - 1 ? T.S - 1 : cx);
     const float f = c32_gauss_exact<R>(Vp + r * NC + (cx - (x - 2 - R)), 1, w, 0, 2 * R);
-    const int yyt = yy - (T.ty0 - 2);
-    const double bl = (cx >= R && cx + R < T.S) ? sB[VH + yyt] : stp_bleed_h(sB[yyt], cx, T.S, R, w);
+    const double bv = stp_bleed_v(yy, T.S, R, w);
+    const double bl = stp_bleed_h(bv, (cx >= R && cx + R < T.S) ? R : cx, T.S, R, w);
     return (double)f / (bl + DBL_EPSILON);       // _canny.py:49
 }
 // magnitude (glibc hypot of the f64 Sobel sums) of pixel l = 3 * (dy + 1) + (dx + 1) of the 3 x 3 block around the

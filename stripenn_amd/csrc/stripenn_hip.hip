@@ -313,17 +313,16 @@ static __host__ __device__ size_t canny_pipe_smem_bytes(int R)
 }
 #define CANNY_PIPE_BITS_BYTES (2 * CT_Y * 8 + 16)   /* class bit-rows + the candidate count */
 
+// one tile of one (frame, level) pair, brightness images bi_lo .. bi_hi-1
 template <int RT>
-__global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
-                                                     int nf, int nlev, int nb, const double* __restrict__ gw,
-                                                     stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_fastdiv fd,
-                                                     const float2* __restrict__ cells /* null: no flat-window skip */)
+__device__ __forceinline__ void canny_pipe_tile(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
+                                                int nf, int nlev, int nb, const double* __restrict__ gw,
+                                                stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_fastdiv fd,
+                                                const float2* __restrict__ cells /* null: no flat-window skip */,
+                                                int pair, int tile, int bi_lo, int bi_hi)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int R = RT;
-    constexpr int TPI = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);   // 91
-    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-    const int pair = xcd + 8 * (j / TPI), tile = j % TPI;
     if (pair >= nf * nlev) return;
     const int fl = pair / nlev, lev = pair - fl * nlev;
     const int S = fS[f0 + fl];
@@ -383,7 +382,7 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
         if (nr * nc > 64) use_cells = false;
         else if (lane < nr * nc) { const int rr = lane / nc; cell_off = (r0 + rr) * GC_COLS + c0 + (lane - rr * nc); }
     }
-    for (int bi = 0; bi < nb; bi++) {
+    for (int bi = bi_lo; bi < bi_hi; bi++) {
         const size_t img = img0 + bi;
         const float* gimg = gray + img * (STP_PITCH * STP_PITCH);
         if (use_cells) {                             // every wave reads the same cells: the verdict is block-uniform
@@ -459,62 +458,109 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
     }
 }
 
+
+template <int RT>
+__global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
+                                                     int nf, int nlev, int nb, const double* __restrict__ gw,
+                                                     stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_fastdiv fd,
+                                                     const float2* __restrict__ cells)
+{
+    constexpr int TPI = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);   // 91
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    canny_pipe_tile<RT>(gray, fS, f0, nf, nlev, nb, gw, low, high, fd, cells, xcd + 8 * (j / TPI), j % TPI, 0, nb);
+}
+// The same arithmetic for FLAGGED (image, tile) pairs: the tile-images k_canny_f32 hands over because more of their
+// pixels were undecidable in f32 than its lists take (plateaus, exact ties).  xflags[image * 91 + tile] != 0 (image
+// counted within the launch); a fixed grid scans the flags.
+template <int RT>
+__global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe_list(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
+                                                     int nf, int nlev, int nb, const double* __restrict__ gw,
+                                                     stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_fastdiv fd,
+                                                     const uint8_t* __restrict__ xflags)
+{
+    constexpr int TPI = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);   // 91
+    const int n = nf * nlev * nb * TPI;
+    __shared__ stp_u64 sAny[4];
+    for (int k0 = blockIdx.x * 256; k0 < n; k0 += gridDim.x * 256) {     // 256 flags at a time
+        const int kk = k0 + (int)threadIdx.x;
+        const stp_u64 any = __ballot(kk < n && xflags[kk] != 0);
+        if ((threadIdx.x & 63) == 0) sAny[threadIdx.x >> 6] = any;
+        __syncthreads();
+        stp_u64 m[4] = {sAny[0], sAny[1], sAny[2], sAny[3]};
+        __syncthreads();
+        for (int w = 0; w < 4; w++)
+            while (m[w]) {                                               // workgroup-uniform
+                const int k = k0 + w * 64 + __builtin_ctzll(m[w]);
+                m[w] &= m[w] - 1;
+                const int img = k / TPI, tile = k - img * TPI;
+                canny_pipe_tile<RT>(gray, fS, f0, nf, nlev, nb, gw, low, high, fd, nullptr, img / nb, tile, img % nb, img % nb + 1);
+                __syncthreads();
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // k_canny_f32 (stp_canny32.h): the same tile / image loop as k_canny_pipe with every phase in f32, the class of a
 // candidate taken from the f32 values when the error budget allows it, and the reference's f64 arithmetic on the
 // 5 x 5 neighbourhood (one wave per pixel) when it does not.  Same class words as k_canny_pipe, bit for bit.
-__device__ __forceinline__ void canny32_collect(int tid, stp_cwin C, stp_p3walk W, float thr, const float* sS, float* sM,
-                                                uint16_t* sQ, int* sQn)
+// Magnitudes and candidate collection of one image: lane = tile column (magnitude columns 1 .. CT_X), each wave a strip
+// of the region's rows, walked top to bottom with the row terms of the two previous rows in registers (conflict-free
+// LDS reads: consecutive lanes, consecutive words); the two halo columns 0 and CT_X + 1 (neighbours only, never
+// candidates) pixel by pixel.  Candidates (magnitude >= thr inside the tile's candidate window) go to the
+// workgroup-wide queue: one ballot and one LDS atomic per row and wave.
+__device__ __forceinline__ void canny32_mag_rows(int tid, stp_cwin C, int my_lo, int nmh, int mx_lo, int nmw, float thr,
+                                                 const float* sS, float* sM, uint16_t* sQ, int* sQn)
 {
-    const int lane = tid & 63;
-    int r = W.r0, c = W.c0;
-    const int rounds = (W.n + 255) >> 8;                    // workgroup-uniform
-    const int soff = W.my_lo * C32_SP + W.mx_lo;
-    for (int k = 0; k < rounds; k++) {
-        const bool act = tid + 256 * k < W.n;
-        float m[4] = {0.f, 0.f, 0.f, 0.f};
-        int y = 0, x = 0;
-        if (act) {
-            y = 2 * r < W.nmh - 2 ? 2 * r : W.nmh - 2; x = 2 * c < W.nmw - 2 ? 2 * c : W.nmw - 2;
-            c32_sobel_blk2(sS + soff + y * C32_SP + x, m);
-            float* o = sM + W.moff + y * (CT_X + 2) + x;
-            o[0] = m[0]; o[1] = m[1]; o[CT_X + 2] = m[2]; o[CT_X + 3] = m[3];
-        }
-        const int Y = y + W.my_lo, X = x + W.mx_lo;
-        const bool r0 = act && (unsigned)(Y - C.y0) < (unsigned)C.ny && y == 2 * r, r1 = act && (unsigned)(Y + 1 - C.y0) < (unsigned)C.ny;
-        const bool c0 = (unsigned)(X - C.x0) < (unsigned)C.nx && x == 2 * c, c1 = (unsigned)(X + 1 - C.x0) < (unsigned)C.nx;
-        const bool q0 = r0 && c0 && m[0] >= thr, q1 = r0 && c1 && m[1] >= thr, q2 = r1 && c0 && m[2] >= thr, q3 = r1 && c1 && m[3] >= thr;
-        const stp_u64 b0 = __ballot(q0), b1 = __ballot(q1), b2 = __ballot(q2), b3 = __ballot(q3);
-        const int n0 = __popcll(b0), n1 = __popcll(b1), n2 = __popcll(b2), n3 = __popcll(b3);
-        if (n0 + n1 + n2 + n3) {                             // wave-uniform
+    const int wv = tid >> 6, lane = tid & 63, MW = CT_X + 2;
+    if (tid < 2 * nmh) {
+        const int col = tid >= nmh, X = col ? CT_X + 1 : 0, Y = my_lo + tid - col * nmh;
+        if (X >= mx_lo && X < mx_lo + nmw) sM[Y * MW + X] = c32_mag_px(sS, Y, X);
+    }
+    const int rows = (nmh + 3) >> 2, Y0 = my_lo + wv * rows, Y1 = min(Y0 + rows, my_lo + nmh);
+    if (Y0 >= Y1) return;                                    // wave-uniform
+    const int X = 1 + lane;
+    const bool colin = X >= mx_lo && X < mx_lo + nmw;
+    const bool xcand = (unsigned)(X - C.x0) < (unsigned)C.nx;
+    const float* sp = sS + Y0 * C32_SP + X;
+    float hd0, hd1, hs0, hs1;
+    c32_row_terms(sp, &hd0, &hs0);
+    c32_row_terms(sp + C32_SP, &hd1, &hs1);
+    const stp_u64 lt = (1ull << lane) - 1ull;
+    for (int Y = Y0; Y < Y1; Y++) {
+        float hd2, hs2;
+        c32_row_terms(sp + (Y - Y0 + 2) * C32_SP, &hd2, &hs2);
+        const float m = c32_mag(hd0, hd1, hd2, hs0, hs2);
+        if (colin) sM[Y * MW + X] = m;
+        const bool q = colin && xcand && (unsigned)(Y - C.y0) < (unsigned)C.ny && m >= thr;
+        const stp_u64 bq = __ballot(q);
+        if (bq) {                                            // wave-uniform
             int base = 0;
-            if (lane == 0) base = atomicAdd(sQn, n0 + n1 + n2 + n3);
+            if (lane == 0) base = atomicAdd(sQn, __popcll(bq));
             base = __shfl(base, 0);
-            const stp_u64 lt = (1ull << lane) - 1ull;
-            const int e = (Y - 1) * 64 + (X - 1);
-            if (q0) sQ[base + __popcll(b0 & lt)] = (uint16_t)e;
-            if (q1) sQ[base + n0 + __popcll(b1 & lt)] = (uint16_t)(e + 1);
-            if (q2) sQ[base + n0 + n1 + __popcll(b2 & lt)] = (uint16_t)(e + 64);
-            if (q3) sQ[base + n0 + n1 + n2 + __popcll(b3 & lt)] = (uint16_t)(e + 65);
+            if (q) sQ[base + __popcll(bq & lt)] = (uint16_t)((Y - 1) * 64 + (X - 1));
         }
-        c += W.dc; r += W.dr;
-        if (c >= W.nbw) { c -= W.nbw; r++; }
+        hd0 = hd1; hd1 = hd2; hs0 = hs1; hs1 = hs2;
     }
 }
+
+// Pixels the f32 class test cannot decide: a tile keeps them in a small LDS list (image << 11 | tile pixel) while it
+// walks its brightness images, and settles them when it is done -- one wave per pixel, the reference's arithmetic on
+// the 5 x 5 neighbourhood (c32_res_*) -- before it writes the class words of all its images.  An image that
+// overflows the list (plateaus, exact ties) is flagged instead and redone by k_canny_pipe_list.
 #define C32_NBMAX 8                  /* brightness images whose class words a workgroup keeps in LDS until its tile ends */
-#define C32_DCAP 192                 /* deferred (image, pixel) entries per tile; beyond it the image's pixels are settled at once */
+#define C32_DCAP 192                 /* undecidable pixels a tile keeps (all its images together) */
 __device__ __forceinline__ void canny32_nms_queue(int tid, int bi, stp_tile T, stp_c32tol E, const float* sS, const float* sM,
-                                                  uint16_t* sQ, int n, stp_u64* sBits, uint16_t* sD, int* sDn)
+                                                  const uint16_t* sQ, int n, stp_u64* sBits, uint16_t* sD, int* sDn, int* sOv)
 {
     stp_u64* lowB = sBits;
     stp_u64* highB = sBits + CT_Y;
     for (int k = tid; k < n; k += 256) {
         const int e = sQ[k], yy = e >> 6, xx = e & 63;
         const int cls = c32_nms(sS, sM, T, T.ty0 + yy, T.tx0 + xx, E);
-        if (cls == 3) {                                              // left to canny32_resolve: at the end of the tile ...
+        if (cls == 3) {
             const int slot = atomicAdd(sDn, 1);
             if (slot < C32_DCAP) sD[slot] = (uint16_t)(bi << 11 | e);
-            else sQ[k] = (uint16_t)(e | 0x8000);                      // ... or, the list being full, right after this image
+            else *sOv = 1;                                            // (benign race: every writer stores 1)
         } else if (cls >= 1) {
             atomicOr(&lowB[yy], 1ull << xx);
             if (cls == 2) atomicOr(&highB[yy], 1ull << xx);
@@ -523,15 +569,15 @@ __device__ __forceinline__ void canny32_nms_queue(int tid, int bi, stp_tile T, s
 }
 // one pixel, one wave: the 5 x (2R+5) vertical-pass values, the 5 x 5 smoothed values, nine magnitudes, the literal test
 template <int R>
-__device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, const double* sW, const double* sB,
-                                                const float* __restrict__ gimg, float* Vp, double* Sp, stp_u64* sBits)
+__device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, const double* sW, const float* __restrict__ gimg,
+                                                float* Vp, double* Sp, stp_u64* sBits)
 {
     constexpr int NV = 5 * (2 * R + 5);
     const int yy = e >> 6, xx = e & 63, y = T.ty0 + yy, x = T.tx0 + xx;
     for (int l = lane; l < NV; l += 64) Vp[l] = c32_res_V<R>(T, y, x, l, sW, gimg);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < 25) Sp[lane] = c32_res_S<R>(T, y, x, lane, sW, sB, Vp);
+    if (lane < 25) Sp[lane] = c32_res_S<R>(T, y, x, lane, sW, Vp);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     double* M9 = (double*)Vp;                    // the vertical-pass values are dead: nine magnitudes in their place
@@ -551,16 +597,17 @@ __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, con
 #define STP_C32_MINBLK 5
 #endif
 #define C32_QCAP (CT_X * CT_Y)       /* candidates of a tile: at most every pixel */
-struct stp_c32_layout { size_t sB, sRB, sRBB, sS, sV, sQ, sD, sBits, sQn, total; };
+#define C32_RES_WAVE_BYTES 768       /* per-wave resolver scratch inside the smoothed tile: 26 doubles, then 5 x (2R+5) floats (<= 125) */
+struct stp_c32_layout { size_t sRB, sRBB, sS, sV, sQ, sD, sBits, sQn, total; };
 static __host__ __device__ stp_c32_layout canny32_layout(int R)
 {
     const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
     stp_c32_layout L;
-    size_t o = 32 * sizeof(double);                          // sW
-    L.sB = o; o += 2 * VH * sizeof(double);
+    size_t o = 32 * sizeof(double);                          // sW: the f64 weights (bleed-over tables, resolver)
     L.sRB = o; o += (size_t)((VH + 1) & ~1) * sizeof(float);
     L.sRBB = o; o += (size_t)VH * 2 * R * sizeof(float);
-    L.sS = o; o += (size_t)VH * C32_SP * sizeof(float);      // smoothed tile | the resolver's per-wave scratch
+    L.sS = o; o += (size_t)VH * C32_SP * sizeof(float);      // smoothed tile (at start-up: the f64 bleed-over factors; at the
+                                                              // end: the resolver's per-wave scratch)
     L.sV = o;                                                 // vertical-pass tile | magnitude tile + candidate queue
     const size_t v = (size_t)(CT_P2_COLS(R) > GW ? CT_P2_COLS(R) : GW) * CT_VP * sizeof(float);
     const size_t mq = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(float);
@@ -573,13 +620,12 @@ static __host__ __device__ stp_c32_layout canny32_layout(int R)
     L.total = o;
     return L;
 }
-#define C32_RES_WAVE_BYTES 768       /* per-wave resolver scratch inside the smoothed tile: 26 doubles, then 5 x (2R+5) floats (<= 125) */
 
 template <int RT>
 __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
                                                     int nf, int nlev, int nb, const double* __restrict__ gw,
                                                     stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_w32 W32,
-                                                    const float2* __restrict__ cells)
+                                                    const float2* __restrict__ cells, uint8_t* __restrict__ xflags)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int R = RT;
@@ -595,43 +641,44 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     T.S = S; T.ty0 = (tile / tpr) * CT_Y; T.tx0 = (tile % tpr) * CT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
     const stp_c32_layout L = canny32_layout(R);
-    double* sW = (double*)smem;                   // f64 weights: the exact resolver and the bleed-over tables
-    double* sB = (double*)(smem + L.sB);
+    double* sW = (double*)smem;
     float* sRB = (float*)(smem + L.sRB);
     float* sRBB = (float*)(smem + L.sRBB);
     float* sS = (float*)(smem + L.sS);
     float* sV = (float*)(smem + L.sV);
     float* sM = sV;                               // magnitude tile over the dead vertical-pass buffer
     uint16_t* sQ = (uint16_t*)(smem + L.sQ);
-    uint16_t* sD = (uint16_t*)(smem + L.sD);      // deferred pixels: image << 11 | tile pixel
+    uint16_t* sD = (uint16_t*)(smem + L.sD);      // undecidable pixels of this tile: image << 11 | tile pixel
     stp_u64* sBits = (stp_u64*)(smem + L.sBits);  // class words of every image of this tile: [image][low | high][row]
     int* sQn = (int*)(smem + L.sQn);
     int* sDn = sQn + 1;
+    int* sOv = sQn + 2;
     const int tid = threadIdx.x, nt = blockDim.x, wv = tid >> 6, lane = tid & 63;
-    float* sVp = (float*)(smem + L.sS + wv * C32_RES_WAVE_BYTES + 26 * sizeof(double));     // (used only while sS is dead)
-    double* sSp = (double*)(smem + L.sS + wv * C32_RES_WAVE_BYTES);
     for (int i = tid; i < nb * 2 * CT_Y; i += nt) sBits[i] = 0ull;
-    if (tid == 64) { *sQn = 0; *sDn = 0; }
-    if (tid < 2 * R + 1) sW[tid] = gw[tid];
-    canny_p1b(tid, nt, T, R, gw, sB);
-    __syncthreads();
+    if (tid == 64) { *sQn = 0; *sDn = 0; *sOv = 0; }
     const bool yin = (T.ty0 - R - 2 >= 0) && (T.ty0 + CT_Y + R + 1 < S);
     const bool xin = (T.tx0 - 2 - R >= 0) && (T.tx0 + CT_X + 1 + R < S);
-    c32_rb_tables<R>(tid, nt, T, sW, sB, sRB, sRBB, xin);
-    __syncthreads();
+    {   // reciprocal bleed-over tables from the f64 factors, which live in the (still unused) smoothed tile meanwhile
+        double* sB = (double*)sS;
+        if (tid < 2 * R + 1) sW[tid] = gw[tid];
+        canny_p1b(tid, nt, T, R, gw, sB);
+        __syncthreads();
+        c32_rb_tables<R>(tid, nt, T, sW, sB, sRB, sRBB, xin);
+        __syncthreads();
+    }
     const size_t img0 = ((size_t)fl * nlev + lev) * nb;
     constexpr int GWc = CT_X + 2 * R + 4, NG1 = (CT_Y + 4) / ((R <= 8) ? CT_VRUN : CT_VRUN / 2);
     constexpr int NR1 = (GWc * NG1 + 255) / 256;
     constexpr int NR2 = ((CT_Y + 4) * ((CT_X + 4 + CT_HRUN_R(R) - 1) / CT_HRUN_R(R)) + 255) / 256;
     int it1[NR1], it2[NR2];
-    stp_p3walk W3;
+    struct { int my_lo, nmh, mx_lo, nmw; } G3;
     {
         const stp_cgeo G = ct_geo<R>(T);
 #pragma unroll
         for (int k = 0; k < NR1; k++) it1[k] = ct_p1_decode<R>(G, tid + 256 * k);
 #pragma unroll
         for (int k = 0; k < NR2; k++) it2[k] = ct_p2_decode<R>(G, tid + 256 * k);
-        W3 = ct_p3_walk(G, tid, 256);
+        G3.my_lo = G.my_lo; G3.nmh = G.nmh; G3.mx_lo = G.mx_lo; G3.nmw = (int)G.nmw.d;
     }
     const stp_cwin CW = canny_cand_window(T);
     int cell_off = -1;
@@ -643,10 +690,13 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         if (nr * nc > 64) use_cells = false;
         else if (lane < nr * nc) { const int rr = lane / nc; cell_off = (r0 + rr) * GC_COLS + c0 + (lane - rr * nc); }
     }
+    // (measured and dropped: requesting the next image's vertical-pass inputs right after the current image's vertical
+    //  pass -- 28 more live registers: 2.21 ms with spills at 5 waves per SIMD, 2.58 ms at 4, against 2.16 ms without;
+    //  settling the undecidable pixels in a kernel of their own from a global list -- 0.51 ms for it (cold grey rows,
+    //  bleed-over factors recomputed) against 0.25 ms in here, and 6 instead of 5 waves per SIMD bought this kernel nothing)
     for (int bi = 0; bi < nb; bi++) {
         const size_t img = img0 + bi;
         const float* gimg = gray + img * (STP_PITCH * STP_PITCH);
-        stp_u64* bits = sBits + bi * 2 * CT_Y;
         float gmax = 1.0000005f;                     // k_gray's grey values never exceed 0.299 + 0.587 + 0.114 (+ 3 roundings)
         if (use_cells) {
             float mn = INFINITY, mx = -INFINITY;
@@ -692,41 +742,33 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
             c32_p3_ring(tid, nt, T, sS);
             __syncthreads();
         }
-        canny32_collect(tid, CW, W3, E.thr, sS, sM, sQ, sQn);
+        canny32_mag_rows(tid, CW, G3.my_lo, G3.nmh, G3.mx_lo, G3.nmw, E.thr, sS, sM, sQ, sQn);
         __syncthreads();
 #if STP_ABLATE_C32 == 3                  /* ... after the magnitudes and the candidate collection ... */
         if (tid == 64) *sQn = 0;
         __syncthreads();
         continue;
 #endif
-        const int nq = *sQn;
-        canny32_nms_queue(tid, bi, T, E, sS, sM, sQ, nq, bits, sD, sDn);
+        canny32_nms_queue(tid, bi, T, E, sS, sM, sQ, *sQn, sBits + bi * 2 * CT_Y, sD, sDn, sOv);
         __syncthreads();     // sM / sQ alias sV: the class test must be done before the next vertical pass writes it
-        if (*sDn > C32_DCAP) {                       // (workgroup-uniform; rare: plateaus, ties) the list overflowed: this image's
-                                                     // remaining pixels are flagged in the queue -- settle them now, a wave per pixel
-#if STP_ABLATE_C32 != 4
-            for (int k0 = wv * 64; k0 < nq; k0 += 256) {
-                const int e = k0 + lane < nq ? sQ[k0 + lane] : 0;
-                stp_u64 todo = __ballot((e & 0x8000) != 0);
-                while (todo) {                                           // wave-uniform
-                    const int src = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    canny32_resolve<R>(T, __shfl(e, src) & 0x7FFF, lane, sW, sB, gimg, sVp, sSp, bits);
-                }
+        if (tid == 64) {
+            *sQn = 0;
+            if (*sOv) {                              // this image overflowed the tile's list: the whole tile-image is redone exactly
+                *sOv = 0;
+                *sDn = C32_DCAP;
+                xflags[img * TPI + tile] = 1;
             }
-#endif
-            __syncthreads();
-            if (tid == 64) *sDn = C32_DCAP;
         }
-        if (tid == 64) *sQn = 0;
     }
     __syncthreads();
-#if STP_ABLATE_C32 == 0
-    {                                                // the deferred pixels of all images of this tile, a wave per pixel
+#if STP_ABLATE_C32 == 0                  /* (4: ... or with the undecidable pixels left unsettled) */
+    {
         const int nd = min(*sDn, C32_DCAP);
-        for (int k = wv; k < nd; k += 4) {
+        float* sVp = (float*)(smem + L.sS + wv * C32_RES_WAVE_BYTES + 26 * sizeof(double));      // the smoothed tile is dead
+        double* sSp = (double*)(smem + L.sS + wv * C32_RES_WAVE_BYTES);
+        for (int k = wv; k < nd; k += 4) {           // wave-uniform
             const int d = sD[k], bi = d >> 11;
-            canny32_resolve<R>(T, d & 2047, lane, sW, sB, gray + (img0 + bi) * (STP_PITCH * STP_PITCH), sVp, sSp, sBits + bi * 2 * CT_Y);
+            canny32_resolve<R>(T, d & 2047, lane, sW, gray + (img0 + bi) * (STP_PITCH * STP_PITCH), sVp, sSp, sBits + bi * 2 * CT_Y);
         }
     }
     __syncthreads();
@@ -1128,7 +1170,7 @@ struct stp_pending {
     double bytes;
 };
 
-enum { WS_GRAY = 0, WS_LOW, WS_HIGH, WS_RECS, WS_CNT, WS_OUT, WS_TOTAL, WS_PARAMS, WS_EDGES, WS_CELLS, WS_NSLOTS };
+enum { WS_GRAY = 0, WS_LOW, WS_HIGH, WS_RECS, WS_CNT, WS_OUT, WS_TOTAL, WS_PARAMS, WS_EDGES, WS_CELLS, WS_C32Q, WS_NSLOTS };
 
 struct stp_ctx {
     int device = 0;
@@ -1746,13 +1788,24 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         if ((R == 8 || R == 10) && p_cells && nb <= C32_NBMAX && !canny_exact) {
             stp_w32 W32;
             for (int k = 0; k <= CT_RMAX; k++) W32.w[k] = k <= R ? (float)prm->gauss_w[k] : 0.0f;
-            const size_t smem = canny32_layout(R).total;
-            if (R == 8)
+            const size_t nflags = nimg * tiles;       // tile-images k_canny_f32 hands over to the exact kernel (see there)
+            void* p_x = nullptr;
+            HIPCHK(ws_get(ctx, WS_C32Q, nflags, &p_x));
+            HIPCHK(hipMemsetAsync(p_x, 0, nflags, ctx->stream));
+            const stp_fastdiv fd = make_fastdiv(ctx, prm->gauss_w, R);
+            const size_t smem = canny32_layout(R).total, smem_x = canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES;
+            const unsigned xgrid = (unsigned)std::min<size_t>(2048, (nflags + 255) / 256);
+            if (R == 8) {
                 hipLaunchKernelGGL(k_canny_f32<8>, dim3(pgrid), dim3(256), smem, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, d_w,
-                                   d_low, d_high, W32, (const float2*)p_cells);
-            else
+                                   d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x);
+                hipLaunchKernelGGL(k_canny_pipe_list<8>, dim3(xgrid), dim3(256), smem_x, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb,
+                                   d_w, d_low, d_high, fd, (const uint8_t*)p_x);
+            } else {
                 hipLaunchKernelGGL(k_canny_f32<10>, dim3(pgrid), dim3(256), smem, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, d_w,
-                                   d_low, d_high, W32, (const float2*)p_cells);
+                                   d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x);
+                hipLaunchKernelGGL(k_canny_pipe_list<10>, dim3(xgrid), dim3(256), smem_x, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb,
+                                   d_w, d_low, d_high, fd, (const uint8_t*)p_x);
+            }
             HIPCHK(hipGetLastError());
         } else {
         const stp_fastdiv fd = make_fastdiv(ctx, prm->gauss_w, R);

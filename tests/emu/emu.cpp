@@ -29,7 +29,7 @@ static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float g
     if (xin) c32_p2_blk<R, true>(0, 1, T, G, W, sV, sRB.data(), sRBB.data(), sS.data());
     else c32_p2_blk<R, false>(0, 1, T, G, W, sV, sRB.data(), sRBB.data(), sS.data());
     if (!(xin && yin)) c32_p3_ring(0, 1, T, sS.data());
-    c32_p3_walk(0, 1, ct_p3_walk(G, 0, 1), sS.data(), sM);
+    c32_p3_region(G, sS.data(), sM);
     const stp_c32tol E = c32_tol(gmax);
     constexpr int NV = 5 * (2 * R + 5);
     for (int i = 0; i < CT_Y * CT_X; i++) {
@@ -43,7 +43,7 @@ static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float g
                 float Vp[NV];
                 double Sp[25];
                 for (int l = 0; l < NV; l++) Vp[l] = c32_res_V<R>(T, y, x, l, w, gray);
-                for (int l = 0; l < 25; l++) Sp[l] = c32_res_S<R>(T, y, x, l, w, sB, Vp);
+                for (int l = 0; l < 25; l++) Sp[l] = c32_res_S<R>(T, y, x, l, w, Vp);
                 double M9[9];
                 for (int l = 0; l < 9; l++) M9[l] = c32_res_mag(Sp, l);
                 cls = c32_res_class(Sp, M9);
