@@ -386,19 +386,22 @@ def main():
             if k.get('valu_insts') is not None and k.get('image_px'):
                 per_px = k['valu_insts'] / k['image_px']
                 step_insts = per_px * image_px                      # wave-instructions of this kernel per step
+                # issue ceiling of the kernel's arithmetic: k_canny_f32 computes in f32 (one wave-instruction per 2 cycles and
+                # SIMD, MI355X_MICROARCH.md), the f64 kernels in FP64 (4 cycles)
+                cyc = 2 if (dom == 'canny' and os.environ.get('STP_CANNY') != 'exact') else 4
                 valu = {'kernel': 'k_' + dom, 'wave_insts_per_image_px': round(per_px, 3), 'lane_insts_per_image_px': round(per_px * 64, 1),
-                        'cycles_per_inst': 4, 'peak_wave_insts_per_s': N_SIMD * CLOCK_HZ / 4,
+                        'cycles_per_inst': cyc, 'peak_wave_insts_per_s': N_SIMD * CLOCK_HZ / cyc,
                         'achieved_wave_insts_per_s': round(step_insts / (d['ms'] / args.steps * 1e-3), 0),
-                        'frac': round(step_insts / (d['ms'] / args.steps * 1e-3) / (N_SIMD * CLOCK_HZ / 4), 4),
+                        'frac': round(step_insts / (d['ms'] / args.steps * 1e-3) / (N_SIMD * CLOCK_HZ / cyc), 4),
                         'source': pmc.get('tag')}
         roof = {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'traffic_source': (pmc.get('tag') if traffic is not None else
                                    ('stale: %s was collected on other kernel sources' % pmc.get('tag')) if pmc and not pmc_fresh else None),
-                'limiter': ('fp64_valu' if valu and valu['frac'] > ach / HBM_PEAK_GBS else 'hbm'),
+                'limiter': ('valu_issue' if valu and valu['frac'] > ach / HBM_PEAK_GBS else 'hbm'),
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4), 'launches_per_step': d['launches'] / args.steps,
                 'alg_bytes_per_launch': d['alg_bytes'] / d['launches'],
-                'fp64_valu': valu,
+                'valu_issue': valu,
                 'chain': {'kernels_ms_per_step': {k: round(v['ms'] / args.steps, 4) for k, v in stats.items()},
                           'alg_bytes_per_image_px': 26.0,
                           'achieved_GBs': round(26.0 * image_px * args.steps / (chain_ms * 1e-3) / 1e9, 1),
@@ -419,7 +422,11 @@ def main():
                                       'no collective on the data path',
                           'rank_ms_per_step': [round(t, 3) for t in rank_ms], 'setup_s': round(setup_s, 1),
                           'comm': comm, 'comm_note': comm_note, 'devices': devnames,
-                          'library': hip.LIB_PATH},
+                          'library': hip.LIB_PATH,
+                          'arithmetic': ('grey images, line joining, scoring: f64 as the reference; Canny classes: '
+                                         + ('f64 throughout (STP_CANNY=exact)' if os.environ.get('STP_CANNY') == 'exact' else
+                                            'f32 with a proven error budget, the undecidable pixels in the reference\'s f64 '
+                                            '(k_canny_f32) -- class maps identical to the f64 kernel and the oracle'))},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
             ci = min({u[0] for u in my_units}, key=lambda c: nbins[c])        # the smallest chromosome held here

@@ -139,7 +139,7 @@ STP_HD void c32_p2_item(stp_tile T, int yy, int xx0, const stp_w32& W, const flo
                         float* sS)
 {
     constexpr int HRUN = CT_HRUN_R(R);
-    const int SW = CT_X + 4;
+    static_assert(((CT_X + 4 + HRUN - 1) / HRUN) * HRUN <= C32_SP, "the last horizontal run must fit the row pitch");
     float win[HRUN + 2 * R];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -151,8 +151,8 @@ STP_HD void c32_p2_item(stp_tile T, int yy, int xx0, const stp_w32& W, const flo
 #pragma unroll
 #endif
     for (int q = 0; q < HRUN; q++) {
-        const int xx = xx0 + q;
-        if (xx >= SW) break;
+        const int xx = xx0 + q;                 // (the last run ends at column C32_SP - 1: its outputs beyond the CT_X + 4
+                                                //  columns of the tile land in the row's padding, which nothing reads)
         float a = win[q + R] * W.w[R];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll

@@ -1,0 +1,114 @@
+"""k_canny_f32 (f32 evaluation + proven error budget + exact resolution of the undecidable pixels) against
+k_canny_pipe (every intermediate in the reference's f64 arithmetic) and against the oracle: the class maps must be
+identical, image by image, and so must everything downstream.  STP_CANNY=exact selects the f64 kernel per call."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+class _exact_kernel:
+    def __enter__(self):
+        os.environ['STP_CANNY'] = 'exact'
+
+    def __exit__(self, *a):
+        os.environ.pop('STP_CANNY', None)
+
+
+def _band_of(dense, hw=512):
+    n = dense.shape[0]
+    band = np.zeros((n, 2 * hw))
+    for i in range(n):
+        lo, hi = max(0, i - hw), min(n, i + hw)
+        band[i, lo - i + hw:hi - i + hw] = dense[i, lo:hi]
+    return band
+
+
+def test_class_maps_of_both_kernels_and_the_oracle(hip_ctx):
+    """Synthetic frames (noisy, with planted stripes, NaN bins) at several maxpixel levels and both default sigmas:
+    class map of every brightness image, f32 kernel == f64 kernel == oracle."""
+    from stripenn_amd import synth, hip
+    ch = synth.SynthChrom(2600, 77, stripe_every=60, stripe_gain=3.0, nan_frac=0.01)
+    band = hip_ctx.band_upload(ch.band(512))
+    st = np.array([0, 300, 900, 1500, 2200]); en = st + 399
+    fr = band.frames(st, en)
+    blk = ch.block(0, 2600, 0, 2600)
+    Ms = np.quantile(blk[blk > 0], [0.9, 0.97, 0.995])
+    nimg = 0
+    for sigma in (2.0, 2.5):
+        gw, gr = hip.gauss_weights(sigma)
+        for f in range(len(st)):
+            D, nz = O.frame_dense(ch.block, int(st[f]), int(en[f]))
+            D = np.ascontiguousarray(D[np.ix_(nz, nz)])
+            for M in Ms:
+                gp = O.gplane(D, float(M))
+                for bi in range(6):
+                    a = fr.dbg_stages(f, float(M), bi, sigma=sigma)
+                    with _exact_kernel():
+                        b = fr.dbg_stages(f, float(M), bi, sigma=sigma)
+                    assert np.array_equal(a['cls'], b['cls']), (sigma, f, M, bi)
+                    assert np.array_equal(a['edges'], b['edges'])
+                    if bi in (0, 5) and f in (0, 3):
+                        _, dbg = O.canny(O.gray(gp, O.brightness_levels()[bi], 3), gw, gr, debug=True)
+                        assert np.array_equal(a['cls'], dbg['cls']), (sigma, f, M, bi)
+                    nimg += 1
+    assert nimg == 180
+    fr.close(); band.close()
+
+
+def test_adversarial_contact_maps(hip_ctx):
+    """Contact maps whose grey images sit on the decision boundaries: block structures (exact ties along straight edges:
+    every candidate is undecidable in f32 -> the per-tile list overflows -> k_canny_pipe_list redoes the tile-images),
+    ramps (magnitude near the thresholds), diagonal ramps (octant boundary), with and without noise."""
+    n = 800
+    rr, cc = np.mgrid[0:n, 0:n].astype(np.float64)
+    rng = np.random.default_rng(3)
+    cases = {
+        'blocks': np.where((cc // 37 + rr // 53) % 2 == 0, 12.0, 3.0) + np.where(np.abs(cc - rr) < 25, 20.0, 0.0),
+        'ramp': 2.0 + 0.11 * ((cc + 0.0 * rr) % 90),
+        'diag': 2.0 + 0.08 * ((cc + rr) % 120),
+        'ramp_noise': 2.0 + 0.11 * (cc % 90) + 1e-4 * rng.standard_normal((n, n)),
+        'stairs': 2.0 + 2.0 * ((cc // 16) % 5) + 1.0 * ((rr // 23) % 3),
+    }
+    for name, dense in cases.items():
+        dense = np.where(np.abs(cc - rr) <= 500, np.maximum(dense, 0.0), 0.0)
+        dense = (dense + dense.T) / 2
+        band = hip_ctx.band_upload(_band_of(dense))
+        fr = band.frames([0, 250], [399, 649])
+        for f, (s, e) in enumerate(((0, 399), (250, 649))):
+            D = np.ascontiguousarray(dense[s:e + 1, s:e + 1])
+            for M in (float(np.quantile(D[D > 0], 0.9)), float(D.max())):
+                gp = O.gplane(D, M)
+                for bi in (0, 3, 5):
+                    a = fr.dbg_stages(f, M, bi)
+                    with _exact_kernel():
+                        b = fr.dbg_stages(f, M, bi)
+                    assert np.array_equal(a['cls'], b['cls']), (name, f, M, bi)
+                    gw, gr = O.gauss_weights(2.0)
+                    _, dbg = O.canny(O.gray(gp, O.brightness_levels()[bi], 3), gw, gr, debug=True)
+                    assert np.array_equal(a['cls'], dbg['cls']), (name, f, M, bi)
+        fr.close(); band.close()
+
+
+def test_chromosome_sweep_records_identical_under_both_kernels(hip_ctx):
+    """The chr16-size five-level sweep: every stripe record (frame, level, brightness, direction, box, total)
+    identical whether the Canny stage ran in f32 or in f64."""
+    from stripenn_amd import synth
+    nb = 19642
+    ch = synth.SynthChrom(nb, 16)
+    band_h = ch.band(512)
+    band = hip_ctx.band_upload(band_h)
+    nfr = -(-nb // 200)
+    st = np.array([max(0, i * 200 - 100) for i in range(nfr)]); en = np.minimum((np.arange(nfr) + 1) * 200 + 99, nb - 1)
+    M = np.quantile(band_h[band_h > 0], [0.95, 0.96, 0.97, 0.98, 0.99])
+    fr = band.frames(st, en)
+    a = fr.stripe_search(M)
+    with _exact_kernel():
+        b = fr.stripe_search(M)
+    assert len(a) == len(b) > 10000
+    assert a.tobytes() == b.tobytes()
+    fr.close(); band.close()
