@@ -17,15 +17,16 @@
 //   horizontal pass   |Ha - Th(Va)| <= 10.01 u Th(Va), Th(|Va - V|) <= 11.01 u T2, |H - Th(V)| <= 1.001 u T2
 //                     (T2 the real 2-D sum):  |Ha - H| <= 22.1 u T2, and T2 <= g * bleed (the same weights summed
 //                     over the in-image taps), so |Ha - H| / bleed <= 22.1 u g at borders too.
-//   scaling           Sa = RN32(Ha * rb), rb = RN32(1 / (bleed + eps)): two more roundings:
-//                     E_S = |Sa - S| <= 24.2 u g   (the reference's f64 quotient adds 2^-53).           used: 25 u g
+//   scaling           Sa = RN32(Ha * rb), rb = RN32(1 / (bleed + eps)): two more roundings; in tiles with border columns
+//                     Sa = RN32(RN32(Ha * rv) * rc), 1 / bleed = (1 / column factor)(1 / row factor): four:
+//                     E_S = |Sa - S| <= 26.2 u g   (the reference's f64 quotient adds 2^-53).           used: 27 u g
 //   Sobel             row terms hd = RN32(s[x+1] - s[x-1]): 2 E_S + u g;  hs = RN32(2 s[x] + RN32(s[x-1] + s[x+1])):
 //                     4 E_S + 6 u g;  j = RN32(2 hd1 + RN32(hd0 + hd2)): 8 E_S + 10 u g;  i = RN32(hs2 - hs0):
 //                     8 E_S + 16 u g  (|i|, |j| <= 4 g; the reference's f64 Sobel adds ~2^-50).  The class test's own
-//                     Sobel sums (c32_sobel: differences first) stay below the same bound.   E_G <= 216 u g, used: 217
+//                     Sobel sums (c32_sobel: differences first) stay below the same bound.   E_G <= 232 u g, used: 233
 //   magnitude         |hypot(ia, ja) - hypot(i, j)| <= sqrt(2) E_G; f32 evaluation: fma + product (2 u of the sum of
 //                     squares -> u of the root) + v_sqrt_f32 (1 ulp <= 2 u): 3.1 u m, m <= 5.66 g:
-//                     E_M <= (306.9 + 17.6) u g                                                           used: 325 u g
+//                     E_M <= (329.6 + 17.6) u g                                                           used: 348 u g
 //   interpolation     w = num / den: |wa - w| <= 2 E_G / (den - E_G) + 4 u (v_rcp_f32 1 ulp + product);
 //                     l = c2 w + c1 (1 - w): |la - l| <= E_M + |wa - w| (|c2a - c1a| + 2 E_M) + 3 u max(c) (17 u g)
 //   A comparison l <= m is taken from the f32 values when |la - ma| > 2 E_M + 17 u g + |wa - w| (...); m >= 0.1 / 0.2
@@ -36,9 +37,9 @@
 #pragma once
 
 #define C32_SP (CT_X + 6)          /* pitch (floats) of the f32 smoothed tile: even (aligned pairs), 6 mod 64 banks per row */
-#define C32_EG_U 218.0f            /* bounds in units of u * g (rounded up; the products below add an absolute slack) */
-#define C32_EM_U 326.0f
-#define C32_T0_U 670.0f            /* 2 E_M + 17 */
+#define C32_EG_U 234.0f            /* bounds in units of u * g (rounded up; the products below add an absolute slack) */
+#define C32_EM_U 349.0f
+#define C32_T0_U 715.0f            /* 2 E_M + 17 */
 
 struct stp_w32 { float w[CT_RMAX + 1]; };     // RN32 of the Gaussian weights, w[R] the centre: a kernel argument (SGPRs)
 
@@ -116,27 +117,31 @@ STP_HD void c32_p1_blk(int tid, int nt, stp_tile T, stp_cgeo G, const stp_w32& W
     }
 }
 
-// reciprocal bleed-over tables (f32): sRB[yy] for an interior column of tile row yy, sRBB[yy * 2R + q] for the border
-// columns (q as in canny_p1c).  From the f64 factors the exact path uses; geometry only.
+// reciprocal bleed-over tables (f32), from the f64 factors the exact path uses; geometry only.
+//   sRB[yy]  = 1 / (bleed + eps) of an interior column of tile row yy (tiles without a border column use it alone);
+//   sRV[yy]  = 1 / column factor of the row,  sRC[xx] = 1 / row factor of tile column xx (0 outside the image):
+// the bleed-over of (row, column) is their product up to f64 roundings (stp_bleed_h scales the row sum by the column
+// factor; eps is 2^-52 of it), so border tiles scale by sRV * sRC without a test per output.
 template <int R>
-STP_HD void c32_rb_tables(int tid, int nt, stp_tile T, const double* w, const double* sB, float* sRB, float* sRBB, bool xin)
+STP_HD void c32_rb_tables(int tid, int nt, stp_tile T, const double* w, const double* sB, float* sRB, float* sRV, float* sRC,
+                          bool xin)
 {
     const int VH = CT_Y + 4;
-    for (int i = tid; i < VH; i += nt) sRB[i] = (float)(1.0 / (sB[VH + i] + DBL_EPSILON));
+    for (int i = tid; i < VH; i += nt) {
+        sRB[i] = (float)(1.0 / (sB[VH + i] + DBL_EPSILON));
+        sRV[i] = (float)(1.0 / sB[i]);                          // (rows outside the image: never used)
+    }
     if (xin) return;
-    for (int i = tid; i < VH * 2 * R; i += nt) {
-        const int yy = i / (2 * R), q = i - yy * (2 * R);
-        const int x = q < R ? q : T.S - R + (q - R);
-        float v = 0.0f;
-        if (x >= 0 && x < T.S) v = (float)(1.0 / (stp_bleed_h(sB[yy], x, T.S, R, w) + DBL_EPSILON));
-        sRBB[i] = v;
+    for (int i = tid; i < C32_SP; i += nt) {
+        const int x = T.tx0 - 2 + i;
+        sRC[i] = (x >= 0 && x < T.S) ? (float)(1.0 / stp_bleed_h(1.0, x, T.S, R, w)) : 0.0f;
     }
 }
 
 // ---- horizontal pass + scaling, one item (tile row yy, HRUN outputs from column xx0): as canny_p2_item ----
 template <int R, bool XIN>
-STP_HD void c32_p2_item(stp_tile T, int yy, int xx0, const stp_w32& W, const float* sVT, const float* sRB, const float* sRBB,
-                        float* sS)
+STP_HD void c32_p2_item(stp_tile T, int yy, int xx0, const stp_w32& W, const float* sVT, const float* sRB, const float* sRV,
+                        const float* sRC, float* sS)
 {
     constexpr int HRUN = CT_HRUN_R(R);
     static_assert(((CT_X + 4 + HRUN - 1) / HRUN) * HRUN <= C32_SP, "the last horizontal run must fit the row pitch");
@@ -145,43 +150,29 @@ STP_HD void c32_p2_item(stp_tile T, int yy, int xx0, const stp_w32& W, const flo
 #pragma unroll
 #endif
     for (int k = 0; k < HRUN + 2 * R; k++) win[k] = sVT[(xx0 + k) * CT_VP + yy];
-    const float rbi = sRB[yy];
+    const float rb = XIN ? sRB[yy] : sRV[yy];
     float* srow = sS + yy * C32_SP + xx0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int q = 0; q < HRUN; q++) {
-        const int xx = xx0 + q;                 // (the last run ends at column C32_SP - 1: its outputs beyond the CT_X + 4
+    for (int q = 0; q < HRUN; q++) {            // (the last run ends at column C32_SP - 1: its outputs beyond the CT_X + 4
                                                 //  columns of the tile land in the row's padding, which nothing reads)
         float a = win[q + R] * W.w[R];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
         for (int k = R; k >= 1; k--) a = fmaf(win[q + R - k] + win[q + R + k], W.w[R - k], a);
-        float s;
-        if (XIN) {
-            s = a * rbi;
-        } else {
-            const int x = T.tx0 - 2 + xx;
-            s = 0.0f;
-            if (x >= 0 && x < T.S) {
-                float rb = rbi;
-                if (x < R) rb = sRBB[yy * 2 * R + x];
-                else if (x + R >= T.S) rb = sRBB[yy * 2 * R + R + (x - (T.S - R))];
-                s = a * rb;
-            }
-        }
-        srow[q] = s;
+        srow[q] = XIN ? a * rb : (a * rb) * sRC[xx0 + q];       // columns outside the image: sRC = 0 (their sums are finite)
     }
 }
 template <int R, bool XIN>
 STP_HD void c32_p2_blk(int tid, int nt, stp_tile T, stp_cgeo G, const stp_w32& W, const float* sVT, const float* sRB,
-                       const float* sRBB, float* sS)
+                       const float* sRV, const float* sRC, float* sS)
 {
     for (int i = tid;; i += nt) {
         const int it = ct_p2_decode<R>(G, i);
         if (it < 0) break;
-        c32_p2_item<R, XIN>(T, it & 255, it >> 8, W, sVT, sRB, sRBB, sS);
+        c32_p2_item<R, XIN>(T, it & 255, it >> 8, W, sVT, sRB, sRV, sRC, sS);
     }
 }
 

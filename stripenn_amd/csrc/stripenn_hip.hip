@@ -598,14 +598,15 @@ __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, con
 #endif
 #define C32_QCAP (CT_X * CT_Y)       /* candidates of a tile: at most every pixel */
 #define C32_RES_WAVE_BYTES 768       /* per-wave resolver scratch inside the smoothed tile: 26 doubles, then 5 x (2R+5) floats (<= 125) */
-struct stp_c32_layout { size_t sRB, sRBB, sS, sV, sQ, sD, sBits, sQn, total; };
+struct stp_c32_layout { size_t sRB, sRV, sRC, sS, sV, sQ, sD, sBits, sQn, total; };
 static __host__ __device__ stp_c32_layout canny32_layout(int R)
 {
     const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
     stp_c32_layout L;
     size_t o = 32 * sizeof(double);                          // sW: the f64 weights (bleed-over tables, resolver)
     L.sRB = o; o += (size_t)((VH + 1) & ~1) * sizeof(float);
-    L.sRBB = o; o += (size_t)VH * 2 * R * sizeof(float);
+    L.sRV = o; o += (size_t)((VH + 1) & ~1) * sizeof(float);
+    L.sRC = o; o += (size_t)C32_SP * sizeof(float);
     L.sS = o; o += (size_t)VH * C32_SP * sizeof(float);      // smoothed tile (at start-up: the f64 bleed-over factors; at the
                                                               // end: the resolver's per-wave scratch)
     L.sV = o;                                                 // vertical-pass tile | magnitude tile + candidate queue
@@ -643,7 +644,8 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     const stp_c32_layout L = canny32_layout(R);
     double* sW = (double*)smem;
     float* sRB = (float*)(smem + L.sRB);
-    float* sRBB = (float*)(smem + L.sRBB);
+    float* sRV = (float*)(smem + L.sRV);
+    float* sRC = (float*)(smem + L.sRC);
     float* sS = (float*)(smem + L.sS);
     float* sV = (float*)(smem + L.sV);
     float* sM = sV;                               // magnitude tile over the dead vertical-pass buffer
@@ -663,7 +665,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         if (tid < 2 * R + 1) sW[tid] = gw[tid];
         canny_p1b(tid, nt, T, R, gw, sB);
         __syncthreads();
-        c32_rb_tables<R>(tid, nt, T, sW, sB, sRB, sRBB, xin);
+        c32_rb_tables<R>(tid, nt, T, sW, sB, sRB, sRV, sRC, xin);
         __syncthreads();
     }
     const size_t img0 = ((size_t)fl * nlev + lev) * nb;
@@ -692,6 +694,8 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     }
     // (measured and dropped: requesting the next image's vertical-pass inputs right after the current image's vertical
     //  pass -- 28 more live registers: 2.21 ms with spills at 5 waves per SIMD, 2.58 ms at 4, against 2.16 ms without;
+    //  the vertical pass on two columns per lane with packed f32 instructions -- half its VALU instructions, same time:
+    //  it waits for its loads, 0.79 ms of the kernel's 1.9 with the pass alone;
     //  settling the undecidable pixels in a kernel of their own from a global list -- 0.51 ms for it (cold grey rows,
     //  bleed-over factors recomputed) against 0.25 ms in here, and 6 instead of 5 waves per SIMD bought this kernel nothing)
     for (int bi = 0; bi < nb; bi++) {
@@ -728,8 +732,8 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
             int it = it2[k];
             asm volatile("" : "+v"(it));
             if (it >= 0) {
-                if (xin) c32_p2_item<R, true>(T, it & 255, it >> 8, W32, sV, sRB, sRBB, sS);
-                else c32_p2_item<R, false>(T, it & 255, it >> 8, W32, sV, sRB, sRBB, sS);
+                if (xin) c32_p2_item<R, true>(T, it & 255, it >> 8, W32, sV, sRB, sRV, sRC, sS);
+                else c32_p2_item<R, false>(T, it & 255, it >> 8, W32, sV, sRB, sRV, sRC, sS);
             }
         }
         __syncthreads();

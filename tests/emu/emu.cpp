@@ -19,15 +19,15 @@ static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float g
 {
     const int VH = CT_Y + 4;
     const float qnan = std::numeric_limits<float>::quiet_NaN();
-    std::vector<float> sS(VH * C32_SP, qnan), sRB(VH, qnan), sRBB(VH * 2 * R, qnan);
+    std::vector<float> sS(VH * C32_SP, qnan), sRB(VH, qnan), sRV(VH, qnan), sRC(C32_SP, qnan);
     stp_w32 W;
     for (int k = 0; k <= R; k++) W.w[k] = (float)w[k];
     const stp_cgeo G = ct_geo<R>(T);
-    c32_rb_tables<R>(0, 1, T, w, sB, sRB.data(), sRBB.data(), xin);
+    c32_rb_tables<R>(0, 1, T, w, sB, sRB.data(), sRV.data(), sRC.data(), xin);
     if (yin) c32_p1_blk<R, true>(0, 1, T, G, W, gray, sV);
     else c32_p1_blk<R, false>(0, 1, T, G, W, gray, sV);
-    if (xin) c32_p2_blk<R, true>(0, 1, T, G, W, sV, sRB.data(), sRBB.data(), sS.data());
-    else c32_p2_blk<R, false>(0, 1, T, G, W, sV, sRB.data(), sRBB.data(), sS.data());
+    if (xin) c32_p2_blk<R, true>(0, 1, T, G, W, sV, sRB.data(), sRV.data(), sRC.data(), sS.data());
+    else c32_p2_blk<R, false>(0, 1, T, G, W, sV, sRB.data(), sRV.data(), sRC.data(), sS.data());
     if (!(xin && yin)) c32_p3_ring(0, 1, T, sS.data());
     c32_p3_region(G, sS.data(), sM);
     const stp_c32tol E = c32_tol(gmax);
