@@ -506,10 +506,11 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe_list(const
 // Magnitudes and candidate collection of one image: lane = tile column (magnitude columns 1 .. CT_X), each wave a strip
 // of the region's rows, walked top to bottom with the row terms of the two previous rows in registers (conflict-free
 // LDS reads: consecutive lanes, consecutive words); the two halo columns 0 and CT_X + 1 (neighbours only, never
-// candidates) pixel by pixel.  Candidates (magnitude >= thr inside the tile's candidate window) go to the
-// workgroup-wide queue: one ballot and one LDS atomic per row and wave.
+// candidates) pixel by pixel.  Candidates (magnitude >= thr inside the tile's candidate window) go to the wave's own
+// segment of the queue -- its fill count is a wave-uniform register, so a row costs one ballot and no atomic.
+#define C32_QSEG (((CT_Y + 2 + 3) / 4) * 64)       /* candidates one wave can find: its rows x 64 columns */
 __device__ __forceinline__ void canny32_mag_rows(int tid, stp_cwin C, int my_lo, int nmh, int mx_lo, int nmw, float thr,
-                                                 const float* sS, float* sM, uint16_t* sQ, int* sQn)
+                                                 const float* sS, float* sM, uint16_t* sQ, int* sQcnt)
 {
     const int wv = tid >> 6, lane = tid & 63, MW = CT_X + 2;
     if (tid < 2 * nmh) {
@@ -517,30 +518,30 @@ __device__ __forceinline__ void canny32_mag_rows(int tid, stp_cwin C, int my_lo,
         if (X >= mx_lo && X < mx_lo + nmw) sM[Y * MW + X] = c32_mag_px(sS, Y, X);
     }
     const int rows = (nmh + 3) >> 2, Y0 = my_lo + wv * rows, Y1 = min(Y0 + rows, my_lo + nmh);
-    if (Y0 >= Y1) return;                                    // wave-uniform
-    const int X = 1 + lane;
-    const bool colin = X >= mx_lo && X < mx_lo + nmw;
-    const bool xcand = (unsigned)(X - C.x0) < (unsigned)C.nx;
-    const float* sp = sS + Y0 * C32_SP + X;
-    float hd0, hd1, hs0, hs1;
-    c32_row_terms(sp, &hd0, &hs0);
-    c32_row_terms(sp + C32_SP, &hd1, &hs1);
-    const stp_u64 lt = (1ull << lane) - 1ull;
-    for (int Y = Y0; Y < Y1; Y++) {
-        float hd2, hs2;
-        c32_row_terms(sp + (Y - Y0 + 2) * C32_SP, &hd2, &hs2);
-        const float m = c32_mag(hd0, hd1, hd2, hs0, hs2);
-        if (colin) sM[Y * MW + X] = m;
-        const bool q = colin && xcand && (unsigned)(Y - C.y0) < (unsigned)C.ny && m >= thr;
-        const stp_u64 bq = __ballot(q);
-        if (bq) {                                            // wave-uniform
-            int base = 0;
-            if (lane == 0) base = atomicAdd(sQn, __popcll(bq));
-            base = __shfl(base, 0);
-            if (q) sQ[base + __popcll(bq & lt)] = (uint16_t)((Y - 1) * 64 + (X - 1));
+    int cnt = 0;
+    if (Y0 < Y1) {                                           // wave-uniform
+        const int X = 1 + lane;
+        const bool colin = X >= mx_lo && X < mx_lo + nmw;
+        const bool xcand = colin && (unsigned)(X - C.x0) < (unsigned)C.nx;
+        const float* sp = sS + Y0 * C32_SP + X;
+        uint16_t* q = sQ + wv * C32_QSEG;
+        float hd0, hd1, hs0, hs1;
+        c32_row_terms(sp, &hd0, &hs0);
+        c32_row_terms(sp + C32_SP, &hd1, &hs1);
+        const stp_u64 lt = (1ull << lane) - 1ull;
+        for (int Y = Y0; Y < Y1; Y++) {
+            float hd2, hs2;
+            c32_row_terms(sp + (Y - Y0 + 2) * C32_SP, &hd2, &hs2);
+            const float m = c32_mag(hd0, hd1, hd2, hs0, hs2);
+            if (colin) sM[Y * MW + X] = m;
+            const bool isq = xcand && (unsigned)(Y - C.y0) < (unsigned)C.ny && m >= thr;
+            const stp_u64 bq = __ballot(isq);
+            if (isq) q[cnt + __popcll(bq & lt)] = (uint16_t)((Y - 1) * 64 + (X - 1));
+            cnt += __popcll(bq);
+            hd0 = hd1; hd1 = hd2; hs0 = hs1; hs1 = hs2;
         }
-        hd0 = hd1; hd1 = hd2; hs0 = hs1; hs1 = hs2;
     }
+    if (lane == 0) sQcnt[wv] = cnt;
 }
 
 // Pixels the f32 class test cannot decide: a tile keeps them in a small LDS list (image << 11 | tile pixel) while it
@@ -550,12 +551,15 @@ __device__ __forceinline__ void canny32_mag_rows(int tid, stp_cwin C, int my_lo,
 #define C32_NBMAX 8                  /* brightness images whose class words a workgroup keeps in LDS until its tile ends */
 #define C32_DCAP 192                 /* undecidable pixels a tile keeps (all its images together) */
 __device__ __forceinline__ void canny32_nms_queue(int tid, int bi, stp_tile T, stp_c32tol E, const float* sS, const float* sM,
-                                                  const uint16_t* sQ, int n, stp_u64* sBits, uint16_t* sD, int* sDn, int* sOv)
+                                                  const uint16_t* sQ, const int* sQcnt, stp_u64* sBits, uint16_t* sD, int* sDn, int* sOv)
 {
     stp_u64* lowB = sBits;
     stp_u64* highB = sBits + CT_Y;
-    for (int k = tid; k < n; k += 256) {
-        const int e = sQ[k], yy = e >> 6, xx = e & 63;
+    const int n0 = sQcnt[0], n1 = n0 + sQcnt[1], n2 = n1 + sQcnt[2], n = n2 + sQcnt[3];
+    for (int k = tid; k < n; k += 256) {                             // candidate k of the four wave segments, in order
+        const int seg = (k >= n0) + (k >= n1) + (k >= n2);
+        const int idx = k - (seg == 0 ? 0 : (seg == 1 ? n0 : (seg == 2 ? n1 : n2)));
+        const int e = sQ[seg * C32_QSEG + idx], yy = e >> 6, xx = e & 63;
         const int cls = c32_nms(sS, sM, T, T.ty0 + yy, T.tx0 + xx, E);
         if (cls == 3) {
             const int slot = atomicAdd(sDn, 1);
@@ -596,7 +600,6 @@ __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, con
 #ifndef STP_C32_MINBLK
 #define STP_C32_MINBLK 5
 #endif
-#define C32_QCAP (CT_X * CT_Y)       /* candidates of a tile: at most every pixel */
 #define C32_RES_WAVE_BYTES 768       /* per-wave resolver scratch inside the smoothed tile: 26 doubles, then 5 x (2R+5) floats (<= 125) */
 struct stp_c32_layout { size_t sRB, sRV, sRC, sS, sV, sQ, sD, sBits, sQn, total; };
 static __host__ __device__ stp_c32_layout canny32_layout(int R)
@@ -613,11 +616,11 @@ static __host__ __device__ stp_c32_layout canny32_layout(int R)
     const size_t v = (size_t)(CT_P2_COLS(R) > GW ? CT_P2_COLS(R) : GW) * CT_VP * sizeof(float);
     const size_t mq = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(float);
     L.sQ = o + mq;
-    const size_t m = mq + C32_QCAP * sizeof(uint16_t);
+    const size_t m = mq + 4 * C32_QSEG * sizeof(uint16_t);
     o += ((v > m ? v : m) + 7) & ~(size_t)7;
     L.sD = o; o += C32_DCAP * sizeof(uint16_t);
     L.sBits = o; o += (size_t)C32_NBMAX * 2 * CT_Y * sizeof(stp_u64);
-    L.sQn = o; o += 16;
+    L.sQn = o; o += 32;                                       // four segment fill counts, list length, overflow flag
     L.total = o;
     return L;
 }
@@ -652,12 +655,12 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     uint16_t* sQ = (uint16_t*)(smem + L.sQ);
     uint16_t* sD = (uint16_t*)(smem + L.sD);      // undecidable pixels of this tile: image << 11 | tile pixel
     stp_u64* sBits = (stp_u64*)(smem + L.sBits);  // class words of every image of this tile: [image][low | high][row]
-    int* sQn = (int*)(smem + L.sQn);
-    int* sDn = sQn + 1;
-    int* sOv = sQn + 2;
+    int* sQcnt = (int*)(smem + L.sQn);
+    int* sDn = sQcnt + 4;
+    int* sOv = sQcnt + 5;
     const int tid = threadIdx.x, nt = blockDim.x, wv = tid >> 6, lane = tid & 63;
     for (int i = tid; i < nb * 2 * CT_Y; i += nt) sBits[i] = 0ull;
-    if (tid == 64) { *sQn = 0; *sDn = 0; *sOv = 0; }
+    if (tid == 64) { *sDn = 0; *sOv = 0; }
     const bool yin = (T.ty0 - R - 2 >= 0) && (T.ty0 + CT_Y + R + 1 < S);
     const bool xin = (T.tx0 - 2 - R >= 0) && (T.tx0 + CT_X + 1 + R < S);
     {   // reciprocal bleed-over tables from the f64 factors, which live in the (still unused) smoothed tile meanwhile
@@ -746,17 +749,15 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
             c32_p3_ring(tid, nt, T, sS);
             __syncthreads();
         }
-        canny32_mag_rows(tid, CW, G3.my_lo, G3.nmh, G3.mx_lo, G3.nmw, E.thr, sS, sM, sQ, sQn);
+        canny32_mag_rows(tid, CW, G3.my_lo, G3.nmh, G3.mx_lo, G3.nmw, E.thr, sS, sM, sQ, sQcnt);
         __syncthreads();
 #if STP_ABLATE_C32 == 3                  /* ... after the magnitudes and the candidate collection ... */
-        if (tid == 64) *sQn = 0;
         __syncthreads();
         continue;
 #endif
-        canny32_nms_queue(tid, bi, T, E, sS, sM, sQ, *sQn, sBits + bi * 2 * CT_Y, sD, sDn, sOv);
+        canny32_nms_queue(tid, bi, T, E, sS, sM, sQ, sQcnt, sBits + bi * 2 * CT_Y, sD, sDn, sOv);
         __syncthreads();     // sM / sQ alias sV: the class test must be done before the next vertical pass writes it
         if (tid == 64) {
-            *sQn = 0;
             if (*sOv) {                              // this image overflowed the tile's list: the whole tile-image is redone exactly
                 *sOv = 0;
                 *sDn = C32_DCAP;
