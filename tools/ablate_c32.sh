@@ -17,7 +17,7 @@ import csv,glob
 acc={}
 for f in glob.glob('$R/gpurun_out/abl32_${l}_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'canny' in r['Kernel_Name']:
+        if 'k_canny_f32' in r['Kernel_Name'] or 'k_canny_pipe<' in r['Kernel_Name']:      # (not the list kernel's empty launches)
             k=r['Counter_Name']; a=acc.setdefault(k,[0,0.0]); a[0]+=1; a[1]+=float(r['Counter_Value'])
 print('$l', {k: round(v/n) for k,(n,v) in sorted(acc.items())})
 PY
