@@ -302,6 +302,8 @@ def main():
     tabs = {ci: frame_table(nbins[ci]) for ci in {u[0] for u in my_units}}
     setup_s = time.time() - t_setup
 
+    host_prof = [0.0]
+
     def launch(unit):
         """frame compaction + medpixel of one unit (small kernels on the context's auxiliary stream) and its whole
         StripeSearch chain enqueued on the main stream; returns without waiting for the chain"""
@@ -319,7 +321,9 @@ def main():
         flight = [launch(todo.pop()) for _ in range(min(2, len(todo)))]
         while flight:
             (ci, f0, f1), fr, pend = flight.pop(0)
+            tw = time.perf_counter()
             recs = pend.wait()
+            host_prof[0] += time.perf_counter() - tw           # time the host spent waiting for the device
             if todo:
                 flight.append(launch(todo.pop()))
             if not args.no_score:
@@ -350,6 +354,7 @@ def main():
     barrier()
     dt_rank = time.perf_counter() - t0
     stats = ctx.stats()
+    host_wait_ms = host_prof[0] / (args.steps + args.warmup) * 1e3      # (the warm-up steps count too: same work)
     dt, total_px, total_rec, rank_ms = dt_rank, contact_px, nrec, [dt_rank / args.steps * 1e3]
     if world > 1:
         tmax = torch.tensor([dt_rank], dtype=torch.float64, device=rdev)
@@ -421,6 +426,8 @@ def main():
                           'sharding': 'contiguous (chromosome x frame) spans of equal frame count, one process per GPU, '
                                       'no collective on the data path',
                           'rank_ms_per_step': [round(t, 3) for t in rank_ms], 'setup_s': round(setup_s, 1),
+                          'host_wait_ms_per_step': round(host_wait_ms, 2),      # of ms_per_step the host spent waiting for searches: the rest is host work the device may or may not hide
+
                           'comm': comm, 'comm_note': comm_note, 'devices': devnames,
                           'library': hip.LIB_PATH,
                           'arithmetic': ('grey images, line joining, scoring: f64 as the reference; Canny classes: '
