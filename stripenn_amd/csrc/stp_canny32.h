@@ -55,29 +55,62 @@ STP_HD stp_c32tol c32_tol(float gmax)
     return t;
 }
 
-// ---- vertical pass, one item (column xx of the tile window, VRUN output rows from yy0): as canny_p1_item ----
-// In two halves, so that k_canny_f32 can issue the loads of the NEXT image's item before the other phases of the
-// current one (the values arrive while those run): the VRUN + 2R grey values of the column ...
+// ---- vertical pass, one item = column xx of the tile window x C32_VRUN output rows from yy0 (as canny_p1_item, with
+// its own run length: f32 windows are half the registers of k_canny_pipe's f64 ones).  Numbering as ct_p1_decode:
+// in-image columns first, then one zero-fill item per (outside column, row group). ----
+#ifndef C32_VRUN
+#define C32_VRUN 12
+#endif
+struct stp_c32geo1 { int c_lo, ncv, nzc, ng; };
 template <int R>
-STP_HD void c32_p1_load(stp_tile T, int xx, int yy0, const float* __restrict__ gimg, float* raw)
+STP_HD stp_c32geo1 c32_geo1(stp_tile T)
 {
-    constexpr int VRUN = (R <= 8) ? CT_VRUN : CT_VRUN / 2;
+    const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
+    stp_c32geo1 g;
+    g.c_lo = R + 2 - T.tx0 > 0 ? R + 2 - T.tx0 : 0;
+    const int c_hi = T.S - T.tx0 + R + 2 < GW ? T.S - T.tx0 + R + 2 : GW;
+    g.ncv = c_hi - g.c_lo;
+    g.nzc = GW - g.ncv;
+    const int yy_hi = T.S - T.ty0 + 2 < VH ? T.S - T.ty0 + 2 : VH;
+    g.ng = (yy_hi + C32_VRUN - 1) / C32_VRUN;
+    return g;
+}
+// returns xx | yy0 << 8 | zero << 16, or -1 past the last item
+STP_HD int c32_p1_decode(stp_c32geo1 G, int i)
+{
+    const int nval = G.ncv * G.ng, nzero = G.nzc * G.ng;
+    if (i < nval) {
+        const int yg = i / G.ncv;
+        return (G.c_lo + (i - yg * G.ncv)) | (yg * C32_VRUN) << 8;
+    }
+    if (i < nval + nzero) {
+        const int j = i - nval, yg = j / G.nzc, zc = j - yg * G.nzc;
+        return (zc < G.c_lo ? zc : zc + G.ncv) | (yg * C32_VRUN) << 8 | 1 << 16;
+    }
+    return -1;
+}
+STP_HD void c32_p1_zero(int xx, int yy0, float* sVT)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int q = 0; q < C32_VRUN; q++) sVT[xx * CT_VP + yy0 + q] = 0.0f;
+}
+template <int R, bool YIN>
+STP_HD void c32_p1_item(stp_tile T, int xx, int yy0, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
+{
+    constexpr int N = C32_VRUN + 2 * R;
+    float raw[N];
     const float* col = gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + (T.tx0 - R - 2 + xx);    // guard bytes around the grey images: see canny_p1_item
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int k = 0; k < VRUN + 2 * R; k++) raw[k] = col[k * STP_PITCH];
-}
-// ... and the VRUN filtered values from them
-template <int R, bool YIN>
-STP_HD void c32_p1_compute(stp_tile T, int xx, int yy0, const stp_w32& W, float* raw, float* sVT)
-{
-    constexpr int VRUN = (R <= 8) ? CT_VRUN : CT_VRUN / 2;
+    for (int k = 0; k < N; k++) raw[k] = col[k * STP_PITCH];
     if (!YIN) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-        for (int k = 0; k < VRUN + 2 * R; k++) {
+        for (int k = 0; k < N; k++) {
             const int y = T.ty0 - R - 2 + yy0 + k;
             if ((unsigned)y >= (unsigned)T.S) raw[k] = 0.0f;
         }
@@ -85,7 +118,7 @@ STP_HD void c32_p1_compute(stp_tile T, int xx, int yy0, const stp_w32& W, float*
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int q = 0; q < VRUN; q++) {
+    for (int q = 0; q < C32_VRUN; q++) {
         float a = raw[q + R] * W.w[R];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -99,20 +132,13 @@ STP_HD void c32_p1_compute(stp_tile T, int xx, int yy0, const stp_w32& W, float*
     }
 }
 template <int R, bool YIN>
-STP_HD void c32_p1_item(stp_tile T, int xx, int yy0, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
+STP_HD void c32_p1_blk(int tid, int nt, stp_tile T, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
 {
-    constexpr int VRUN = (R <= 8) ? CT_VRUN : CT_VRUN / 2;
-    float raw[VRUN + 2 * R];
-    c32_p1_load<R>(T, xx, yy0, gimg, raw);
-    c32_p1_compute<R, YIN>(T, xx, yy0, W, raw, sVT);
-}
-template <int R, bool YIN>
-STP_HD void c32_p1_blk(int tid, int nt, stp_tile T, stp_cgeo G, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
-{
+    const stp_c32geo1 G = c32_geo1<R>(T);
     for (int i = tid;; i += nt) {
-        const int it = ct_p1_decode<R>(G, i);
+        const int it = c32_p1_decode(G, i);
         if (it < 0) break;
-        if (it >> 16) canny_p1_zero<R>(it & 255, (it >> 8) & 255, sVT);
+        if (it >> 16) c32_p1_zero(it & 255, (it >> 8) & 255, sVT);
         else c32_p1_item<R, YIN>(T, it & 255, (it >> 8) & 255, W, gimg, sVT);
     }
 }

@@ -672,15 +672,16 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         __syncthreads();
     }
     const size_t img0 = ((size_t)fl * nlev + lev) * nb;
-    constexpr int GWc = CT_X + 2 * R + 4, NG1 = (CT_Y + 4) / ((R <= 8) ? CT_VRUN : CT_VRUN / 2);
-    constexpr int NR1 = (GWc * NG1 + 255) / 256;
+    static_assert((CT_Y + 4) % C32_VRUN == 0, "whole row groups");
+    constexpr int NR1 = ((CT_X + 2 * R + 4) * ((CT_Y + 4) / C32_VRUN) + 255) / 256;
     constexpr int NR2 = ((CT_Y + 4) * ((CT_X + 4 + CT_HRUN_R(R) - 1) / CT_HRUN_R(R)) + 255) / 256;
     int it1[NR1], it2[NR2];
     struct { int my_lo, nmh, mx_lo, nmw; } G3;
     {
         const stp_cgeo G = ct_geo<R>(T);
+        const stp_c32geo1 G1 = c32_geo1<R>(T);
 #pragma unroll
-        for (int k = 0; k < NR1; k++) it1[k] = ct_p1_decode<R>(G, tid + 256 * k);
+        for (int k = 0; k < NR1; k++) it1[k] = c32_p1_decode(G1, tid + 256 * k);
 #pragma unroll
         for (int k = 0; k < NR2; k++) it2[k] = ct_p2_decode<R>(G, tid + 256 * k);
         G3.my_lo = G.my_lo; G3.nmh = G.nmh; G3.mx_lo = G.mx_lo; G3.nmw = (int)G.nmw.d;
@@ -697,6 +698,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     }
     // (measured and dropped: requesting the next image's vertical-pass inputs right after the current image's vertical
     //  pass -- 28 more live registers: 2.21 ms with spills at 5 waves per SIMD, 2.58 ms at 4, against 2.16 ms without;
+    //  18 instead of 12 output rows per vertical-pass item (19 % fewer row loads, 168 instead of 252 items): 1.96 vs 1.88 ms;
     //  the vertical pass on two columns per lane with packed f32 instructions -- half its VALU instructions, same time:
     //  it waits for its loads, 0.79 ms of the kernel's 1.9 with the pass alone;
     //  settling the undecidable pixels in a kernel of their own from a global list -- 0.51 ms for it (cold grey rows,
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
             int it = it1[k];
             asm volatile("" : "+v"(it));              // see k_canny_pipe
             if (it >= 0) {
-                if (it >> 16) canny_p1_zero<R>(it & 255, (it >> 8) & 255, sV);
+                if (it >> 16) c32_p1_zero(it & 255, (it >> 8) & 255, sV);
                 else if (yin) c32_p1_item<R, true>(T, it & 255, (it >> 8) & 255, W32, gimg, sV);
                 else c32_p1_item<R, false>(T, it & 255, (it >> 8) & 255, W32, gimg, sV);
             }

@@ -24,8 +24,8 @@ static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float g
     for (int k = 0; k <= R; k++) W.w[k] = (float)w[k];
     const stp_cgeo G = ct_geo<R>(T);
     c32_rb_tables<R>(0, 1, T, w, sB, sRB.data(), sRV.data(), sRC.data(), xin);
-    if (yin) c32_p1_blk<R, true>(0, 1, T, G, W, gray, sV);
-    else c32_p1_blk<R, false>(0, 1, T, G, W, gray, sV);
+    if (yin) c32_p1_blk<R, true>(0, 1, T, W, gray, sV);
+    else c32_p1_blk<R, false>(0, 1, T, W, gray, sV);
     if (xin) c32_p2_blk<R, true>(0, 1, T, G, W, sV, sRB.data(), sRV.data(), sRC.data(), sS.data());
     else c32_p2_blk<R, false>(0, 1, T, G, W, sV, sRB.data(), sRV.data(), sRC.data(), sS.data());
     if (!(xin && yin)) c32_p3_ring(0, 1, T, sS.data());
