@@ -33,7 +33,7 @@
 //   when |ma - thr| > E_M; the sector (signs of i, j and |i| vs |j|) when |ia|, |ja| > E_G and ||ia| - |ja|| > 2 E_G.
 //   Everything else ("uncertain": ~1e-4 of the pixels of noisy data, every edge pixel of a synthetic step) is
 //   resolved by c32_res_*: the reference's arithmetic on the 5 x 5 smoothed values around the pixel, recomputed
-//   from the grey image in the exact order (stp_gauss_exact), glibc's hypot, the literal tests.
+//   from the grey image in the exact order (c32_gauss_exact), glibc's hypot, the literal tests.
 #pragma once
 
 #define C32_SP (CT_X + 6)          /* pitch (floats) of the f32 smoothed tile: even (aligned pairs), 6 mod 64 banks per row */

@@ -35,7 +35,8 @@ typedef unsigned long long stp_u64;
 #define CT_Y 32
 #define CT_X 64
 #define CT_RMAX 12
-#define CT_SP (CT_X + 5) /* pitch (doubles) of the smoothed tile: odd -> few LDS write conflicts */
+#define CT_SP (CT_X + 7) /* pitch (doubles) of the smoothed tile: odd -> few LDS write conflicts; >= the 70 columns the
+                            horizontal pass's whole runs write (the last run ends in the padding) */
 #define CT_VP (CT_Y + 5) /* pitch (floats) of the transposed vertical-pass tile */
 
 struct stp_tile {
@@ -533,7 +534,8 @@ STP_HD void canny_p2_item(stp_tile T, int yy, int xx0, const double* w, const fl
                           const double* sBB, double* sS, stp_fastdiv fd)
 {
     constexpr int HRUN = CT_HRUN_R(R);
-    const int VH = CT_Y + 4, SW = CT_X + 4;
+    static_assert(((CT_X + 4 + HRUN - 1) / HRUN) * HRUN <= CT_SP, "the last horizontal run must fit the row pitch");
+    const int VH = CT_Y + 4;
     double win[HRUN + 2 * R];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -558,9 +560,8 @@ STP_HD void canny_p2_item(stp_tile T, int yy, int xx0, const double* w, const fl
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int q = 0; q < HRUN; q++) {
-        const int xx = xx0 + q;
-        if (xx >= SW) break;
+    for (int q = 0; q < HRUN; q++) {            // (no test for the last run's outputs beyond the tile's CT_X + 4 columns: they land in
+        const int xx = xx0 + q;                 //  the row's padding, which nothing reads -- a test here keeps the loop from being unrolled)
         const float f = fv[q];
         double s;
         if (fast) {
