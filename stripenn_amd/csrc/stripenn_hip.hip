@@ -1440,6 +1440,30 @@ static int check_hw(stp_ctx* ctx, int64_t nrows, int32_t hw)
     return STP_OK;
 }
 
+// The caller's (pageable) host array pinned in place for the duration of one call: the copies out of it then run as DMA at
+// PCIe speed (57 GB/s measured on the MI355X box) instead of through the runtime's staging copies (11-20 GB/s);
+// registering 2 GiB of touched pages takes 17 ms.  Failing to register (range already registered, overlapping pages,
+// STP_NO_PIN=1) is not an error: the copies fall back to the pageable path.  The stream is drained before the range
+// is released.
+struct host_pin {
+    void* p = nullptr;
+    hipStream_t st = nullptr;
+    void pin(const void* ptr, size_t bytes, hipStream_t stream)
+    {
+        static const bool off = getenv("STP_NO_PIN") != nullptr;
+        st = stream;
+        if (off || !ptr || bytes < ((size_t)1 << 20)) return;
+        if (hipHostRegister((void*)ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = (void*)ptr;
+        else (void)hipGetLastError();                       // clear the sticky error: pageable copies from here on
+    }
+    ~host_pin()
+    {
+        if (!p) return;
+        (void)hipStreamSynchronize(st);
+        if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+    }
+};
+
 int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_t hw, stp_band** out)
 {
     if (!ctx || !band_host || !out) return STP_E_ARG;
@@ -1453,8 +1477,12 @@ int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_
     size_t bytes = (size_t)nrows * b->W * sizeof(double);
     hipError_t e = hipMalloc((void**)&d, bytes);
     if (e != hipSuccess) { delete b; return set_err(ctx, STP_E_NOMEM, "hipMalloc(band) failed"); }
-    e = hipMemcpyAsync(d, band_host, bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    {
+        host_pin pin;
+        pin.pin(band_host, bytes, ctx->stream);
+        e = hipMemcpyAsync(d, band_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
     if (e != hipSuccess) { (void)hipFree(d); delete b; return set_err(ctx, STP_E_HIP, "band upload failed"); }
     b->d = d;
     *out = b;
@@ -1628,10 +1656,14 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
     if (hipMalloc((void**)&d, bytes) != hipSuccess) { delete b; return set_err(ctx, STP_E_NOMEM, "hipMalloc(band) failed"); }
     // (measured and dropped in round 3: two pinned staging sets filled by eight host threads, 40 MB pieces, DMA of piece
     //  k beside the host copy of piece k + 1 -- 0.34 s for the 5.3 GB of the mm10-size table against 0.26 s for the
-    //  runtime's own pageable path below, which already pipelines its staging)
+    //  runtime's own pageable path; what does pay is pinning the caller's columns IN PLACE for the call: host_pin)
     const int64_t CH = (int64_t)1 << 23;                 // pixels per staged chunk (160 MB of table columns)
     const int64_t nch = npix < CH ? npix : CH;
     dev_buf b1, b2, bc, bw;
+    host_pin pin1, pin2, pinc;                            // (declared after the device buffers: released first)
+    pin1.pin(bin1, (size_t)npix * sizeof(int64_t), ctx->io);
+    pin2.pin(bin2, (size_t)npix * sizeof(int64_t), ctx->io);
+    pinc.pin(count, (size_t)npix * csz, ctx->io);
     int32_t* near = nullptr;
     if (hipMalloc((void**)&near, (size_t)nrows * 2 * sizeof(int32_t)) != hipSuccess) {
         (void)hipFree(d); delete b;
@@ -2491,6 +2523,10 @@ int stp_select_append_pixels_ex(stp_ctx* ctx, stp_select* s, const int64_t* bin1
     const int64_t CH = (int64_t)1 << 23;                 // pixels per staged chunk
     const int64_t nch = npix < CH ? npix : CH;
     dev_buf d1, d2, dc, dw;
+    host_pin pin1, pin2, pinc;
+    pin1.pin(bin1, (size_t)npix * sizeof(int64_t), ctx->io);
+    pin2.pin(bin2, (size_t)npix * sizeof(int64_t), ctx->io);
+    pinc.pin(count, (size_t)npix * csz, ctx->io);
     HIPCHK(d1.alloc(ctx, (size_t)nch * sizeof(int64_t)));
     HIPCHK(d2.alloc(ctx, (size_t)nch * sizeof(int64_t)));
     HIPCHK(dc.alloc(ctx, (size_t)nch * csz));
