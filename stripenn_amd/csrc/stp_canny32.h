@@ -31,29 +31,75 @@
 //                     l = c2 w + c1 (1 - w): |la - l| <= E_M + |wa - w| (|c2a - c1a| + 2 E_M) + 3 u max(c) (17 u g)
 //   A comparison l <= m is taken from the f32 values when |la - ma| > 2 E_M + 17 u g + |wa - w| (...); m >= 0.1 / 0.2
 //   when |ma - thr| > E_M; the sector (signs of i, j and |i| vs |j|) when |ia|, |ja| > E_G and ||ia| - |ja|| > 2 E_G.
+//   A second budget, absolute in g instead of relative to the local sums, is much tighter for the tile-wide scale: the
+//   accumulation roundings of a pass are bounded by u times the PARTIAL sums, and with inputs <= g the partial sum after
+//   a step is at most g times the weights added so far -- the centre tap and the far (tiny) taps first, so the
+//   partial sums stay near 0.2 g for most of the chain.  Per pass, with W the sum of the in-range weights and P_k
+//   the in-range weight added up to step k:  |Va - V| <= u g (3 W + sum_k P_k)  (weights, pair sums and the centre
+//   product: 2 W; the reference's own rounding: W).  For the two passes and the scaling by 1 / bleed = 1 / (Wy Wx):
+//   E_S <= u g (rho_y + rho_x + 2.1 [4.2 with the two-factor scaling of border tiles]), rho = 3 + sum_k P_k / W:
+//   6.2 for a full window at sigma 2 (E_S = 14.4 u g instead of 27), at most ~7.1 for a window cut by the image
+//   border on one side (c32_budget computes rho for every cut of the actual weights; a window cut on both sides --
+//   an image narrower than 2R+1 -- can reach 11).  The tile-wide look uses this budget (interior tiles: full windows;
+//   border tiles: the worst one-sided cut, or the worst cut of all for such small images), the per-pixel second look
+//   the relative one above.
 //   Everything else ("uncertain": ~1e-4 of the pixels of noisy data, every edge pixel of a synthetic step) is
 //   resolved by c32_res_*: the reference's arithmetic on the 5 x 5 smoothed values around the pixel, recomputed
 //   from the grey image in the exact order (c32_gauss_exact), glibc's hypot, the literal tests.
 #pragma once
 
 #define C32_SP (CT_X + 6)          /* pitch (floats) of the f32 smoothed tile: even (aligned pairs), 6 mod 64 banks per row */
-#define C32_EG_U 234.0f            /* bounds in units of u * g (rounded up; the products below add an absolute slack) */
+#define C32_EG_U 234.0f            /* the relative budget (g = local scale), in units of u * g, rounded up */
 #define C32_EM_U 349.0f
 #define C32_T0_U 715.0f            /* 2 E_M + 17 */
 
-struct stp_w32 { float w[CT_RMAX + 1]; };     // RN32 of the Gaussian weights, w[R] the centre: a kernel argument (SGPRs)
+// kernel arguments (SGPRs): RN32 of the Gaussian weights, w[R] the centre; the tile-wide budget (E_G, E_M, T0 in units
+// of u * g) for interior tiles [0], for tiles whose windows the image border cuts on ONE side at most (every tile of an
+// image of at least 2R+1 pixels) [1], and for any cut [2] (c32_budget)
+struct stp_w32 { float w[CT_RMAX + 1]; float eu[3][3]; };
+
+// rho = 3 + sum_k P_k / W of one pass for the window cut to taps lo .. hi (-R <= lo <= 0 <= hi <= R), see above
+STP_HD double c32_rho(const double* w /* w[R] = centre */, int R, int lo, int hi)
+{
+    double W = w[R], P = w[R], sumP = 0.0;
+    for (int k = R; k >= 1; k--) {
+        const double add = (-k >= lo ? w[R - k] : 0.0) + (k <= hi ? w[R - k] : 0.0);
+        P += add; W += add;
+        sumP += P;                                     // (a step that adds nothing rounds nothing: counted anyway)
+    }
+    return 3.0 + sumP / W;
+}
+STP_HD void c32_budget(const double* w, int R, stp_w32* out)
+{
+    const double rho_int = c32_rho(w, R, -R, R);
+    double rho_one = rho_int, rho_any = rho_int;
+    for (int lo = -R; lo <= 0; lo++)
+        for (int hi = 0; hi <= R; hi++) {
+            const double r = c32_rho(w, R, lo, hi);
+            rho_any = r > rho_any ? r : rho_any;
+            if (lo == -R || hi == R) rho_one = r > rho_one ? r : rho_one;
+        }
+    const double es[3] = {(2.0 * rho_int + 2.1) * 1.0001, (2.0 * rho_one + 4.2) * 1.0001, (2.0 * rho_any + 4.2) * 1.0001};   // (1 + 12 u), f64 slack
+    for (int t = 0; t < 3; t++) {
+        const double eg = 8.0 * es[t] + 16.1, em = 1.41422 * eg + 17.7, t0 = 2.0 * em + 17.1;
+        out->eu[t][0] = (float)(eg * 1.000001); out->eu[t][1] = (float)(em * 1.000001); out->eu[t][2] = (float)(t0 * 1.000001);
+    }
+}
+// which of the three a tile uses
+STP_HD int c32_budget_of(bool interior, int S, int R) { return interior ? 0 : (S >= 2 * R + 1 ? 1 : 2); }
 
 struct stp_c32tol { float Eg, Em, T0, thr; };
-STP_HD stp_c32tol c32_tol(float gmax)
+STP_HD stp_c32tol c32_tol_u(float gmax, float eg_u, float em_u, float t0_u)
 {
     stp_c32tol t;
     const float su = gmax * 5.9604644775390625e-08f;      // g * 2^-24 (exact scaling)
-    t.Eg = fmaf(C32_EG_U, su, 1e-8f);
-    t.Em = fmaf(C32_EM_U, su, 2e-8f);                      // the slack also covers 0.1f / 0.2f vs the f64 thresholds (< 3e-9)
-    t.T0 = fmaf(C32_T0_U, su, 4e-8f);
+    t.Eg = fmaf(eg_u, su, 1e-8f);
+    t.Em = fmaf(em_u, su, 2e-8f);                          // the slack also covers 0.1f / 0.2f vs the f64 thresholds (< 3e-9)
+    t.T0 = fmaf(t0_u, su, 4e-8f);
     t.thr = 0.1f - t.Em - 1e-8f;                           // below it the exact magnitude is < 0.1: no class
     return t;
 }
+STP_HD stp_c32tol c32_tol(float gmax) { return c32_tol_u(gmax, C32_EG_U, C32_EM_U, C32_T0_U); }      // the relative budget
 
 // ---- vertical pass, one item = column xx of the tile window x C32_VRUN output rows from yy0 (as canny_p1_item, with
 // its own run length: f32 windows are half the registers of k_canny_pipe's f64 ones).  Numbering as ct_p1_decode:

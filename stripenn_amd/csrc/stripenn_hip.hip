@@ -715,7 +715,8 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
             if (mx - mn < STP_FLAT_RANGE) continue;  // flat window: no pixel of this tile can reach the low threshold (words stay 0)
             gmax = mx;
         }
-        const stp_c32tol E = c32_tol(gmax);
+        const int et = c32_budget_of(xin && yin, S, R);  // tile-wide budget: full windows everywhere, or the worst cut
+        const stp_c32tol E = c32_tol_u(gmax, W32.eu[et][0], W32.eu[et][1], W32.eu[et][2]);
 #pragma unroll
         for (int k = 0; k < NR1; k++) {
             int it = it1[k];
@@ -1828,6 +1829,7 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         if ((R == 8 || R == 10) && p_cells && nb <= C32_NBMAX && !canny_exact) {
             stp_w32 W32;
             for (int k = 0; k <= CT_RMAX; k++) W32.w[k] = k <= R ? (float)prm->gauss_w[k] : 0.0f;
+            c32_budget(prm->gauss_w, R, &W32);
             const size_t nflags = nimg * tiles;       // tile-images k_canny_f32 hands over to the exact kernel (see there)
             void* p_x = nullptr;
             HIPCHK(ws_get(ctx, WS_C32Q, nflags, &p_x));

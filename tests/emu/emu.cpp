@@ -13,6 +13,10 @@
 
 // k_canny_f32 of one tile: the f32 phases, the certified class test and the exact per-pixel resolver
 static long long g_c32_uncertain = 0, g_c32_candidates = 0;
+// optional full-image dumps of the f32 intermediates (tests of the error budget): smoothed value, Sobel sums, magnitude,
+// and the scale g the tile used; pitch STP_PITCH
+static float g_c32_last_eg = 0.0f;
+static float *g_c32_dS = nullptr, *g_c32_dI = nullptr, *g_c32_dJ = nullptr, *g_c32_dM = nullptr, *g_c32_dG = nullptr, *g_c32_dE = nullptr;
 template <int R>
 static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float gmax, const double* sB, float* sV, float* sM,
                          uint8_t* sC, bool xin, bool yin)
@@ -22,6 +26,7 @@ static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float g
     std::vector<float> sS(VH * C32_SP, qnan), sRB(VH, qnan), sRV(VH, qnan), sRC(C32_SP, qnan);
     stp_w32 W;
     for (int k = 0; k <= R; k++) W.w[k] = (float)w[k];
+    c32_budget(w, R, &W);
     const stp_cgeo G = ct_geo<R>(T);
     c32_rb_tables<R>(0, 1, T, w, sB, sRB.data(), sRV.data(), sRC.data(), xin);
     if (yin) c32_p1_blk<R, true>(0, 1, T, W, gray, sV);
@@ -30,11 +35,21 @@ static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float g
     else c32_p2_blk<R, false>(0, 1, T, G, W, sV, sRB.data(), sRV.data(), sRC.data(), sS.data());
     if (!(xin && yin)) c32_p3_ring(0, 1, T, sS.data());
     c32_p3_region(G, sS.data(), sM);
-    const stp_c32tol E = c32_tol(gmax);
+    const int et = c32_budget_of(xin && yin, T.S, R);
+    const stp_c32tol E = c32_tol_u(gmax, W.eu[et][0], W.eu[et][1], W.eu[et][2]);
+    g_c32_last_eg = W.eu[et][0];
     constexpr int NV = 5 * (2 * R + 5);
     for (int i = 0; i < CT_Y * CT_X; i++) {
         const int yy = i / CT_X, xx = i - yy * CT_X, y = T.ty0 + yy, x = T.tx0 + xx;
         int cls = 0;
+        if (g_c32_dS && y < T.S && x < T.S) {
+            const float* c = sS.data() + (yy + 2) * C32_SP + (xx + 2);
+            float gi, gj;
+            c32_sobel(c, &gi, &gj);
+            const int o = y * STP_PITCH + x;
+            g_c32_dS[o] = c[0]; g_c32_dI[o] = gi; g_c32_dJ[o] = gj; g_c32_dM[o] = sM[(yy + 1) * (CT_X + 2) + xx + 1]; g_c32_dG[o] = gmax;
+            if (g_c32_dE) g_c32_dE[o] = W.eu[et][0];
+        }
         if (y < T.S && x < T.S) {
             cls = c32_nms(sS.data(), sM, T, y, x, E);
             if (y >= 1 && x >= 1 && y < T.S - 1 && x < T.S - 1 && sM[(yy + 1) * (CT_X + 2) + xx + 1] >= E.thr) g_c32_candidates++;
@@ -196,6 +211,15 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
 void emu_canny(const float* gray, int S, int R, const double* w, stp_u64* low, stp_u64* high)
 {
     emu_canny2(gray, S, R, w, low, high, 1);
+}
+// the f32 intermediates of every pixel (five STP_PITCH x STP_PITCH float images: S, isobel, jsobel, magnitude, scale g)
+void emu_canny_f32_dump(const float* gray, int S, int R, const double* w, float* dS, float* dI, float* dJ, float* dM, float* dG,
+                        float* dE /* the tile's E_G in units of u g */)
+{
+    std::vector<stp_u64> low(STP_FRAME_MAX * STP_NW), high(STP_FRAME_MAX * STP_NW);
+    g_c32_dS = dS; g_c32_dI = dI; g_c32_dJ = dJ; g_c32_dM = dM; g_c32_dG = dG; g_c32_dE = dE;
+    emu_canny2(gray, S, R, w, low.data(), high.data(), 2);
+    g_c32_dS = g_c32_dI = g_c32_dJ = g_c32_dM = g_c32_dG = g_c32_dE = nullptr;
 }
 void emu_canny_f32(const float* gray, int S, int R, const double* w, stp_u64* low, stp_u64* high, long long* counts /* candidates, uncertain */)
 {

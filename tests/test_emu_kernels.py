@@ -242,3 +242,55 @@ def test_f32_path_on_threshold_and_octant_boundaries(emu, golden_stages, sigma, 
         total += cnt
         assert np.array_equal(cls32, dbg['cls']), 'image %d (sigma %.1f): %d pixels differ' % (k, sigma, int((cls32 != dbg['cls']).sum()))
     assert total[1] > 1000        # the inputs do reach the resolver
+
+
+@pytest.mark.parametrize('sigma,key', [(2.0, 'gw_2p0'), (2.5, 'gw_2p5')])
+def test_f32_error_budget_holds_for_every_intermediate(emu, golden_stages, chr7, sigma, key):
+    """The bounds k_canny_f32's tile-wide certificates rest on (stp_canny32.h, c32_budget), checked quantity by quantity
+    against the reference's f64 intermediates (oracle debug arrays) on every pixel of noisy, bright, dark and
+    synthetic-frame images: with E_G the tile's Sobel bound in units of u g (interior tiles ~131, border tiles ~165
+    at sigma 2), |S_f32 - S| <= (E_G - 16.1) / 8, |Sobel_f32 - Sobel| <= E_G, |m_f32 - m| <= sqrt(2) E_G + 17.7,
+    g the scale the tile used (flat tiles are skipped by the kernel and carry no values).  Also reports how far below
+    the bounds the observed errors stay."""
+    gw = np.ascontiguousarray(golden_stages[key])
+    R = (len(gw) - 1) // 2
+    u = 2.0 ** -24
+    rng = np.random.default_rng(17)
+    S = 300
+    yy, xx = np.mgrid[0:S, 0:S].astype(np.float64)
+    imgs = [_noisy(S, 5),
+            np.clip(0.9 + 0.1 * rng.standard_normal((S, S)), 0, 1),                      # bright: the largest absolute errors
+            0.299 + 0.05 * rng.random((S, S)),                                            # dark, low contrast
+            np.clip(0.5 + 0.5 * np.sin(xx / 2.5) * np.sin(yy / 3.5), 0, 1),               # strong gradients everywhere
+            np.clip(rng.random((S, S)) > 0.5, 0.299, 1.0).astype(np.float64)]             # salt and pepper between the extremes
+    g = golden_stages
+    p = 'c2_'
+    band = chr7.band(512)
+    start, end, Sg, M = int(g[p + 'start']), int(g[p + 'end']), int(g[p + 'S']), float(g[p + 'M'])
+    nz = np.zeros(400, np.int16)
+    emu.emu_compact(_p(band), 1024, 512, C.c_int64(start), end - start + 1, _p(nz))
+    gray6 = np.zeros((6, 400, 400), np.float32)
+    emu.emu_gray(_p(band), 1024, 512, C.c_int64(start), _p(nz), Sg, C.c_double(M), _p(np.ascontiguousarray(g['bvals'])), 6, 1, _p(gray6))
+    imgs += [gray6[0, :Sg, :Sg], gray6[5, :Sg, :Sg]]
+    worst = np.zeros(3)            # observed error / bound
+    budgets = set()
+    for k, img in enumerate(imgs):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        Si = img.shape[0]
+        full = np.zeros((400, 400), np.float32); full[:Si, :Si] = img
+        d = [np.full((400, 400), np.nan, np.float32) for _ in range(6)]
+        emu.emu_canny_f32_dump(_p(full), Si, R, _p(gw), *[_p(a) for a in d])
+        _, dbg = O.canny(img, gw, R, debug=True)
+        dS, dI, dJ, dM, dG, dE = [a[:Si, :Si].astype(np.float64) for a in d]
+        live = ~np.isnan(dS)                                     # tiles the kernel did not skip as flat
+        assert live.any()
+        budgets |= set(np.round(dE[live], 1).tolist())
+        ug = u * dG
+        inner = live.copy(); inner[0, :] = inner[-1, :] = False; inner[:, 0] = inner[:, -1] = False
+        rS = (np.abs(dS - dbg['smoothed']) / ug / ((dE - 16.1) / 8.0))[live]
+        rG = (np.maximum(np.abs(dI - dbg['isobel']), np.abs(dJ - dbg['jsobel'])) / ug / dE)[inner]
+        rM = (np.abs(dM - dbg['mag']) / ug / (1.41422 * dE + 17.7))[inner]
+        assert rS.max() <= 1.0 and rG.max() <= 1.0 and rM.max() <= 1.0, (k, rS.max(), rG.max(), rM.max())
+        worst = np.maximum(worst, [rS.max(), rG.max(), rM.max()])
+    print('E_G budgets in use (u g):', sorted(budgets), '; largest observed error / bound: smoothed %.2f, Sobel %.2f, magnitude %.2f' % tuple(worst))
+    assert worst[0] > 0.05           # the comparison is not vacuous
