@@ -402,20 +402,20 @@ STP_HD float c32_res_V(stp_tile T, int y, int x, int l, const double* w, const f
     return c32_gauss_exact<R>(gimg + yy * STP_PITCH + xx, STP_PITCH, w, lo, hi);
 }
 // S patch: element l = r * 5 + c is the smoothed value at (clamp(y-2+r), clamp(x-2+c)), the reference's operations
-// (canny_p2: f32 horizontal sum in the exact order, f64 quotient by bleed + eps; the bleed-over factors as canny_p1b
-// tabulates them: column factor of the row, then the row pass at the pixel's column -- at column R for every
-// interior column)
+// (canny_p2: f32 horizontal sum in the exact order, f64 quotient by bleed + eps; bleed-over factors as canny_p1b
+// tabulates them in sB: [yy] the column factor of tile row yy, [VH + yy] the full factor for an interior column)
 template <int R>
-STP_HD double c32_res_S(stp_tile T, int y, int x, int l, const double* w, const float* Vp)
+STP_HD double c32_res_S(stp_tile T, int y, int x, int l, const double* w, const double* sB, const float* Vp)
 {
     constexpr int NC = 2 * R + 5;
+    const int VH = CT_Y + 4;
     const int r = l / 5, c = l - r * 5;
     int yy = y - 2 + r, cx = x - 2 + c;
     yy = yy < 0 ? 0 : (yy > T.S - 1 ? T.S - 1 : yy);
     cx = cx < 0 ? 0 : (cx > T.S - 1 ? T.S - 1 : cx);
     const float f = c32_gauss_exact<R>(Vp + r * NC + (cx - (x - 2 - R)), 1, w, 0, 2 * R);
-    const double bv = stp_bleed_v(yy, T.S, R, w);
-    const double bl = stp_bleed_h(bv, (cx >= R && cx + R < T.S) ? R : cx, T.S, R, w);
+    const int yyt = yy - (T.ty0 - 2);
+    const double bl = (cx >= R && cx + R < T.S) ? sB[VH + yyt] : stp_bleed_h(sB[yyt], cx, T.S, R, w);
     return (double)f / (bl + DBL_EPSILON);       // _canny.py:49
 }
 // magnitude (glibc hypot of the f64 Sobel sums) of pixel l = 3 * (dy + 1) + (dx + 1) of the 3 x 3 block around the

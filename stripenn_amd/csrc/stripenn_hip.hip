@@ -573,15 +573,15 @@ __device__ __forceinline__ void canny32_nms_queue(int tid, int bi, stp_tile T, s
 }
 // one pixel, one wave: the 5 x (2R+5) vertical-pass values, the 5 x 5 smoothed values, nine magnitudes, the literal test
 template <int R>
-__device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, const double* sW, const float* __restrict__ gimg,
-                                                float* Vp, double* Sp, stp_u64* sBits)
+__device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, const double* sW, const double* sB,
+                                                const float* __restrict__ gimg, float* Vp, double* Sp, stp_u64* sBits)
 {
     constexpr int NV = 5 * (2 * R + 5);
     const int yy = e >> 6, xx = e & 63, y = T.ty0 + yy, x = T.tx0 + xx;
     for (int l = lane; l < NV; l += 64) Vp[l] = c32_res_V<R>(T, y, x, l, sW, gimg);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < 25) Sp[lane] = c32_res_S<R>(T, y, x, lane, sW, Vp);
+    if (lane < 25) Sp[lane] = c32_res_S<R>(T, y, x, lane, sW, sB, Vp);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     double* M9 = (double*)Vp;                    // the vertical-pass values are dead: nine magnitudes in their place
@@ -601,17 +601,17 @@ __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, con
 #define STP_C32_MINBLK 5
 #endif
 #define C32_RES_WAVE_BYTES 768       /* per-wave resolver scratch inside the smoothed tile: 26 doubles, then 5 x (2R+5) floats (<= 125) */
-struct stp_c32_layout { size_t sRB, sRV, sRC, sS, sV, sQ, sD, sBits, sQn, total; };
+struct stp_c32_layout { size_t sB, sRB, sRV, sRC, sS, sV, sQ, sD, sBits, sQn, total; };
 static __host__ __device__ stp_c32_layout canny32_layout(int R)
 {
     const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
     stp_c32_layout L;
     size_t o = 32 * sizeof(double);                          // sW: the f64 weights (bleed-over tables, resolver)
+    L.sB = o; o += 2 * VH * sizeof(double);                  // f64 bleed-over factors (reciprocal tables, resolver)
     L.sRB = o; o += (size_t)((VH + 1) & ~1) * sizeof(float);
     L.sRV = o; o += (size_t)((VH + 1) & ~1) * sizeof(float);
     L.sRC = o; o += (size_t)C32_SP * sizeof(float);
-    L.sS = o; o += (size_t)VH * C32_SP * sizeof(float);      // smoothed tile (at start-up: the f64 bleed-over factors; at the
-                                                              // end: the resolver's per-wave scratch)
+    L.sS = o; o += (size_t)VH * C32_SP * sizeof(float);      // smoothed tile (at the end: the resolver's per-wave scratch)
     L.sV = o;                                                 // vertical-pass tile | magnitude tile + candidate queue
     const size_t v = (size_t)(CT_P2_COLS(R) > GW ? CT_P2_COLS(R) : GW) * CT_VP * sizeof(float);
     const size_t mq = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(float);
@@ -663,8 +663,8 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     if (tid == 64) { *sDn = 0; *sOv = 0; }
     const bool yin = (T.ty0 - R - 2 >= 0) && (T.ty0 + CT_Y + R + 1 < S);
     const bool xin = (T.tx0 - 2 - R >= 0) && (T.tx0 + CT_X + 1 + R < S);
-    {   // reciprocal bleed-over tables from the f64 factors, which live in the (still unused) smoothed tile meanwhile
-        double* sB = (double*)sS;
+    double* sB = (double*)(smem + L.sB);
+    {   // f64 bleed-over factors of the tile's rows and their f32 reciprocal tables
         if (tid < 2 * R + 1) sW[tid] = gw[tid];
         canny_p1b(tid, nt, T, R, gw, sB);
         __syncthreads();
@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         double* sSp = (double*)(smem + L.sS + wv * C32_RES_WAVE_BYTES);
         for (int k = wv; k < nd; k += 4) {           // wave-uniform
             const int d = sD[k], bi = d >> 11;
-            canny32_resolve<R>(T, d & 2047, lane, sW, gray + (img0 + bi) * (STP_PITCH * STP_PITCH), sVp, sSp, sBits + bi * 2 * CT_Y);
+            canny32_resolve<R>(T, d & 2047, lane, sW, sB, gray + (img0 + bi) * (STP_PITCH * STP_PITCH), sVp, sSp, sBits + bi * 2 * CT_Y);
         }
     }
     __syncthreads();

@@ -58,7 +58,7 @@ static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float g
                 float Vp[NV];
                 double Sp[25];
                 for (int l = 0; l < NV; l++) Vp[l] = c32_res_V<R>(T, y, x, l, w, gray);
-                for (int l = 0; l < 25; l++) Sp[l] = c32_res_S<R>(T, y, x, l, w, Vp);
+                for (int l = 0; l < 25; l++) Sp[l] = c32_res_S<R>(T, y, x, l, w, sB, Vp);
                 double M9[9];
                 for (int l = 0; l < 9; l++) M9[l] = c32_res_mag(Sp, l);
                 cls = c32_res_class(Sp, M9);
