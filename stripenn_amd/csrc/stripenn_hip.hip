@@ -1822,11 +1822,11 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         const int tiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
         const dim3 cg(tiles, (unsigned)nimg);
         const unsigned pgrid = (unsigned)(((nf * nlev + 7) / 8) * 8 * tiles);
-        // STP_CANNY=exact selects k_canny_pipe (every intermediate in the reference's f64 arithmetic); the default
-        // k_canny_f32 needs k_gray's per-cell grey maxima for its error budget (bfilter 3)
+        // STP_CANNY=exact selects k_canny_pipe (every intermediate in the reference's f64 arithmetic)
         const char* canny_env = getenv("STP_CANNY");      // read per call: the tests compare both kernels in one process
         const bool canny_exact = canny_env && strcmp(canny_env, "exact") == 0;
-        if ((R == 8 || R == 10) && p_cells && nb <= C32_NBMAX && !canny_exact) {
+        if ((R == 8 || R == 10) && nb <= C32_NBMAX && !canny_exact) {      // (without k_gray's cell maxima -- bfilter other than 3 -- g is the
+                                                                           //  largest grey value k_gray can write, and no tile is skipped as flat)
             stp_w32 W32;
             for (int k = 0; k <= CT_RMAX; k++) W32.w[k] = k <= R ? (float)prm->gauss_w[k] : 0.0f;
             c32_budget(prm->gauss_w, R, &W32);

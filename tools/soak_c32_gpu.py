@@ -29,16 +29,17 @@ def main():
                 continue
             M = float(np.quantile(pos, float(rng.uniform(0.7, 0.9995))))
             sigma = float(rng.choice([2.0, 2.5]))
+            bf = int(rng.choice([3, 3, 3, 1, 5]))
             for bi in range(6):
                 os.environ.pop('STP_CANNY', None)
-                a = fr.dbg_stages(f, M, bi, sigma=sigma)
+                a = fr.dbg_stages(f, M, bi, sigma=sigma, bfilter=bf)
                 os.environ['STP_CANNY'] = 'exact'
-                b = fr.dbg_stages(f, M, bi, sigma=sigma)
+                b = fr.dbg_stages(f, M, bi, sigma=sigma, bfilter=bf)
                 os.environ.pop('STP_CANNY', None)
                 nimg += 1
                 if not (np.array_equal(a['cls'], b['cls']) and np.array_equal(a['edges'], b['edges'])):
                     bad += 1
-                    print('MISMATCH seed', seed0, 'chrom', k, 'frame', f, 'M', M, 'sigma', sigma, 'bi', bi,
+                    print('MISMATCH seed', seed0, 'chrom', k, 'frame', f, 'M', M, 'sigma', sigma, 'bfilter', bf, 'bi', bi,
                           int((a['cls'] != b['cls']).sum()), flush=True)
         fr.close(); band.close()
         if k % 25 == 0:
