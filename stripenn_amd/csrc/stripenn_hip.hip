@@ -600,7 +600,7 @@ __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, con
 #ifndef STP_C32_MINBLK
 #define STP_C32_MINBLK 5
 #endif
-#define C32_RES_WAVE_BYTES 768       /* per-wave resolver scratch inside the smoothed tile: 26 doubles, then 5 x (2R+5) floats (<= 125) */
+#define C32_RES_WAVE_BYTES 832       /* per-wave resolver scratch inside the smoothed tile: 26 doubles, then 5 x (2R+5) floats (<= 145) */
 struct stp_c32_layout { size_t sB, sRB, sRV, sRC, sS, sV, sQ, sD, sBits, sQn, total; };
 static __host__ __device__ stp_c32_layout canny32_layout(int R)
 {
@@ -1782,6 +1782,11 @@ static stp_fastdiv make_fastdiv(stp_ctx* ctx, const double* w, int R)
     return fd;
 }
 
+// Gaussian radii the tiled Canny kernels are instantiated for: int(4 sigma + 0.5) of sigma 1.0, 1.5, 2.0 (the reference's
+// default), 2.5 and 3.0; any other radius <= 12 runs the generic k_canny
+static bool canny_tiled_radius(int R) { return R == 4 || R == 6 || R == 8 || R == 10 || R == 12; }
+#define STP_CANNY_RADII(X) X(4) X(6) X(8) X(10) X(12)
+
 // shared by stp_stripe_search and stp_dbg_stages: run the three image kernels on frames
 // [f0, f0+nf) for n_levels levels; buffers sized by the caller.
 static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, int f0, int nf,
@@ -1801,7 +1806,7 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     // (no memset of the class bit-planes: the Canny kernels write every word k_lines reads -- one word per tile
     //  row for each tile that reaches into the image, zeros included)
     void* p_cells = nullptr;     // min / max of the grey values per 8 x 16 cell (flat-window rule, bfilter 3 only)
-    if (a == 1 && (R == 8 || R == 10))
+    if (a == 1 && canny_tiled_radius(R))
         HIPCHK(ws_get(ctx, WS_CELLS, nimg * GC_ROWS * GC_COLS * sizeof(float2), &p_cells));
     // (measured and dropped: running k_lines of one sub-chunk on a second stream beside gray / canny of the
     //  next -- chain wall 5.99 ms alone vs 6.02 / 6.29 / 6.83 ms with 2 / 4 / 8 sub-chunks)
@@ -1825,7 +1830,7 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         // STP_CANNY=exact selects k_canny_pipe (every intermediate in the reference's f64 arithmetic)
         const char* canny_env = getenv("STP_CANNY");      // read per call: the tests compare both kernels in one process
         const bool canny_exact = canny_env && strcmp(canny_env, "exact") == 0;
-        if ((R == 8 || R == 10) && nb <= C32_NBMAX && !canny_exact) {      // (without k_gray's cell maxima -- bfilter other than 3 -- g is the
+        if (canny_tiled_radius(R) && nb <= C32_NBMAX && !canny_exact) {    // (without k_gray's cell maxima -- bfilter other than 3 -- g is the
                                                                            //  largest grey value k_gray can write, and no tile is skipped as flat)
             stp_w32 W32;
             for (int k = 0; k <= CT_RMAX; k++) W32.w[k] = k <= R ? (float)prm->gauss_w[k] : 0.0f;
@@ -1837,27 +1842,28 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
             const stp_fastdiv fd = make_fastdiv(ctx, prm->gauss_w, R);
             const size_t smem = canny32_layout(R).total, smem_x = canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES;
             const unsigned xgrid = (unsigned)std::min<size_t>(2048, (nflags + 255) / 256);
-            if (R == 8) {
-                hipLaunchKernelGGL(k_canny_f32<8>, dim3(pgrid), dim3(256), smem, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, d_w,
-                                   d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x);
-                hipLaunchKernelGGL(k_canny_pipe_list<8>, dim3(xgrid), dim3(256), smem_x, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb,
-                                   d_w, d_low, d_high, fd, (const uint8_t*)p_x);
-            } else {
-                hipLaunchKernelGGL(k_canny_f32<10>, dim3(pgrid), dim3(256), smem, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, d_w,
-                                   d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x);
-                hipLaunchKernelGGL(k_canny_pipe_list<10>, dim3(xgrid), dim3(256), smem_x, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb,
-                                   d_w, d_low, d_high, fd, (const uint8_t*)p_x);
+            switch (R) {
+#define STP_X(RR) case RR: \
+                hipLaunchKernelGGL(k_canny_f32<RR>, dim3(pgrid), dim3(256), smem, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, d_w, \
+                                   d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x); \
+                hipLaunchKernelGGL(k_canny_pipe_list<RR>, dim3(xgrid), dim3(256), smem_x, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, \
+                                   d_w, d_low, d_high, fd, (const uint8_t*)p_x); \
+                break;
+                STP_CANNY_RADII(STP_X)
+#undef STP_X
             }
             HIPCHK(hipGetLastError());
+        } else if (canny_tiled_radius(R)) {
+            const stp_fastdiv fd = make_fastdiv(ctx, prm->gauss_w, R);
+            switch (R) {
+#define STP_X(RR) case RR: \
+                hipLaunchKernelGGL(k_canny_pipe<RR>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES, ctx->stream, \
+                                   d_gray, fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high, fd, (const float2*)p_cells); \
+                break;
+                STP_CANNY_RADII(STP_X)
+#undef STP_X
+            }
         } else {
-        const stp_fastdiv fd = make_fastdiv(ctx, prm->gauss_w, R);
-        if (R == 8)
-            hipLaunchKernelGGL(k_canny_pipe<8>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES, ctx->stream, d_gray,
-                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high, fd, (const float2*)p_cells);
-        else if (R == 10)
-            hipLaunchKernelGGL(k_canny_pipe<10>, dim3(pgrid), dim3(256), canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES, ctx->stream, d_gray,
-                               fr->d_S, f0, nf, nlev, nb, d_w, d_low, d_high, fd, (const float2*)p_cells);
-        else
             hipLaunchKernelGGL(k_canny, cg, dim3(256), canny_smem_bytes(R) + CANNY_NMS_BYTES, ctx->stream, d_gray, fr->d_S, f0, ipf, R, d_w,
                                d_low, d_high);
         }

@@ -68,6 +68,24 @@ static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float g
     }
 }
 
+// k_canny_pipe<R>'s phases of one tile (the device path of the tiled radii)
+template <int R>
+static void emu_tile_pipe(stp_tile T, const double* w, const float* gray, const double* sB, float* sV, double* sS, float* sM,
+                          stp_fastdiv fd, bool xin, bool yin)
+{
+    const int VH = CT_Y + 4;
+    std::vector<double> sBB(VH * 2 * R);
+    const stp_cgeo G = ct_geo<R>(T);
+    if (!xin) canny_p1c<R>(0, 1, T, w, sB, sBB.data());
+    if (yin) canny_p1_blk_g<R, true>(0, 1, T, G, w, gray, sV);
+    else canny_p1_blk_g<R, false>(0, 1, T, G, w, gray, sV);
+    if (xin) canny_p2_blk<R, true>(0, 1, T, G, w, sV, sB, sBB.data(), sS, fd);
+    else canny_p2_blk<R, false>(0, 1, T, G, w, sV, sB, sBB.data(), sS, fd);
+    if (!(xin && yin)) canny_p3_ring(0, 1, T, sS);
+    canny_p3_reg(0, 1, G, sS, sM);
+}
+static bool emu_tiled_radius(int R) { return R == 4 || R == 6 || R == 8 || R == 10 || R == 12; }
+
 extern "C" {
 
 // zero-column removal (mirror of k_frame_compact)
@@ -147,7 +165,7 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
         for (int tx0 = 0; tx0 < S; tx0 += CT_X) {
             stp_tile T; T.S = S; T.ty0 = ty0; T.tx0 = tx0;
             float gmax = 1.0f;
-            if (blocked && (R == 8 || R == 10)) {
+            if (blocked && emu_tiled_radius(R)) {
                 // k_canny_pipe's flat-window rule, evaluated here straight from the grey image over the same
                 // cell-aligned window (the kernel unites k_gray's per-cell min / max): skipped tiles stay all-zero
                 const int wy0 = std::max(ty0 - R - 2, 0), wy1 = std::min(ty0 + CT_Y + R + 2, S);
@@ -165,39 +183,33 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
             const bool yin = (T.ty0 - R - 2 >= 0) && (T.ty0 + CT_Y + R + 1 < S);
             const bool xin = (T.tx0 - 2 - R >= 0) && (T.tx0 + CT_X + 1 + R < S);
             bool did_p3 = false;
-            if (blocked && (R == 8 || R == 10)) {
+            if (blocked && emu_tiled_radius(R)) {
                 // k_canny_pipe writes only what lies inside the image (stp_cgeo): poison the LDS stand-ins so that a
                 // read of anything it did not write reaches the result as a NaN
                 std::fill(sV.begin(), sV.end(), std::numeric_limits<float>::quiet_NaN());
                 std::fill(sS.begin(), sS.end(), std::numeric_limits<double>::quiet_NaN());
                 std::fill(sM.begin(), sM.end(), std::numeric_limits<float>::quiet_NaN());
             }
-            if (blocked == 2 && (R == 8 || R == 10)) {     // k_canny_f32: f32 phases, certified classes, exact resolver
-                if (R == 8) emu_tile_c32<8>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin);
-                else emu_tile_c32<10>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin);
+            if (blocked == 2 && emu_tiled_radius(R)) {     // k_canny_f32: f32 phases, certified classes, exact resolver
+                switch (R) {
+                    case 4: emu_tile_c32<4>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin); break;
+                    case 6: emu_tile_c32<6>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin); break;
+                    case 8: emu_tile_c32<8>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin); break;
+                    case 10: emu_tile_c32<10>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin); break;
+                    default: emu_tile_c32<12>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin); break;
+                }
                 canny_p5(0, 1, T, sC.data(), low, high);
                 continue;
             }
-            if (R == 8 && blocked) {       // the device path for sigma 2.0 (k_canny_pipe<8>)
-                std::vector<double> sBB(VH * 16);
-                const stp_cgeo G = ct_geo<8>(T);
-                if (!xin) canny_p1c<8>(0, 1, T, w, sB.data(), sBB.data());
-                if (yin) canny_p1_blk_g<8, true>(0, 1, T, G, w, gray, sV.data());
-                else canny_p1_blk_g<8, false>(0, 1, T, G, w, gray, sV.data());
-                if (xin) canny_p2_blk<8, true>(0, 1, T, G, w, sV.data(), sB.data(), sBB.data(), sS.data(), fd);
-                else canny_p2_blk<8, false>(0, 1, T, G, w, sV.data(), sB.data(), sBB.data(), sS.data(), fd);
-                if (!(xin && yin)) canny_p3_ring(0, 1, T, sS.data());
-                canny_p3_reg(0, 1, G, sS.data(), sM.data()); did_p3 = true;
-            } else if (R == 10 && blocked) {
-                std::vector<double> sBB(VH * 20);
-                const stp_cgeo G = ct_geo<10>(T);
-                if (!xin) canny_p1c<10>(0, 1, T, w, sB.data(), sBB.data());
-                if (yin) canny_p1_blk_g<10, true>(0, 1, T, G, w, gray, sV.data());
-                else canny_p1_blk_g<10, false>(0, 1, T, G, w, gray, sV.data());
-                if (xin) canny_p2_blk<10, true>(0, 1, T, G, w, sV.data(), sB.data(), sBB.data(), sS.data(), fd);
-                else canny_p2_blk<10, false>(0, 1, T, G, w, sV.data(), sB.data(), sBB.data(), sS.data(), fd);
-                if (!(xin && yin)) canny_p3_ring(0, 1, T, sS.data());
-                canny_p3_reg(0, 1, G, sS.data(), sM.data()); did_p3 = true;
+            if (blocked && emu_tiled_radius(R)) {          // the device path of the tiled radii (k_canny_pipe<R>)
+                switch (R) {
+                    case 4: emu_tile_pipe<4>(T, w, gray, sB.data(), sV.data(), sS.data(), sM.data(), fd, xin, yin); break;
+                    case 6: emu_tile_pipe<6>(T, w, gray, sB.data(), sV.data(), sS.data(), sM.data(), fd, xin, yin); break;
+                    case 8: emu_tile_pipe<8>(T, w, gray, sB.data(), sV.data(), sS.data(), sM.data(), fd, xin, yin); break;
+                    case 10: emu_tile_pipe<10>(T, w, gray, sB.data(), sV.data(), sS.data(), sM.data(), fd, xin, yin); break;
+                    default: emu_tile_pipe<12>(T, w, gray, sB.data(), sV.data(), sS.data(), sM.data(), fd, xin, yin); break;
+                }
+                did_p3 = true;
             } else {
                 canny_p1(0, 1, T, R, w, sG.data(), sV.data());
                 canny_p2(0, 1, T, R, w, sV.data(), sB.data(), sS.data());

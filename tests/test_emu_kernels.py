@@ -294,3 +294,24 @@ def test_f32_error_budget_holds_for_every_intermediate(emu, golden_stages, chr7,
         worst = np.maximum(worst, [rS.max(), rG.max(), rM.max()])
     print('E_G budgets in use (u g):', sorted(budgets), '; largest observed error / bound: smoothed %.2f, Sobel %.2f, magnitude %.2f' % tuple(worst))
     assert worst[0] > 0.05           # the comparison is not vacuous
+
+
+@pytest.mark.parametrize('sigma', [1.0, 1.5, 3.0])
+@pytest.mark.parametrize('S', [400, 301, 64, 41])
+def test_other_tiled_radii(emu, emu_allnear, S, sigma):
+    """The tiled kernels are also instantiated for the radii of sigma 1.0, 1.5 and 3.0 (4, 6, 12): k_canny_pipe's phases
+    (certified FMA and its exact-order fallback alone) and k_canny_f32's against the oracle, noisy and plateau images."""
+    gw, R = O.gauss_weights(sigma)
+    gw = np.ascontiguousarray(gw)
+    assert R in (4, 6, 12)
+    for k, img in enumerate([_noisy(S, 3 + S)] + (_plateau_images(S)[:4] if S >= 41 else [])):
+        full = np.zeros((400, 400), np.float32)
+        full[:S, :S] = img
+        oe, dbg = O.canny(img, gw, R, debug=True)
+        for lib in (emu, emu_allnear):
+            low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64)
+            lib.emu_canny(_p(full), S, R, _p(gw), _p(low), _p(high))
+            got = _unpack(low, S).astype(np.uint8) + _unpack(high, S)
+            assert np.array_equal(got, dbg['cls']), 'image %d (S=%d, sigma %.1f)' % (k, S, sigma)
+        cls32, cnt = _canny_f32(emu, full, S, R, gw)
+        assert np.array_equal(cls32, dbg['cls']), 'f32 path, image %d (S=%d, sigma %.1f)' % (k, S, sigma)

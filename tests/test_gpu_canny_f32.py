@@ -112,3 +112,47 @@ def test_chromosome_sweep_records_identical_under_both_kernels(hip_ctx):
     assert len(a) == len(b) > 10000
     assert a.tobytes() == b.tobytes()
     fr.close(); band.close()
+
+
+@pytest.mark.parametrize('sigma', [1.0, 1.5, 3.0])
+def test_other_tiled_radii_on_the_device(hip_ctx, sigma):
+    """Sigma 1.0 / 1.5 / 3.0 (radii 4 / 6 / 12) run the tiled kernels too: class maps of both kernels against the oracle on
+    synthetic frames and on a block-structured map (exact ties: the redo path), and the records of a small sweep."""
+    from stripenn_amd import synth, hip
+    ch = synth.SynthChrom(1500, 5, stripe_every=50, stripe_gain=3.0)
+    band = hip_ctx.band_upload(ch.band(512))
+    st = np.array([0, 400, 1000]); en = st + np.array([399, 349, 399])
+    fr = band.frames(st, en)
+    blk = ch.block(0, 1500, 0, 1500)
+    Ms = np.quantile(blk[blk > 0], [0.92, 0.99])
+    gw, gr = hip.gauss_weights(sigma)
+    for f in range(3):
+        D, nz = O.frame_dense(ch.block, int(st[f]), int(en[f]))
+        D = np.ascontiguousarray(D[np.ix_(nz, nz)])
+        for M in Ms:
+            gp = O.gplane(D, float(M))
+            for bi in (0, 2, 5):
+                a = fr.dbg_stages(f, float(M), bi, sigma=sigma)
+                with _exact_kernel():
+                    b = fr.dbg_stages(f, float(M), bi, sigma=sigma)
+                _, dbg = O.canny(O.gray(gp, O.brightness_levels()[bi], 3), gw, gr, debug=True)
+                assert np.array_equal(a['cls'], dbg['cls']), (sigma, f, M, bi)
+                assert np.array_equal(b['cls'], dbg['cls']), (sigma, f, M, bi, 'f64 kernel')
+    a = fr.stripe_search(Ms, sigma=sigma)
+    with _exact_kernel():
+        b = fr.stripe_search(Ms, sigma=sigma)
+    assert a.tobytes() == b.tobytes()
+    fr.close(); band.close()
+    n = 600
+    rr, cc = np.mgrid[0:n, 0:n].astype(np.float64)
+    dense = np.where((cc // 37 + rr // 53) % 2 == 0, 12.0, 3.0) + np.where(np.abs(cc - rr) < 25, 20.0, 0.0)
+    dense = np.where(np.abs(cc - rr) <= 500, dense, 0.0)
+    band = hip_ctx.band_upload(_band_of(dense))
+    fr = band.frames([100], [499])
+    D = np.ascontiguousarray(dense[100:500, 100:500])
+    gp = O.gplane(D, 10.0)
+    for bi in (0, 5):
+        a = fr.dbg_stages(0, 10.0, bi, sigma=sigma)
+        _, dbg = O.canny(O.gray(gp, O.brightness_levels()[bi], 3), gw, gr, debug=True)
+        assert np.array_equal(a['cls'], dbg['cls']), (sigma, 'blocks', bi)
+    fr.close(); band.close()

@@ -28,7 +28,7 @@ def main():
             if fr.S[f] < 20:
                 continue
             M = float(np.quantile(pos, float(rng.uniform(0.7, 0.9995))))
-            sigma = float(rng.choice([2.0, 2.5]))
+            sigma = float(rng.choice([2.0, 2.0, 2.5, 1.0, 1.5, 3.0]))
             bf = int(rng.choice([3, 3, 3, 1, 5]))
             for bi in range(6):
                 os.environ.pop('STP_CANNY', None)
