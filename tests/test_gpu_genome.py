@@ -104,6 +104,12 @@ def test_mm10_genome_compute_determinism_invariants_and_sampled_frames(tmp_path)
     a = _run_compute(table, str(tmp_path / 'a'), '0.95,0.96,0.97,0.98,0.99')
     b = _run_compute(table, str(tmp_path / 'b'), '0.95,0.96,0.97,0.98,0.99')
     assert a == b, 'two runs of the same genome differ'
+    os.environ['STP_CANNY'] = 'exact'             # the all-f64 Canny kernel instead of k_canny_f32 (79 350 images): same TSVs
+    try:
+        c = _run_compute(table, str(tmp_path / 'c'), '0.95,0.96,0.97,0.98,0.99')
+    finally:
+        os.environ.pop('STP_CANNY', None)
+    assert a == c, 'k_canny_f32 and k_canny_pipe give different tables'
     u, f = _check_tables(a[0], a[1], names, MM10, levels, 0.1)
     assert len(u) > 30000 and len(f) > 2000 and set(u['chr']) == set(names)
     # >= 40 frames across all chromosomes against the oracle: the facade's own quantiles and searches
