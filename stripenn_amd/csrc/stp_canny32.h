@@ -370,14 +370,18 @@ STP_HD int c32_nms(const float* sS, const float* sM, stp_tile T, int y, int x, s
 // The reference's order for one output (as stp_gauss_exact) with a compile-time radius: every tap is loaded before the
 // first use, so the 2R+1 loads of a lane are in flight together (the resolver is latency, not throughput).
 // Tap k (0 .. 2R) counts as 0 unless lo <= k <= hi (constant-mode zero padding); masked taps are not dereferenced.
+// In two halves, so that a caller can request the taps of several outputs before summing the first:
 template <int R>
-STP_HD float c32_gauss_exact(const float* centre, int stride, const double* w, int lo, int hi)
+STP_HD void c32_gauss_taps(const float* centre, int stride, int lo, int hi, float* v)
 {
-    float v[2 * R + 1];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int k = 0; k <= 2 * R; k++) v[k] = (k >= lo && k <= hi) ? centre[(k - R) * stride] : 0.0f;
+}
+template <int R>
+STP_HD float c32_gauss_sum(const float* v, const double* w)
+{
     double a = (double)v[R] * w[R];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -385,21 +389,37 @@ STP_HD float c32_gauss_exact(const float* centre, int stride, const double* w, i
     for (int k = R; k >= 1; k--) a += ((double)v[R - k] + (double)v[R + k]) * w[R - k];
     return (float)a;
 }
+template <int R>
+STP_HD float c32_gauss_exact(const float* centre, int stride, const double* w, int lo, int hi)
+{
+    float v[2 * R + 1];
+    c32_gauss_taps<R>(centre, stride, lo, hi, v);
+    return c32_gauss_sum<R>(v, w);
+}
 
 // ---- the exact resolver: one pixel (y, x) of the tile, interior of the image ----
 // V patch: 5 rows (y-2 .. y+2, clamped into the image: scipy's 'reflect' by one = edge replication) x (2R + 5) columns
 // x-2-R .. x+2+R of the vertical pass (0 outside the image: constant mode), element l = r * (2R+5) + c.
+// c32_res_V_taps requests the taps of element l (nothing for an element outside the image: all taps 0),
+// c32_gauss_sum turns them into the value.
 template <int R>
-STP_HD float c32_res_V(stp_tile T, int y, int x, int l, const double* w, const float* __restrict__ gimg)
+STP_HD void c32_res_V_taps(stp_tile T, int y, int x, int l, const float* __restrict__ gimg, float* v)
 {
     constexpr int NC = 2 * R + 5;
     const int r = l / NC, c = l - r * NC;
     int yy = y - 2 + r;
     yy = yy < 0 ? 0 : (yy > T.S - 1 ? T.S - 1 : yy);
     const int xx = x - 2 - R + c;
-    if (xx < 0 || xx >= T.S) return 0.0f;
-    const int lo = yy - R < 0 ? R - yy : 0, hi = yy + R >= T.S ? R + (T.S - 1 - yy) : 2 * R;
-    return c32_gauss_exact<R>(gimg + yy * STP_PITCH + xx, STP_PITCH, w, lo, hi);
+    const bool in = xx >= 0 && xx < T.S;
+    const int lo = !in ? 1 : (yy - R < 0 ? R - yy : 0), hi = !in ? 0 : (yy + R >= T.S ? R + (T.S - 1 - yy) : 2 * R);
+    c32_gauss_taps<R>(gimg + yy * STP_PITCH + (in ? xx : 0), STP_PITCH, lo, hi, v);
+}
+template <int R>
+STP_HD float c32_res_V(stp_tile T, int y, int x, int l, const double* w, const float* __restrict__ gimg)
+{
+    float v[2 * R + 1];
+    c32_res_V_taps<R>(T, y, x, l, gimg, v);
+    return c32_gauss_sum<R>(v, w);
 }
 // S patch: element l = r * 5 + c is the smoothed value at (clamp(y-2+r), clamp(x-2+c)), the reference's operations
 // (canny_p2: f32 horizontal sum in the exact order, f64 quotient by bleed + eps; bleed-over factors as canny_p1b

@@ -578,7 +578,15 @@ __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, con
 {
     constexpr int NV = 5 * (2 * R + 5);
     const int yy = e >> 6, xx = e & 63, y = T.ty0 + yy, x = T.tx0 + xx;
-    for (int l = lane; l < NV; l += 64) Vp[l] = c32_res_V<R>(T, y, x, l, sW, gimg);
+    {   // the taps of a lane's first two elements are requested together (one memory round trip instead of two)
+        float va[2 * R + 1], vb[2 * R + 1];
+        const bool hb = lane + 64 < NV;
+        c32_res_V_taps<R>(T, y, x, lane, gimg, va);
+        if (hb) c32_res_V_taps<R>(T, y, x, lane + 64, gimg, vb);
+        Vp[lane] = c32_gauss_sum<R>(va, sW);
+        if (hb) Vp[lane + 64] = c32_gauss_sum<R>(vb, sW);
+        for (int l = lane + 128; l < NV; l += 64) Vp[l] = c32_res_V<R>(T, y, x, l, sW, gimg);     // (radius 12 only)
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < 25) Sp[lane] = c32_res_S<R>(T, y, x, lane, sW, sB, Vp);
