@@ -345,3 +345,21 @@ extern "C" int emu_fastdiv_ok(const double* w, int R, double* c_out)
     }
     return 1;
 }
+
+// the tile-wide error budgets of k_canny_f32 for the given weights: out[9] = E_G, E_M, T0 (units of u g) for interior
+// tiles, tiles cut on one side, tiles of images narrower than 2R + 1; rho[3] = the per-pass constants behind them
+extern "C" void emu_c32_budget(const double* w, int R, float* out, double* rho)
+{
+    stp_w32 W;
+    c32_budget(w, R, &W);
+    for (int t = 0; t < 3; t++) for (int k = 0; k < 3; k++) out[3 * t + k] = W.eu[t][k];
+    rho[0] = c32_rho(w, R, -R, R);
+    double one = rho[0], any = rho[0];
+    for (int lo = -R; lo <= 0; lo++)
+        for (int hi = 0; hi <= R; hi++) {
+            const double r = c32_rho(w, R, lo, hi);
+            any = r > any ? r : any;
+            if (lo == -R || hi == R) one = r > one ? r : one;
+        }
+    rho[1] = one; rho[2] = any;
+}

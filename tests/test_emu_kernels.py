@@ -315,3 +315,35 @@ def test_other_tiled_radii(emu, emu_allnear, S, sigma):
             assert np.array_equal(got, dbg['cls']), 'image %d (S=%d, sigma %.1f)' % (k, S, sigma)
         cls32, cnt = _canny_f32(emu, full, S, R, gw)
         assert np.array_equal(cls32, dbg['cls']), 'f32 path, image %d (S=%d, sigma %.1f)' % (k, S, sigma)
+
+
+@pytest.mark.parametrize('sigma', [1.0, 1.5, 2.0, 2.5, 3.0])
+def test_tile_wide_budget_constants(emu, sigma):
+    """c32_budget's constants from first principles: rho = 3 + sum_k P_k / W recomputed here in numpy for the full window,
+    for every one-sided cut and for every cut; the budgets follow from them (E_S = rho_y + rho_x + scaling roundings,
+    E_G = 8 E_S + 16, E_M = sqrt(2) E_G + 17.6, T0 = 2 E_M + 17) and are ordered interior < one-sided < any cut < the
+    relative budget the second look uses."""
+    gw, R = O.gauss_weights(sigma)
+    gw = np.ascontiguousarray(gw)
+
+    def rho(lo, hi):
+        W = P = gw[R]
+        tot = 0.0
+        for k in range(R, 0, -1):
+            add = (gw[R - k] if -k >= lo else 0.0) + (gw[R - k] if k <= hi else 0.0)
+            P += add; W += add; tot += P
+        return 3.0 + tot / W
+    cuts = [(lo, hi) for lo in range(-R, 1) for hi in range(0, R + 1)]
+    r_int = rho(-R, R)
+    r_one = max(rho(lo, hi) for lo, hi in cuts if lo == -R or hi == R)
+    r_any = max(rho(lo, hi) for lo, hi in cuts)
+    out = np.zeros(9, np.float32); rr = np.zeros(3)
+    emu.emu_c32_budget(_p(gw), R, _p(out), _p(rr))
+    assert np.allclose(rr, [r_int, r_one, r_any], rtol=1e-12)
+    assert 5.0 < r_int < r_one <= r_any <= 3.0 + R + 1e-9          # a window of the centre tap alone: P_k = W at every step
+    for t, (r, sc) in enumerate(((r_int, 2.1), (r_one, 4.2), (r_any, 4.2))):
+        es = 2 * r + sc
+        eg = 8 * es + 16.1
+        assert eg <= out[3 * t] <= eg * 1.001
+        assert out[3 * t + 1] >= 1.41421 * out[3 * t] + 17.6 and out[3 * t + 2] >= 2 * out[3 * t + 1] + 17.0
+    assert out[0] < out[3] <= out[6] and out[3] < 234.0
