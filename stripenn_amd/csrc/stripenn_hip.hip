@@ -605,11 +605,18 @@ __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, con
     __builtin_amdgcn_wave_barrier();
 }
 
+#ifndef STP_C32_WIN
+#define STP_C32_WIN 0                /* 1: the tile's grey window reaches LDS by 16-byte LDS-DMA, one image ahead (round 4); 0: round 3's
+                                        vertical pass straight from global memory (dword loads) */
+#endif
+#ifndef STP_C32_PAIR
+#define STP_C32_PAIR 0               /* 1: vertical-pass items are column pairs (8-byte loads, packed arithmetic); 0: single columns */
+#endif
 #ifndef STP_C32_MINBLK
-#define STP_C32_MINBLK 5
+#define STP_C32_MINBLK (STP_C32_WIN ? 3 : 5)
 #endif
 #define C32_RES_WAVE_BYTES 832       /* per-wave resolver scratch inside the smoothed tile: 26 doubles, then 5 x (2R+5) floats (<= 145) */
-struct stp_c32_layout { size_t sB, sRB, sRV, sRC, sS, sV, sQ, sD, sBits, sQn, total; };
+struct stp_c32_layout { size_t sB, sRB, sRV, sRC, sS, sV, sQ, sD, sBits, sQn, sG, sWin, total; };
 static __host__ __device__ stp_c32_layout canny32_layout(int R)
 {
     const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
@@ -629,8 +636,45 @@ static __host__ __device__ stp_c32_layout canny32_layout(int R)
     L.sD = o; o += C32_DCAP * sizeof(uint16_t);
     L.sBits = o; o += (size_t)C32_NBMAX * 2 * CT_Y * sizeof(stp_u64);
     L.sQn = o; o += 32;                                       // four segment fill counts, list length, overflow flag
+    L.sG = o; o += C32_NBMAX * sizeof(float);                 // largest grey value under the tile's window, per image
+    L.sWin = o = (o + 15) & ~(size_t)15;                      // the grey window (c32_win), 16-byte pieces
+#if STP_C32_WIN
+    const int xoff = ((R + 2 + 3) / 4) * 4;
+    o += (size_t)(CT_Y + 2 * R + 4) * (2 * xoff + CT_X) * sizeof(float);
+#endif
     L.total = o;
     return L;
+}
+
+// One 16-byte LDS-DMA piece per lane: the lane's source address -> LDS byte lds_dst (wave-uniform) + 16 * lane.  M0 holds the
+// DMA's LDS base; it is compiler-reserved, so it is saved and restored inside the one statement.  The compiler does not
+// count this load: the kernel waits for it with its own s_waitcnt vmcnt(0) (stp_glds_wait) before the barrier that precedes
+// the first read of the window, and compiler-inserted waits can only over-wait (vector-memory operations retire in order).
+__device__ __forceinline__ void stp_glds16(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void stp_glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// the whole window of one image: piece i (row i / (WP/4), 16-byte column i % (WP/4)) by thread i % 256 in round i / 256.
+// Rows / columns outside the image are read as they lie in memory (guard bytes around the grey buffer, neighbouring rows)
+// and never used: the vertical pass numbers in-image columns only and zeroes out-of-image rows after the load.
+template <int R>
+__device__ __forceinline__ void canny32_win_issue(int tid, stp_tile T, const float* __restrict__ gimg, unsigned lds_win)
+{
+    using WN = c32_win<R>;
+    constexpr int NR = (WN::NV4 + 255) / 256, P4 = WN::WP / 4;
+    const float* src0 = gimg + (T.ty0 - R - 2) * STP_PITCH + (T.tx0 - WN::XOFF);
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const int i = tid + 256 * k;
+        if (i < WN::NV4) {
+            const int row = i / P4, c4 = i - row * P4;
+            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_win + (unsigned)((i & ~63) * 16)));
+            stp_glds16(src0 + row * STP_PITCH + 4 * c4, dst);
+        }
+    }
 }
 
 template <int RT>
@@ -666,7 +710,43 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     int* sQcnt = (int*)(smem + L.sQn);
     int* sDn = sQcnt + 4;
     int* sOv = sQcnt + 5;
+    float* sG = (float*)(smem + L.sG);
     const int tid = threadIdx.x, nt = blockDim.x, wv = tid >> 6, lane = tid & 63;
+    const size_t img0 = ((size_t)fl * nlev + lev) * nb;
+    // which images of this tile are live (not flat: STP_FLAT_RANGE) and the largest grey value under the tile's window:
+    // all cell loads of a lane are in flight together; every wave computes the same verdicts
+    unsigned live = nb >= 32 ? ~0u : ((1u << nb) - 1u);
+    {
+        const int wy0 = max(T.ty0 - R - 2, 0), wy1 = min(T.ty0 + CT_Y + R + 2, S);
+        const int wx0 = max(T.tx0 - R - 2, 0), wx1 = min(T.tx0 + CT_X + R + 2, S);
+        const int r0 = wy0 / GC_CY, nr = (wy1 - 1) / GC_CY - r0 + 1, c0 = wx0 / GC_CX, nc = (wx1 - 1) / GC_CX - c0 + 1;
+        const bool use_cells = cells != nullptr && nr * nc <= 64;
+        if (use_cells) {
+            int cell_off = -1;
+            if (lane < nr * nc) { const int rr = lane / nc; cell_off = (r0 + rr) * GC_COLS + c0 + (lane - rr * nc); }
+            float2 cv[C32_NBMAX];
+#pragma unroll
+            for (int bi = 0; bi < C32_NBMAX; bi++) {
+                cv[bi] = make_float2(INFINITY, -INFINITY);
+                if (bi < nb && cell_off >= 0) cv[bi] = cells[(img0 + bi) * (GC_ROWS * GC_COLS) + cell_off];
+            }
+#pragma unroll
+            for (int bi = 0; bi < C32_NBMAX; bi++) {
+                float mn = cv[bi].x, mx = cv[bi].y;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+                if (bi < nb && mx - mn < STP_FLAT_RANGE) live &= ~(1u << bi);   // flat window: no pixel of this tile can reach the low
+                                                                               // threshold (its class words stay 0)
+                if (tid == 0) sG[bi] = mx;
+            }
+        } else if (tid < C32_NBMAX) sG[tid] = 1.0000005f;     // k_gray's grey values never exceed 0.299 + 0.587 + 0.114 (+ 3 roundings)
+    }
+    live = (unsigned)__builtin_amdgcn_readfirstlane((int)live);
+#if STP_C32_WIN
+    const unsigned lds_win = (unsigned)(uintptr_t)(smem + L.sWin);        // (low half of the flat address = the LDS byte address)
+    const float* sWin = (const float*)(smem + L.sWin);
+    if (live) canny32_win_issue<R>(tid, T, gray + (img0 + __builtin_ctz(live)) * (size_t)(STP_PITCH * STP_PITCH), lds_win);
+#endif
     for (int i = tid; i < nb * 2 * CT_Y; i += nt) sBits[i] = 0ull;
     if (tid == 64) { *sDn = 0; *sOv = 0; }
     const bool yin = (T.ty0 - R - 2 >= 0) && (T.ty0 + CT_Y + R + 1 < S);
@@ -677,9 +757,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         canny_p1b(tid, nt, T, R, gw, sB);
         __syncthreads();
         c32_rb_tables<R>(tid, nt, T, sW, sB, sRB, sRV, sRC, xin);
-        __syncthreads();
     }
-    const size_t img0 = ((size_t)fl * nlev + lev) * nb;
     static_assert((CT_Y + 4) % C32_VRUN == 0, "whole row groups");
     constexpr int NR1 = ((CT_X + 2 * R + 4) * ((CT_Y + 4) / C32_VRUN) + 255) / 256;
     constexpr int NR2 = ((CT_Y + 4) * ((CT_X + 4 + CT_HRUN_R(R) - 1) / CT_HRUN_R(R)) + 255) / 256;
@@ -687,58 +765,66 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     struct { int my_lo, nmh, mx_lo, nmw; } G3;
     {
         const stp_cgeo G = ct_geo<R>(T);
+#if STP_C32_PAIR
+        const stp_c32geo2 G1 = c32_geo2<R>(T);
+#pragma unroll
+        for (int k = 0; k < NR1; k++) it1[k] = c32_p1_decode2(G1, tid + 256 * k);
+#else
         const stp_c32geo1 G1 = c32_geo1<R>(T);
 #pragma unroll
         for (int k = 0; k < NR1; k++) it1[k] = c32_p1_decode(G1, tid + 256 * k);
+#endif
 #pragma unroll
         for (int k = 0; k < NR2; k++) it2[k] = ct_p2_decode<R>(G, tid + 256 * k);
         G3.my_lo = G.my_lo; G3.nmh = G.nmh; G3.mx_lo = G.mx_lo; G3.nmw = (int)G.nmw.d;
     }
     const stp_cwin CW = canny_cand_window(T);
-    int cell_off = -1;
-    bool use_cells = cells != nullptr;
-    {
-        const int wy0 = max(T.ty0 - R - 2, 0), wy1 = min(T.ty0 + CT_Y + R + 2, S);
-        const int wx0 = max(T.tx0 - R - 2, 0), wx1 = min(T.tx0 + CT_X + R + 2, S);
-        const int r0 = wy0 / GC_CY, nr = (wy1 - 1) / GC_CY - r0 + 1, c0 = wx0 / GC_CX, nc = (wx1 - 1) / GC_CX - c0 + 1;
-        if (nr * nc > 64) use_cells = false;
-        else if (lane < nr * nc) { const int rr = lane / nc; cell_off = (r0 + rr) * GC_COLS + c0 + (lane - rr * nc); }
-    }
-    // (measured and dropped: requesting the next image's vertical-pass inputs right after the current image's vertical
-    //  pass -- 28 more live registers: 2.21 ms with spills at 5 waves per SIMD, 2.58 ms at 4, against 2.16 ms without;
-    //  18 instead of 12 output rows per vertical-pass item (19 % fewer row loads, 168 instead of 252 items): 1.96 vs 1.88 ms;
-    //  the vertical pass on two columns per lane with packed f32 instructions -- half its VALU instructions, same time:
-    //  it waits for its loads, 0.79 ms of the kernel's 1.9 with the pass alone;
-    //  settling the undecidable pixels in a kernel of their own from a global list -- 0.51 ms for it (cold grey rows,
-    //  bleed-over factors recomputed) against 0.25 ms in here, and 6 instead of 5 waves per SIMD bought this kernel nothing)
-    for (int bi = 0; bi < nb; bi++) {
+    const int et = c32_budget_of(xin && yin, S, R);  // tile-wide budget: full windows everywhere, or the worst cut
+    // (measured and dropped in round 3, on the dword-load form: prefetching the next image's inputs into registers, 18-row
+    //  items, two packed columns per lane, the resolver in a kernel of its own, 6 waves per SIMD -- DESIGN.md section 3)
+    int prev = -1;                                   // the image whose class test has just run (overflow check below)
+    while (live) {                                   // workgroup-uniform
+        const int bi = __builtin_ctz(live);
+        live &= live - 1;
         const size_t img = img0 + bi;
         const float* gimg = gray + img * (STP_PITCH * STP_PITCH);
-        float gmax = 1.0000005f;                     // k_gray's grey values never exceed 0.299 + 0.587 + 0.114 (+ 3 roundings)
-        if (use_cells) {
-            float mn = INFINITY, mx = -INFINITY;
-            if (cell_off >= 0) { const float2 v = cells[img * (GC_ROWS * GC_COLS) + cell_off]; mn = v.x; mx = v.y; }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
-            if (mx - mn < STP_FLAT_RANGE) continue;  // flat window: no pixel of this tile can reach the low threshold (words stay 0)
-            gmax = mx;
+#if STP_C32_WIN
+        stp_glds_wait();                             // this wave's pieces of the window have landed ...
+#endif
+        __syncthreads();                             // ... and everybody's; the class test of the previous image is done
+                                                     // (sM / sQ alias sV); first pass: the tables are written
+        if (tid == 64 && prev >= 0 && *sOv) {        // the previous image overflowed the tile's list: the whole tile-image is redone exactly
+            *sOv = 0;
+            *sDn = C32_DCAP;
+            xflags[(img0 + prev) * TPI + tile] = 1;
         }
-        const int et = c32_budget_of(xin && yin, S, R);  // tile-wide budget: full windows everywhere, or the worst cut
-        const stp_c32tol E = c32_tol_u(gmax, W32.eu[et][0], W32.eu[et][1], W32.eu[et][2]);
+        prev = bi;
+        const stp_c32tol E = c32_tol_u(sG[bi], W32.eu[et][0], W32.eu[et][1], W32.eu[et][2]);
 #pragma unroll
         for (int k = 0; k < NR1; k++) {
             int it = it1[k];
             asm volatile("" : "+v"(it));              // see k_canny_pipe
             if (it >= 0) {
-                if (it >> 16) c32_p1_zero(it & 255, (it >> 8) & 255, sV);
+                if ((it >> 16) & 1) c32_p1_zero(it & 255, (it >> 8) & 255, sV);
+#if STP_C32_WIN
+                else if (yin) c32_p1_item_win<R, true>(T, it & 255, (it >> 8) & 255, W32, sWin, sV);
+                else c32_p1_item_win<R, false>(T, it & 255, (it >> 8) & 255, W32, sWin, sV);
+#elif STP_C32_PAIR
+                else if (yin) c32_p1_item2<R, true>(T, it & 255, (it >> 8) & 255, (it >> 17) & 1, W32, gimg, sV);
+                else c32_p1_item2<R, false>(T, it & 255, (it >> 8) & 255, (it >> 17) & 1, W32, gimg, sV);
+#else
                 else if (yin) c32_p1_item<R, true>(T, it & 255, (it >> 8) & 255, W32, gimg, sV);
                 else c32_p1_item<R, false>(T, it & 255, (it >> 8) & 255, W32, gimg, sV);
+#endif
             }
         }
         __syncthreads();
+#if STP_C32_WIN
+        // the window is free: the next live image's pieces travel while this image goes through its other phases
+        if (live) canny32_win_issue<R>(tid, T, gray + (img0 + __builtin_ctz(live)) * (size_t)(STP_PITCH * STP_PITCH), lds_win);
+#endif
 #if STP_ABLATE_C32 == 1                  /* timing-only builds: stop after the vertical pass ... */
         if (tid == 0) low[img * (STP_FRAME_MAX * STP_NW)] = (stp_u64)sV[70];
-        __syncthreads();
         continue;
 #endif
 #pragma unroll
@@ -753,7 +839,6 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         __syncthreads();
 #if STP_ABLATE_C32 == 2                  /* ... after the horizontal pass ... */
         if (tid == 0) low[img * (STP_FRAME_MAX * STP_NW)] = (stp_u64)sS[70];
-        __syncthreads();
         continue;
 #endif
         if (!(xin && yin)) {
@@ -763,18 +848,15 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         canny32_mag_rows(tid, CW, G3.my_lo, G3.nmh, G3.mx_lo, G3.nmw, E.thr, sS, sM, sQ, sQcnt);
         __syncthreads();
 #if STP_ABLATE_C32 == 3                  /* ... after the magnitudes and the candidate collection ... */
-        __syncthreads();
         continue;
 #endif
         canny32_nms_queue(tid, bi, T, E, sS, sM, sQ, sQcnt, sBits + bi * 2 * CT_Y, sD, sDn, sOv);
-        __syncthreads();     // sM / sQ alias sV: the class test must be done before the next vertical pass writes it
-        if (tid == 64) {
-            if (*sOv) {                              // this image overflowed the tile's list: the whole tile-image is redone exactly
-                *sOv = 0;
-                *sDn = C32_DCAP;
-                xflags[img * TPI + tile] = 1;
-            }
-        }
+    }
+    __syncthreads();
+    if (tid == 64 && prev >= 0 && *sOv) {            // (the last image's overflow)
+        *sOv = 0;
+        *sDn = C32_DCAP;
+        xflags[(img0 + prev) * TPI + tile] = 1;
     }
     __syncthreads();
 #if STP_ABLATE_C32 == 0                  /* (4: ... or with the undecidable pixels left unsettled) */
