@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <float.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #define STP_HD __host__ __device__ __forceinline__
@@ -233,6 +234,97 @@ STP_HD void gray_wrow_get(int lane, int strip, int r, stp_tile T, const double* 
 #endif
     for (int c = 0; c < 3; c++) { st->w0[c] = st->w1[c]; st->w1[c] = w2[c]; }
 }
+
+// ---- certified grey for the 3 x 3 mean filter (round 4, k_gray_c3) ---------------------------------------------------
+// Every vector instruction of k_gray costs the same ~4.25 cycles per wave and SIMD -- an f64 add like an f64 division
+// step (tools/ubench_valu.hip) -- so what the kernel pays for is the NUMBER of operations per grey pixel: two f64
+// divisions per contact pixel, two compares + two products + nine sequential additions per image pixel.  The grey value
+// is the FLOAT rounding of the blurred green plane, though, so -- exactly as stp_gauss_fma.h does for the Gaussian
+// passes -- a cheaper f64 evaluation decides it whenever it lands far enough from a float rounding boundary:
+//   reference (getStripe.py:889-913, ImageProcessing.py:15-31, cv.filter2D):
+//       g = clip(((255 (M - D)) / M) / 255, 0, 1)                         three roundings after M - D
+//       adj = 0 if g <= 0, 1 if g > b, else k g     (k = 1 / b)            one
+//       blur = (((0 + kv adj_00) + kv adj_01) + ... + kv adj_22)          one per product (kv = 1 / 9), one per addition
+//       G = float(clip(blur, 0, 1))
+//   here:   g~ = clip((M - D) rM, 0, 1)               rM = RN(1 / M): two roundings after the same M - D
+//           a = min(g~, b)
+//           S = ((a_00 + a_01) + a_02  +  (a_10 + a_11) + a_12)  +  (a_20 + a_21) + a_22      row sums shared by three outputs
+//           blur~ = S c_b                             c_b = RN(k kv)
+// Bound (u = 2^-53; every quantity is >= 0, so every bound is relative to the sums themselves).  Let
+// T = sum_i kv k min(max(g_i, 0), b) in real arithmetic on the machine numbers kv, k, b, g_i.
+//   reference: a product is kv k g_i (1 + 2.01 u) when 0 < g_i <= b; when g_i > b it is kv while the term of T is
+//     kv k b = kv (1 + d), |d| <= u (k = RN(1 / b)); nine non-negative terms added in sequence: |blur - T| <= 10.1 u T.
+//   here: g~_i = g_i (1 + 5.01 u) (the rounding of M - D is common to both; 1 / M, the product against 255 x, / M, / 255);
+//     min(., b) is monotone and 1-Lipschitz, so |a_i - min(g_i, b)| <= 5.01 u min(g_i, b) also when g_i and g~_i lie on
+//     different sides of b; four levels of additions: 4.01 u; c_b and the final product: 2.01 u:  |blur~ - T| <= 11.1 u T.
+//   |blur~ - blur| <= 21.2 u T < 22 ulp(blur~)  (u x < ulp(x)).  The clip at 1 changes nothing: a sum above 1 exceeds it by
+//   ulps and converts to 1.0f like the clipped one.  A non-zero g is >= 2^-53 (M - D is a difference of doubles relative
+//   to M), so blur never comes near the float denormals, where the conversion drops more than 29 bits.
+// So float(blur~) == float(clip(blur)) unless blur~ lies within 22 ulp(f64) of a float rounding boundary; the test uses
+// STP_GRAY_NEAR = 64 (1.2e-7 of the outputs) and a flagged lane redoes its strip of outputs from the band in the
+// reference's own operations (stp_gray_exact9).  M must be a normal number for RN(1 / M) to be finite: the host sends any
+// other level to the exact kernel.  tests/emu: 4e7 random and adversarial windows, and the golden grey images.
+#define STP_GRAY_NEAR 64u
+STP_HD double stp_gplane_fast(double D, double M, double rM)
+{
+    double t = (M - D) * rM;
+    t = t < 0.0 ? 0.0 : t;
+    return t > 1.0 ? 1.0 : t;
+}
+STP_HD unsigned stp_near_word(double v, unsigned near)      // see stp_fma_near_word: < 16 * near when within `near` ulp of a boundary
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lo = (unsigned)__double2loint(v);
+#else
+    unsigned long long bb;
+    memcpy(&bb, &v, 8);
+    const unsigned lo = (unsigned)bb;
+#endif
+    return (lo << 3) + ((near - 0x10000000u) << 3);
+}
+// RGB2GRAY of (1, G, G) in float, left to right; the red plane is the constant 1 through the same filter
+STP_HD float stp_gray_rgb(float g32)
+{
+    const double kv = 1.0 / 9.0;
+    double rb = 0.0;
+    for (int t = 0; t < 9; t++) rb = rb + kv * 1.0;
+    if (rb < 0.0) rb = 0.0;
+    if (rb > 1.0) rb = 1.0;
+    const float r32 = (float)rb;
+    float v = r32 * 0.299f;
+    v = v + g32 * 0.587f;
+    v = v + g32 * 0.114f;
+    return v;
+}
+// the reference's operations for one grey pixel from its nine contact values (row-major, NaN -> 0 and border reflection
+// already applied): the rare path of k_gray_c3 and the checker of its certification test
+STP_HD double stp_gray_exact9_blur(const double* D9, double M, double b)
+{
+    const double k = (1.0 - 0.0) / (b - 0.0), kv = 1.0 / 9.0;
+    double acc = 0.0;
+    for (int i = 0; i < 9; i++) acc = acc + kv * stp_bright_px(stp_gplane_px(D9[i], M), b, k);
+    if (acc < 0.0) acc = 0.0;
+    if (acc > 1.0) acc = 1.0;
+    return acc;
+}
+STP_HD float stp_gray_exact9(const double* D9, double M, double b) { return stp_gray_rgb((float)stp_gray_exact9_blur(D9, M, b)); }
+// the cheap evaluation of the same pixel from the nine g~ values; *near gets the boundary word of blur~
+STP_HD double stp_gray_c3_blur(const double* g9, double b, double cb)
+{
+    double rs[3];
+    for (int r = 0; r < 3; r++) {
+        const double a0 = fmin(g9[3 * r], b), a1 = fmin(g9[3 * r + 1], b), a2 = fmin(g9[3 * r + 2], b);
+        rs[r] = (a0 + a1) + a2;
+    }
+    return ((rs[0] + rs[1]) + rs[2]) * cb;
+}
+STP_HD float stp_gray_c3_px(const double* g9, double b, double cb, unsigned* near)
+{
+    const double blur = stp_gray_c3_blur(g9, b, cb);
+    *near = stp_near_word(blur, STP_GRAY_NEAR);
+    return stp_gray_rgb((float)blur);
+}
+STP_HD double stp_gray_cb(double b) { return ((1.0 - 0.0) / (b - 0.0)) * (1.0 / 9.0); }
 
 // ---------------------------------------------------------------------------------------------
 // kernel B (k_canny): grey -> Gaussian (f32 rounding after each axis) -> /bleed -> Sobel ->

@@ -123,6 +123,153 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
     }
 }
 
+// K-A for the 3 x 3 mean filter, certified (stp_phases.h, "certified grey"): the same tile / strip geometry as k_gray<1> -- one
+// workgroup per (tile, level, frame), the g~ plane of the tile in LDS, each wave an 8-row strip with lane = column and no
+// workgroup barrier in the brightness loop -- but per image pixel one min, four additions (row sums shared by the three
+// outputs below each other), one product and the conversion instead of two compares, two products and nine additions, and
+// per contact pixel a subtraction and a product instead of two divisions.  A lane whose strip holds an output within
+// STP_GRAY_NEAR ulp of a float rounding boundary recomputes its eight outputs from the band in the reference's operations.
+// Grey images and cell minima / maxima are bit for bit those of k_gray<1> (STP_GRAY=exact selects that kernel).
+// the rare path: one lane's strip of eight outputs from the band in the reference's operations, stored; returns the
+// smallest / largest bit pattern stored (not inlined: it must not cost the common path registers)
+__device__ __noinline__ static uint2 gray_c3_redo(const double* __restrict__ band, int W, int hw, int64_t st, const int16_t* s_ny,
+                                                  const int16_t* s_nx, int yy0, int xx, int nrows, double M, double b, float* gcol)
+{   // (yy0 + j, xx): window coordinates of the output pixels' centres in the (GT_Y + 2) x (GT_X + 2) plane
+    unsigned vmn = 0x7F800000u, vmx = 0u;
+#pragma unroll 1
+    for (int j = 0; j < nrows; j++) {
+        const double k = (1.0 - 0.0) / (b - 0.0), kv = 1.0 / 9.0;         // as stp_gray_exact9, one contact value at a time
+        double acc = 0.0;
+#pragma unroll 1
+        for (int i = 0; i < 9; i++) {
+            const int oy = s_ny[yy0 + j - 1 + i / 3], ox = s_nx[xx - 1 + i % 3];
+            double d = band[(st + oy) * (int64_t)W + (ox - oy + hw)];
+            if (d != d) d = 0.0;
+            acc = acc + kv * stp_bright_px(stp_gplane_px(d, M), b, k);
+        }
+        if (acc < 0.0) acc = 0.0;
+        if (acc > 1.0) acc = 1.0;
+        const float v = stp_gray_rgb((float)acc);
+        gcol[j * STP_PITCH] = v;
+        const unsigned bits = __float_as_uint(v);
+        vmn = min(vmn, bits); vmx = max(vmx, bits);
+    }
+    return make_uint2(vmn, vmx);
+}
+__global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band, int W, int hw,
+                                                  const int32_t* __restrict__ fstart, const int32_t* __restrict__ fS,
+                                                  const int16_t* __restrict__ fnz, int f0,
+                                                  const double* __restrict__ Mlev, int nlev,
+                                                  const double* __restrict__ bvals, int nb,
+                                                  float* __restrict__ gray, float2* __restrict__ cells)
+{
+    constexpr int HH = GT_Y + 2, WW = GT_X + 2, N = HH * WW, IT = (N + 255) / 256;
+    __shared__ double sg[N], sd[N];
+    __shared__ int16_t s_ny[HH], s_nx[WW];
+    const int fl = blockIdx.z, f = f0 + fl;
+    const int S = fS[f];
+    if (S == 0) return;
+    const int tpr = (STP_FRAME_MAX + GT_X - 1) / GT_X;
+    stp_tile T;
+    T.S = S; T.ty0 = (blockIdx.x / tpr) * GT_Y; T.tx0 = (blockIdx.x % tpr) * GT_X;
+    if (T.ty0 >= S || T.tx0 >= S) return;
+    const int tid = threadIdx.x;
+    const int16_t* nzf = fnz + (size_t)f * STP_FRAME_MAX;
+    if (tid < HH) s_ny[tid] = nzf[stp_refl101(min(T.ty0 + tid - 1, S), S)];
+    if (tid >= 64 && tid < 64 + WW) s_nx[tid - 64] = nzf[stp_refl101(min(T.tx0 + (tid - 64) - 1, S), S)];
+    __syncthreads();
+    const int64_t st = fstart[f];
+    // the tile's contact values are read ONCE for all maxpixel levels (one workgroup walks the levels: the two dependent
+    // global round trips of this prologue are paid once per tile, not once per level)
+    // (parked in LDS, each thread its own elements: 36 KB per workgroup -- four per CU, as the registers allow anyway)
+    {
+        double v[IT];
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = min(tid + k * 256, N - 1);
+            const int yy = i / WW, xx = i - yy * WW;
+            const int oy = s_ny[yy], ox = s_nx[xx];
+            v[k] = band[(st + oy) * (int64_t)W + (ox - oy + hw)];
+        }
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = tid + k * 256;
+            if (i < N) sd[i] = (v[k] != v[k]) ? 0.0 : v[k];                  // nantozero (getStripe.py:809)
+        }
+    }
+    const int lane = tid & 63, strip = tid >> 6;
+    const int x = T.tx0 + lane, y0 = T.ty0 + strip * GS_ROWS;
+    const bool xin = x < S;
+    const int nrows = min(GS_ROWS, S - y0);                                  // rows of the strip inside the image (wave-uniform)
+    const double* g0 = sg + (strip * GS_ROWS) * WW + lane;                   // g~ of (strip row -1, columns x-1 .. x+1)
+    for (int lev = 0; lev < nlev; lev++) {
+        const double M = Mlev[lev], rM = 1.0 / M;
+        if (lev) __syncthreads();                                            // everybody is done with the previous level's plane
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int i = tid + k * 256;
+            if (i < N) {
+                const int yy = i / WW, xx = i - yy * WW;
+                const bool in = (T.ty0 + yy - 1 < S + 1) && (T.tx0 + xx - 1 < S + 1);
+                sg[i] = in ? stp_gplane_fast(sd[i], M, rM) : 0.0;
+            }
+        }
+        __syncthreads();
+        for (int bi = 0; bi < nb; bi++) {
+            const size_t img = ((size_t)fl * nlev + lev) * nb + bi;
+            float* gimg = gray + img * (size_t)(STP_PITCH * STP_PITCH) + (size_t)y0 * STP_PITCH + x;
+            const double b = bvals[bi], cb = stp_gray_cb(b);
+            float out[GS_ROWS];
+            unsigned far = 0xFFFFFFFFu;
+            double rs0 = 0.0, rs1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < GS_ROWS + 2; r++) {
+                const double* g = g0 + r * WW;
+                const double a0 = fmin(g[0], b), a1 = fmin(g[1], b), a2 = fmin(g[2], b);
+                const double rs2 = (a0 + a1) + a2;
+                if (r >= 2) {
+                    const double blur = ((rs0 + rs1) + rs2) * cb;
+                    const unsigned nw = stp_near_word(blur, STP_GRAY_NEAR);
+                    far = nw < far ? nw : far;
+                    out[r - 2] = stp_gray_rgb((float)blur);
+                }
+                rs0 = rs1; rs1 = rs2;
+            }
+            unsigned vmn = 0x7F800000u, vmx = 0u;                            // +inf / +0: a cell without pixels unites to nothing
+            if (xin && nrows > 0) {
+                if (far < 16u * STP_GRAY_NEAR) {                              // ~1e-6 of the lanes: the reference's own operations
+                    const uint2 mm = gray_c3_redo(band, W, hw, st, s_ny, s_nx, strip * GS_ROWS + 1, lane + 1, nrows, M, b, gimg);
+                    vmn = mm.x; vmx = mm.y;
+                } else if (nrows == GS_ROWS) {                                // (whole strip inside the image: no test per row)
+#pragma unroll
+                    for (int j = 0; j < GS_ROWS; j++) {
+                        gimg[j * STP_PITCH] = out[j];
+                        const unsigned bits = __float_as_uint(out[j]);       // grey values are >= +0: their bit patterns order like the values
+                        vmn = min(vmn, bits); vmx = max(vmx, bits);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < GS_ROWS; j++)
+                        if (j < nrows) {
+                            gimg[j * STP_PITCH] = out[j];
+                            const unsigned bits = __float_as_uint(out[j]);
+                            vmn = min(vmn, bits); vmx = max(vmx, bits);
+                        }
+                }
+            }
+            // min / max of the strip's grey values per 16-column cell (see STP_FLAT_RANGE)
+#pragma unroll
+            for (int o = 1; o < GC_CX; o <<= 1) {
+                vmn = min(vmn, (unsigned)__shfl_xor((int)vmn, o));
+                vmx = max(vmx, (unsigned)__shfl_xor((int)vmx, o));
+            }
+            const int crow = T.ty0 / GC_CY + strip, ccol = (T.tx0 + lane) / GC_CX;
+            if (cells && (lane & (GC_CX - 1)) == 0 && crow < GC_ROWS && ccol < GC_COLS)
+                cells[(img * GC_ROWS + crow) * GC_COLS + ccol] = make_float2(__uint_as_float(vmn), __uint_as_float(vmx));
+        }
+    }
+}
+
 // NMS class of the tile's pixels and bit-plane packing.  Each wave owns 8 rows (lane = x, CT_X == 64):
 // it first collects the pixels whose magnitude reaches the low threshold (the only ones that can get a
 // class) into a wave-private LDS queue by ballot + popcount, then runs the interpolation test densely
@@ -1880,7 +2027,7 @@ static bool canny_tiled_radius(int R) { return R == 4 || R == 6 || R == 8 || R =
 // shared by stp_stripe_search and stp_dbg_stages: run the three image kernels on frames
 // [f0, f0+nf) for n_levels levels; buffers sized by the caller.
 static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, int f0, int nf,
-                     const double* d_M, int nlev, const double* d_b, const double* d_w, float* d_gray, stp_u64* d_low,
+                     const double* h_M /* the levels on the host */, const double* d_M, int nlev, const double* d_b, const double* d_w, float* d_gray, stp_u64* d_low,
                      stp_u64* d_high, stp_drec* d_recs, int32_t* d_cnt, int want_dbg, stp_u64* d_dbg, int16_t* d_dbgc,
                      int rcap = STP_RCAP)
 {
@@ -1890,6 +2037,9 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     const int nb = prm->n_bright, a = prm->bfilter / 2, R = prm->gauss_radius;
     const int ipf = nlev * nb;
     const size_t nimg = (size_t)nf * ipf;
+    bool levels_normal = true;                     // the certified grey kernel forms 1 / M and 1 / b once per level / image
+    for (int i = 0; i < nlev; i++) levels_normal = levels_normal && h_M[i] > 1e-280 && h_M[i] < 1e280;
+    for (int i = 0; i < nb; i++) levels_normal = levels_normal && prm->bright[i] > 1e-6 && prm->bright[i] < 1e6;
     double px = 0;
     for (int i = 0; i < nf; i++) px += (double)fr->h_S[f0 + i] * fr->h_S[f0 + i];
     const double ipx = px * ipf;   // image pixels in this launch
@@ -1904,7 +2054,13 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     {
         prof_scope ps(ctx, "gray", ipx * 12.0);          // stage A of SURVEY 8(d): 8 B read + 4 B written per image px
         const int tiles = ((STP_FRAME_MAX + GT_X - 1) / GT_X) * ((STP_FRAME_MAX + GT_Y - 1) / GT_Y);
-        if (a == 1)
+        // STP_GRAY=exact selects k_gray<1> (every operation of the reference); the certified kernel needs finite 1 / M
+        const char* gray_env = getenv("STP_GRAY");        // read per call: the tests compare both kernels in one process
+        const bool gray_exact = (gray_env && strcmp(gray_env, "exact") == 0) || !levels_normal;
+        if (a == 1 && !gray_exact)
+            hipLaunchKernelGGL(k_gray_c3, dim3(tiles, 1, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
+                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (float2*)p_cells);
+        else if (a == 1)
             hipLaunchKernelGGL(k_gray<1>, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
                                fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray, (float2*)p_cells);
         else
@@ -2082,7 +2238,7 @@ static int search_enqueue(stp_ctx* ctx, stp_search* s)
         const int f0 = c * chunk;
         const int nf = (fr->n - f0 < chunk) ? fr->n - f0 : chunk;
         const size_t nimg = (size_t)nf * ipf;
-        int rc = run_chain(ctx, fr, prm, f0, nf, dM, n_levels, dB, dW, (float*)pGray, (stp_u64*)pLow, (stp_u64*)pHigh,
+        int rc = run_chain(ctx, fr, prm, f0, nf, s->M.data(), dM, n_levels, dB, dW, (float*)pGray, (stp_u64*)pLow, (stp_u64*)pHigh,
                            (stp_drec*)pRecs, (int32_t*)pCnt, 0, nullptr, nullptr, rcap);
         if (rc) return rc;
         {
@@ -2243,7 +2399,7 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
     HIPCHK(hipMemcpyAsync(bB.p, prm->bright, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(bW.p, prm->gauss_w, (2 * prm->gauss_radius + 1) * sizeof(double), hipMemcpyHostToDevice,
                           ctx->stream));
-    rc = run_chain(ctx, fr, prm, f, 1, (const double*)bM.p, 1, (const double*)bB.p, (const double*)bW.p, dGray,
+    rc = run_chain(ctx, fr, prm, f, 1, &M, (const double*)bM.p, 1, (const double*)bB.p, (const double*)bW.p, dGray,
                    (stp_u64*)bLow.p, (stp_u64*)bHigh.p, (stp_drec*)bRecs.p, (int32_t*)bCnt.p, 1, (stp_u64*)bDbg.p,
                    (int16_t*)bDbgc.p, STP_RCAP_MAX);
     if (rc) return rc;

@@ -135,6 +135,85 @@ void emu_gray(const double* band, int W, int hw, int64_t st, const int16_t* nz, 
         }
 }
 
+// k_gray_c3 (certified grey, bfilter 3), pixel by pixel: the cheap evaluation from the nine g~ values, the reference's
+// operations where the near-boundary test flags it; counts[0] = outputs, counts[1] = flagged ones
+void emu_gray_c3(const double* band, int W, int hw, int64_t st, const int16_t* nz, int S, double M, const double* bvals,
+                 int nb, float* gray /* nb images, pitch 400 */, long long* counts)
+{
+    const double rM = 1.0 / M;
+    long long nout = 0, nflag = 0;
+    for (int bi = 0; bi < nb; bi++) {
+        const double b = bvals[bi], cb = stp_gray_cb(b);
+        for (int y = 0; y < S; y++)
+            for (int x = 0; x < S; x++) {
+                double D9[9], g9[9];
+                for (int i = 0; i < 9; i++) {
+                    const int oy = nz[stp_refl101(y - 1 + i / 3, S)], ox = nz[stp_refl101(x - 1 + i % 3, S)];
+                    double d = band[(st + oy) * (int64_t)W + (ox - oy + hw)];
+                    if (d != d) d = 0.0;
+                    D9[i] = d;
+                    g9[i] = stp_gplane_fast(d, M, rM);
+                }
+                unsigned near;
+                float v = stp_gray_c3_px(g9, b, cb, &near);
+                nout++;
+                if (near < 16u * STP_GRAY_NEAR) { v = stp_gray_exact9(D9, M, b); nflag++; }
+                gray[(size_t)bi * STP_PITCH * STP_PITCH + y * STP_PITCH + x] = v;
+            }
+    }
+    if (counts) { counts[0] = nout; counts[1] = nflag; }
+}
+// The claim behind k_gray_c3 on n random 3 x 3 windows: an output the near-boundary test does not flag is the reference's
+// float.  mode 0: contact values spread over [0, 1.2 M] with zeros, saturated and near-saturated pixels mixed in;
+// mode 1: all nine values close to each other (flat regions); mode 2: values at M (1 - 2^-k) and M b (1 +- few ulp).
+// Returns the number of unflagged outputs that differ; *flagged counts the flagged ones, *worst is the largest
+// |blur~ - blur| in ulp(f64) seen.
+long long emu_certify_gray(long long n, unsigned long long seed, int mode, long long* flagged, double* worst)
+{
+    unsigned long long sst = seed * 0x9E3779B97F4A7C15ull + 12345ull;
+    auto rnd = [&]() { sst ^= sst << 13; sst ^= sst >> 7; sst ^= sst << 17; return sst; };
+    auto uni = [&]() { return (double)(rnd() >> 11) * (1.0 / 9007199254740992.0); };
+    const double bl[6] = {0.5, 0.6, 0.7, 0.7999999999999999, 0.8999999999999999, 0.9999999999999999};
+    long long bad = 0, nfl = 0;
+    double w = 0.0;
+    for (long long it = 0; it < n; it++) {
+        const double M = ldexp(1.0 + uni(), (int)(rnd() % 20) - 10);
+        const double b = (rnd() & 7) ? bl[rnd() % 6] : 0.3 + 0.7 * uni();
+        const double rM = 1.0 / M, cb = stp_gray_cb(b);
+        double D9[9], g9[9];
+        const double centre = uni() * 1.1 * M;
+        for (int i = 0; i < 9; i++) {
+            double d;
+            const unsigned sel = (unsigned)(rnd() % 16);
+            if (mode == 1) d = centre * (1.0 + (uni() - 0.5) * 1e-3);
+            else if (mode == 2) {
+                if (sel < 6) d = M * (1.0 - ldexp(1.0, -(int)(rnd() % 52) - 1));
+                else if (sel < 12) d = M * (1.0 - b) * (1.0 + ((double)(rnd() % 9) - 4.0) * 2.220446049250313e-16);
+                else d = uni() * M;
+            } else {
+                if (sel == 0) d = 0.0;
+                else if (sel == 1) d = M * (1.0 + uni());            // beyond M: blue 0
+                else if (sel == 2) d = M * (1.0 - b) * uni();        // above the brightness cut: saturated
+                else d = uni() * 1.2 * M;
+            }
+            if (d < 0.0) d = 0.0;
+            D9[i] = d;
+            g9[i] = stp_gplane_fast(d, M, rM);
+        }
+        const double be = stp_gray_exact9_blur(D9, M, b), ba = stp_gray_c3_blur(g9, b, cb);
+        if (be > 0.0 && be < 1.0) {
+            const double ulp = ldexp(1.0, ilogb(ba > be ? ba : be) - 52), e = fabs(ba - be) / ulp;
+            if (e > w) w = e;
+        }
+        unsigned near;
+        const float va = stp_gray_c3_px(g9, b, cb, &near), ve = stp_gray_exact9(D9, M, b);
+        if (near < 16u * STP_GRAY_NEAR) nfl++;
+        else if (memcmp(&va, &ve, 4) != 0) bad++;
+    }
+    *flagged = nfl; *worst = w;
+    return bad;
+}
+
 void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double* w, stp_u64* low, stp_u64* high, int blocked)
 {
     // as in the library: the grey image sits between two guard regions (filled with NaN here: whatever the

@@ -57,6 +57,9 @@ def test_emulated_kernels_match_oracle(emu, golden_stages, chr7, ci):
     assert np.array_equal(nz[:S], g[p + 'nz'])
     gray = np.zeros((6, 400, 400), np.float32)
     emu.emu_gray(_p(band), W, hw, C.c_int64(start), _p(nz), S, C.c_double(M), _p(bvals), 6, 1, _p(gray))
+    gray_c3 = np.zeros((6, 400, 400), np.float32); c3n = np.zeros(2, np.int64)     # k_gray_c3: the certified evaluation
+    emu.emu_gray_c3(_p(band), W, hw, C.c_int64(start), _p(nz), S, C.c_double(M), _p(bvals), 6, _p(gray_c3), _p(c3n))
+    assert np.array_equal(gray_c3, gray) and c3n[0] == 6 * S * S and c3n[1] < 20
     D, nzo = O.frame_dense(chr7.block, start, end)
     D = np.ascontiguousarray(D[np.ix_(nzo, nzo)])
     gp = O.gplane(D, M)
@@ -210,6 +213,23 @@ def test_fma_certification_random_windows(emu, golden_stages):
         assert bad == 0
         assert worst.value <= R + 1
         assert flagged.value < 100          # ~64 / 2^29 of the outputs
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_gray_certification_random_windows(emu, mode):
+    """The claim behind k_gray_c3 (stp_phases.h, "certified grey"): whenever the near-boundary test does not flag an
+    output, the grey value from min / shared row sums / one product equals the one from the reference's two divisions,
+    two products and nine sequential additions.  1.4e7 random 3 x 3 windows per mode (spread values with zeros and
+    saturated pixels; flat windows; values at M (1 - 2^-k) and at the brightness cut +- ulps): no unflagged mismatch,
+    the two f64 sums within the 22 ulp of the derivation, ~2 * 64 / 2^29 of the outputs flagged."""
+    emu.emu_certify_gray.restype = C.c_longlong
+    flagged = C.c_longlong(0); worst = C.c_double(0)
+    n = 14000000
+    bad = emu.emu_certify_gray(C.c_longlong(n), C.c_ulonglong(1234 + mode), mode, C.byref(flagged), C.byref(worst))
+    assert bad == 0
+    assert worst.value <= 22.0
+    # expected n * 2 * 64 / 2^29 = 3.3 on spread data; sums of few-bit values (mode 2) sit on half-way patterns more often
+    assert flagged.value < (40 if mode < 2 else n // 1000)
 
 
 @pytest.mark.parametrize('sigma,key', [(2.0, 'gw_2p0'), (2.5, 'gw_2p5')])
