@@ -119,13 +119,12 @@ STP_HD void c32_fma2(float p0, float p1, float w, float* a0, float* a1)
 #endif
 }
 
-// ---- vertical pass, one item = column xx of the tile window x C32_VRUN output rows from yy0 (as canny_p1_item, with
+// ---- vertical pass, one item = column xx of the tile window x C32_VRUN_R(R) output rows from yy0 (as canny_p1_item, with
 // its own run length: f32 windows are half the registers of k_canny_pipe's f64 ones).  Numbering as ct_p1_decode:
 // in-image columns first, then one zero-fill item per (outside column, row group). ----
-#ifndef C32_VRUN
-#define C32_VRUN 12
-#endif
-struct stp_c32geo1 { int c_lo, ncv, nzc, ng; };
+#define C32_VRUN_R(R) ((R) <= 8 ? 12 : 6)      /* output rows per item: the window of VRUN + 2R rows must fit the registers of
+                                                  five waves per SIMD (96): 28 at radius 8, 26 / 30 at radii 10 / 12 */
+struct stp_c32geo1 { int c_lo, ncv, nzc, ng, vrun; };
 template <int R>
 STP_HD stp_c32geo1 c32_geo1(stp_tile T)
 {
@@ -136,7 +135,8 @@ STP_HD stp_c32geo1 c32_geo1(stp_tile T)
     g.ncv = c_hi - g.c_lo;
     g.nzc = GW - g.ncv;
     const int yy_hi = T.S - T.ty0 + 2 < VH ? T.S - T.ty0 + 2 : VH;
-    g.ng = (yy_hi + C32_VRUN - 1) / C32_VRUN;
+    g.vrun = C32_VRUN_R(R);
+    g.ng = (yy_hi + g.vrun - 1) / g.vrun;
     return g;
 }
 // returns xx | yy0 << 8 | zero << 16, or -1 past the last item
@@ -145,20 +145,21 @@ STP_HD int c32_p1_decode(stp_c32geo1 G, int i)
     const int nval = G.ncv * G.ng, nzero = G.nzc * G.ng;
     if (i < nval) {
         const int yg = i / G.ncv;
-        return (G.c_lo + (i - yg * G.ncv)) | (yg * C32_VRUN) << 8;
+        return (G.c_lo + (i - yg * G.ncv)) | (yg * G.vrun) << 8;
     }
     if (i < nval + nzero) {
         const int j = i - nval, yg = j / G.nzc, zc = j - yg * G.nzc;
-        return (zc < G.c_lo ? zc : zc + G.ncv) | (yg * C32_VRUN) << 8 | 1 << 16;
+        return (zc < G.c_lo ? zc : zc + G.ncv) | (yg * G.vrun) << 8 | 1 << 16;
     }
     return -1;
 }
+template <int R>
 STP_HD void c32_p1_zero(int xx, int yy0, float* sVT)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int q = 0; q < C32_VRUN; q++) sVT[xx * CT_VP + yy0 + q] = 0.0f;
+    for (int q = 0; q < C32_VRUN_R(R); q++) sVT[xx * CT_VP + yy0 + q] = 0.0f;
 }
 // one vertical-pass item from any source: `col` points at the window element (first input row of the item, column xx),
 // `pitch` floats from one row to the next -- the grey image itself (pitch STP_PITCH; the CPU replay and tiles of the
@@ -166,7 +167,7 @@ STP_HD void c32_p1_zero(int xx, int yy0, float* sVT)
 template <int R, bool YIN>
 STP_HD void c32_p1_item_src(stp_tile T, int xx, int yy0, const stp_w32& W, const float* col, int pitch, float* sVT)
 {
-    constexpr int N = C32_VRUN + 2 * R;
+    constexpr int VRUN = C32_VRUN_R(R), N = VRUN + 2 * R;
     float raw[N];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -184,7 +185,7 @@ STP_HD void c32_p1_item_src(stp_tile T, int xx, int yy0, const stp_w32& W, const
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int q = 0; q < C32_VRUN; q += 2) {            // two outputs at a time (c32_fma2)
+    for (int q = 0; q < VRUN; q += 2) {                // two outputs at a time (c32_fma2)
         float a0 = raw[q + R] * W.w[R], a1 = raw[q + 1 + R] * W.w[R];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -206,126 +207,6 @@ STP_HD void c32_p1_item(stp_tile T, int xx, int yy0, const stp_w32& W, const flo
     // guard bytes around the grey images: see canny_p1_item
     c32_p1_item_src<R, YIN>(T, xx, yy0, W, gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + (T.tx0 - R - 2 + xx), STP_PITCH, sVT);
 }
-// ---- vertical pass on column PAIRS (round 4).  The texture-data path of a CU returns one quad of lanes per cycle whatever
-// the width of the load (<= 16 B per lane): a wave's dword load holds it for 16 cycles, and with 28 of them per item that
-// path -- not HBM, L2 or the vector ALUs -- was what the pass waited for (TD_TD_BUSY 95 % in the pass-only build, 69 % in
-// the whole kernel; profiles/r04_*).  An item is therefore two adjacent columns (xx even: the window origin tx0 - R - 2 is
-// even for every tiled radius, so the 8-byte loads are aligned) x C32_VRUN output rows: half the load instructions, and
-// the two columns are the two halves of packed additions / fused multiply-adds (same operations per output as before).
-// Numbering: pairs covering the in-image columns first ((ncv + 1) / 2 of them per row group; a pair whose second column is
-// the first one outside the image writes zeros there), then one zero-fill item per remaining column and row group.
-struct stp_c32geo2 { int c_lo, ncv, npair, nzc, ng; };
-template <int R>
-STP_HD stp_c32geo2 c32_geo2(stp_tile T)
-{
-    static_assert(R % 2 == 0, "aligned column pairs need an even window origin");
-    const stp_c32geo1 g1 = c32_geo1<R>(T);
-    stp_c32geo2 g;
-    g.c_lo = g1.c_lo; g.ncv = g1.ncv; g.ng = g1.ng;
-    g.npair = (g1.ncv + 1) >> 1;
-    g.nzc = (CT_X + 2 * R + 4) - 2 * g.npair;
-    return g;
-}
-// returns xx | yy0 << 8 | zero << 16 | second column outside the image << 17, or -1 past the last item
-STP_HD int c32_p1_decode2(stp_c32geo2 G, int i)
-{
-    const int nval = G.npair * G.ng, nzero = G.nzc * G.ng;
-    if (i < nval) {
-        const int yg = i / G.npair, xx = G.c_lo + 2 * (i - yg * G.npair);
-        return xx | (yg * C32_VRUN) << 8 | (xx + 1 >= G.c_lo + G.ncv ? 1 << 17 : 0);
-    }
-    if (i < nval + nzero) {
-        const int j = i - nval, yg = j / G.nzc, zc = j - yg * G.nzc;
-        return (zc < G.c_lo ? zc : zc + 2 * G.npair) | (yg * C32_VRUN) << 8 | 1 << 16;
-    }
-    return -1;
-}
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef float stp_f2 __attribute__((ext_vector_type(2)));
-#else
-struct stp_f2 { float x, y; };
-#endif
-STP_HD stp_f2 c32_f2_load(const float* p)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return *(const stp_f2*)p;                        // 8-byte aligned by construction (see above)
-#else
-    stp_f2 r; r.x = p[0]; r.y = p[1]; return r;
-#endif
-}
-STP_HD stp_f2 c32_f2_fma(stp_f2 a, stp_f2 b, float w, stp_f2 c)      // (a + b) * w + c per half, the product and sum fused
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_elementwise_fma(a + b, (stp_f2){w, w}, c);
-#else
-    stp_f2 r; r.x = fmaf(a.x + b.x, w, c.x); r.y = fmaf(a.y + b.y, w, c.y); return r;
-#endif
-}
-template <int R, bool YIN>
-STP_HD void c32_p1_item2(stp_tile T, int xx, int yy0, bool second_out, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
-{
-    constexpr int N = C32_VRUN + 2 * R;
-    stp_f2 raw[N];
-    const float* col = gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + (T.tx0 - R - 2 + xx);    // guard bytes around the grey images: see canny_p1_item
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int k = 0; k < N; k++) raw[k] = c32_f2_load(col + k * STP_PITCH);
-    if (!YIN) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int k = 0; k < N; k++) {
-            const int y = T.ty0 - R - 2 + yy0 + k;
-            if ((unsigned)y >= (unsigned)T.S) { raw[k].x = 0.0f; raw[k].y = 0.0f; }
-        }
-    }
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int q = 0; q < C32_VRUN; q++) {
-        stp_f2 a;
-        a.x = raw[q + R].x * W.w[R]; a.y = raw[q + R].y * W.w[R];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int k = R; k >= 1; k--) a = c32_f2_fma(raw[q + R - k], raw[q + R + k], W.w[R - k], a);
-        if (!YIN) {
-            const int y = T.ty0 - 2 + yy0 + q;
-            if (!(y >= 0 && y < T.S)) { a.x = 0.0f; a.y = 0.0f; }
-        }
-        sVT[xx * CT_VP + yy0 + q] = a.x;
-        sVT[(xx + 1) * CT_VP + yy0 + q] = second_out ? 0.0f : a.y;      // (x + 1 == S: constant-mode zero)
-    }
-}
-template <int R, bool YIN>
-STP_HD void c32_p1_blk2(int tid, int nt, stp_tile T, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
-{
-    const stp_c32geo2 G = c32_geo2<R>(T);
-    for (int i = tid;; i += nt) {
-        const int it = c32_p1_decode2(G, i);
-        if (it < 0) break;
-        if ((it >> 16) & 1) c32_p1_zero(it & 255, (it >> 8) & 255, sVT);
-        else c32_p1_item2<R, YIN>(T, it & 255, (it >> 8) & 255, (it >> 17) & 1, W, gimg, sVT);
-    }
-}
-
-// The tile's grey window in LDS (k_canny_f32, round 4): rows ty0-R-2 .. ty0+CT_Y+R+1, columns from the 16-byte aligned
-// tx0 - XOFF (tx0 is a multiple of 64, the row pitch 1600 B, an image 640 000 B, the buffer 256-byte aligned) in whole
-// 16-byte pieces, row-major, piece i at byte 16 i: the lane-linear image a wave's LDS-DMA instruction writes.
-template <int R>
-struct c32_win {
-    static constexpr int XOFF = ((R + 2 + 3) / 4) * 4;
-    static constexpr int WP = XOFF + CT_X + ((R + 2 + 3) / 4) * 4;     // floats per row
-    static constexpr int ROWS = CT_Y + 2 * R + 4;
-    static constexpr int NV4 = ROWS * (WP / 4);                        // 16-byte pieces
-    static constexpr int COL0 = XOFF - (R + 2);                        // window column of the vertical pass's column xx = 0
-};
-template <int R, bool YIN>
-STP_HD void c32_p1_item_win(stp_tile T, int xx, int yy0, const stp_w32& W, const float* sWin, float* sVT)
-{
-    c32_p1_item_src<R, YIN>(T, xx, yy0, W, sWin + yy0 * c32_win<R>::WP + (c32_win<R>::COL0 + xx), c32_win<R>::WP, sVT);
-}
 template <int R, bool YIN>
 STP_HD void c32_p1_blk(int tid, int nt, stp_tile T, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
 {
@@ -333,7 +214,7 @@ STP_HD void c32_p1_blk(int tid, int nt, stp_tile T, const stp_w32& W, const floa
     for (int i = tid;; i += nt) {
         const int it = c32_p1_decode(G, i);
         if (it < 0) break;
-        if (it >> 16) c32_p1_zero(it & 255, (it >> 8) & 255, sVT);
+        if (it >> 16) c32_p1_zero<R>(it & 255, (it >> 8) & 255, sVT);
         else c32_p1_item<R, YIN>(T, it & 255, (it >> 8) & 255, W, gimg, sVT);
     }
 }
@@ -552,6 +433,18 @@ STP_HD float c32_gauss_sum(const float* v, const double* w)
 template <int R>
 STP_HD float c32_gauss_exact(const float* centre, int stride, const double* w, int lo, int hi)
 {
+    if (R > 8) {                                   // (25 / 21 taps at once would not fit the registers of five waves per SIMD)
+        double a = (R >= lo && R <= hi) ? (double)centre[0] * w[R] : 0.0 * w[R];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 4
+#endif
+        for (int k = R; k >= 1; k--) {                // (four tap pairs -- eight loads -- in flight at a time)
+            const double xl = (R - k >= lo && R - k <= hi) ? (double)centre[-k * stride] : 0.0;
+            const double xh = (R + k >= lo && R + k <= hi) ? (double)centre[k * stride] : 0.0;
+            a += (xl + xh) * w[R - k];
+        }
+        return (float)a;
+    }
     float v[2 * R + 1];
     c32_gauss_taps<R>(centre, stride, lo, hi, v);
     return c32_gauss_sum<R>(v, w);
@@ -577,6 +470,16 @@ STP_HD void c32_res_V_taps(stp_tile T, int y, int x, int l, const float* __restr
 template <int R>
 STP_HD float c32_res_V(stp_tile T, int y, int x, int l, const double* w, const float* __restrict__ gimg)
 {
+    if (R > 8) {                                   // (as c32_gauss_exact: one tap pair at a time)
+        constexpr int NC = 2 * R + 5;
+        const int r = l / NC, c = l - r * NC;
+        int yy = y - 2 + r;
+        yy = yy < 0 ? 0 : (yy > T.S - 1 ? T.S - 1 : yy);
+        const int xx = x - 2 - R + c;
+        const bool in = xx >= 0 && xx < T.S;
+        const int lo = !in ? 1 : (yy - R < 0 ? R - yy : 0), hi = !in ? 0 : (yy + R >= T.S ? R + (T.S - 1 - yy) : 2 * R);
+        return c32_gauss_exact<R>(gimg + yy * STP_PITCH + (in ? xx : 0), STP_PITCH, w, lo, hi);
+    }
     float v[2 * R + 1];
     c32_res_V_taps<R>(T, y, x, l, gimg, v);
     return c32_gauss_sum<R>(v, w);

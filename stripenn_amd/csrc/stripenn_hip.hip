@@ -659,33 +659,40 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe_list(const
 __device__ __forceinline__ void canny32_mag_rows(int tid, stp_cwin C, int my_lo, int nmh, int mx_lo, int nmw, float thr,
                                                  const float* sS, float* sM, uint16_t* sQ, int* sQcnt)
 {
-    const int wv = tid >> 6, lane = tid & 63, MW = CT_X + 2;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, MW = CT_X + 2;     // (scalar: the row bounds below live in SGPRs)
     if (tid < 2 * nmh) {
         const int col = tid >= nmh, X = col ? CT_X + 1 : 0, Y = my_lo + tid - col * nmh;
         if (X >= mx_lo && X < mx_lo + nmw) sM[Y * MW + X] = c32_mag_px(sS, Y, X);
     }
+    constexpr int RMAX = (CT_Y + 2 + 3) / 4;                 // rows of a wave's strip at most
     const int rows = (nmh + 3) >> 2, Y0 = my_lo + wv * rows, Y1 = min(Y0 + rows, my_lo + nmh);
     int cnt = 0;
     if (Y0 < Y1) {                                           // wave-uniform
         const int X = 1 + lane;
         const bool colin = X >= mx_lo && X < mx_lo + nmw;
         const bool xcand = colin && (unsigned)(X - C.x0) < (unsigned)C.nx;
-        const float* sp = sS + Y0 * C32_SP + X;
         uint16_t* q = sQ + wv * C32_QSEG;
-        float hd0, hd1, hs0, hs1;
-        c32_row_terms(sp, &hd0, &hs0);
-        c32_row_terms(sp + C32_SP, &hd1, &hs1);
         const stp_u64 lt = (1ull << lane) - 1ull;
-        for (int Y = Y0; Y < Y1; Y++) {
-            float hd2, hs2;
-            c32_row_terms(sp + (Y - Y0 + 2) * C32_SP, &hd2, &hs2);
-            const float m = c32_mag(hd0, hd1, hd2, hs0, hs2);
-            if (colin) sM[Y * MW + X] = m;
-            const bool isq = xcand && (unsigned)(Y - C.y0) < (unsigned)C.ny && m >= thr;
-            const stp_u64 bq = __ballot(isq);
-            if (isq) q[cnt + __popcll(bq & lt)] = (uint16_t)((Y - 1) * 64 + (X - 1));
-            cnt += __popcll(bq);
-            hd0 = hd1; hd1 = hd2; hs0 = hs1; hs1 = hs2;
+        // all rows of the strip in one go (round 4): the RMAX + 2 smoothed rows are requested together -- one LDS
+        // round trip per image instead of one per row -- and the walk is unrolled (no register rotation, no
+        // pointer arithmetic per row); rows beyond the strip repeat its last row and are not used
+        float hd[RMAX + 2], hs[RMAX + 2];
+#pragma unroll
+        for (int r = 0; r < RMAX + 2; r++) {
+            const int Yr = min(Y0 + r, Y1 + 1);             // (wave-uniform; Y1 + 1 <= CT_Y + 3, the tile's last smoothed row)
+            c32_row_terms(sS + Yr * C32_SP + X, &hd[r], &hs[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) {
+            const int Y = Y0 + r;
+            if (Y < Y1) {                                    // wave-uniform
+                const float m = c32_mag(hd[r], hd[r + 1], hd[r + 2], hs[r], hs[r + 2]);
+                if (colin) sM[Y * MW + X] = m;
+                const bool isq = xcand && (unsigned)(Y - C.y0) < (unsigned)C.ny && m >= thr;
+                const stp_u64 bq = __ballot(isq);
+                if (isq) q[cnt + __popcll(bq & lt)] = (uint16_t)((Y - 1) * 64 + (X - 1));
+                cnt += __popcll(bq);
+            }
         }
     }
     if (lane == 0) sQcnt[wv] = cnt;
@@ -725,14 +732,16 @@ __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, con
 {
     constexpr int NV = 5 * (2 * R + 5);
     const int yy = e >> 6, xx = e & 63, y = T.ty0 + yy, x = T.tx0 + xx;
-    {   // the taps of a lane's first two elements are requested together (one memory round trip instead of two)
+    if constexpr (R <= 8) {   // the taps of a lane's two elements are requested together (one memory round trip instead of two)
         float va[2 * R + 1], vb[2 * R + 1];
         const bool hb = lane + 64 < NV;
         c32_res_V_taps<R>(T, y, x, lane, gimg, va);
         if (hb) c32_res_V_taps<R>(T, y, x, lane + 64, gimg, vb);
         Vp[lane] = c32_gauss_sum<R>(va, sW);
         if (hb) Vp[lane + 64] = c32_gauss_sum<R>(vb, sW);
-        for (int l = lane + 128; l < NV; l += 64) Vp[l] = c32_res_V<R>(T, y, x, l, sW, gimg);     // (radius 12 only)
+    } else {                  // (two windows of 21 / 25 taps would not fit the registers of five waves per SIMD)
+#pragma unroll 1
+        for (int l = lane; l < NV; l += 64) Vp[l] = c32_res_V<R>(T, y, x, l, sW, gimg);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -752,18 +761,11 @@ __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, con
     __builtin_amdgcn_wave_barrier();
 }
 
-#ifndef STP_C32_WIN
-#define STP_C32_WIN 0                /* 1: the tile's grey window reaches LDS by 16-byte LDS-DMA, one image ahead (round 4); 0: round 3's
-                                        vertical pass straight from global memory (dword loads) */
-#endif
-#ifndef STP_C32_PAIR
-#define STP_C32_PAIR 0               /* 1: vertical-pass items are column pairs (8-byte loads, packed arithmetic); 0: single columns */
-#endif
 #ifndef STP_C32_MINBLK
-#define STP_C32_MINBLK (STP_C32_WIN ? 3 : 5)
+#define STP_C32_MINBLK 5
 #endif
 #define C32_RES_WAVE_BYTES 832       /* per-wave resolver scratch inside the smoothed tile: 26 doubles, then 5 x (2R+5) floats (<= 145) */
-struct stp_c32_layout { size_t sB, sRB, sRV, sRC, sS, sV, sQ, sD, sBits, sQn, sG, sWin, total; };
+struct stp_c32_layout { size_t sB, sRB, sRV, sRC, sS, sV, sQ, sD, sBits, sQn, sG, total; };
 static __host__ __device__ stp_c32_layout canny32_layout(int R)
 {
     const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
@@ -784,44 +786,8 @@ static __host__ __device__ stp_c32_layout canny32_layout(int R)
     L.sBits = o; o += (size_t)C32_NBMAX * 2 * CT_Y * sizeof(stp_u64);
     L.sQn = o; o += 32;                                       // four segment fill counts, list length, overflow flag
     L.sG = o; o += C32_NBMAX * sizeof(float);                 // largest grey value under the tile's window, per image
-    L.sWin = o = (o + 15) & ~(size_t)15;                      // the grey window (c32_win), 16-byte pieces
-#if STP_C32_WIN
-    const int xoff = ((R + 2 + 3) / 4) * 4;
-    o += (size_t)(CT_Y + 2 * R + 4) * (2 * xoff + CT_X) * sizeof(float);
-#endif
     L.total = o;
     return L;
-}
-
-// One 16-byte LDS-DMA piece per lane: the lane's source address -> LDS byte lds_dst (wave-uniform) + 16 * lane.  M0 holds the
-// DMA's LDS base; it is compiler-reserved, so it is saved and restored inside the one statement.  The compiler does not
-// count this load: the kernel waits for it with its own s_waitcnt vmcnt(0) (stp_glds_wait) before the barrier that precedes
-// the first read of the window, and compiler-inserted waits can only over-wait (vector-memory operations retire in order).
-__device__ __forceinline__ void stp_glds16(const void* gsrc, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void stp_glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// the whole window of one image: piece i (row i / (WP/4), 16-byte column i % (WP/4)) by thread i % 256 in round i / 256.
-// Rows / columns outside the image are read as they lie in memory (guard bytes around the grey buffer, neighbouring rows)
-// and never used: the vertical pass numbers in-image columns only and zeroes out-of-image rows after the load.
-template <int R>
-__device__ __forceinline__ void canny32_win_issue(int tid, stp_tile T, const float* __restrict__ gimg, unsigned lds_win)
-{
-    using WN = c32_win<R>;
-    constexpr int NR = (WN::NV4 + 255) / 256, P4 = WN::WP / 4;
-    const float* src0 = gimg + (T.ty0 - R - 2) * STP_PITCH + (T.tx0 - WN::XOFF);
-#pragma unroll
-    for (int k = 0; k < NR; k++) {
-        const int i = tid + 256 * k;
-        if (i < WN::NV4) {
-            const int row = i / P4, c4 = i - row * P4;
-            const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_win + (unsigned)((i & ~63) * 16)));
-            stp_glds16(src0 + row * STP_PITCH + 4 * c4, dst);
-        }
-    }
 }
 
 template <int RT>
@@ -889,11 +855,6 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         } else if (tid < C32_NBMAX) sG[tid] = 1.0000005f;     // k_gray's grey values never exceed 0.299 + 0.587 + 0.114 (+ 3 roundings)
     }
     live = (unsigned)__builtin_amdgcn_readfirstlane((int)live);
-#if STP_C32_WIN
-    const unsigned lds_win = (unsigned)(uintptr_t)(smem + L.sWin);        // (low half of the flat address = the LDS byte address)
-    const float* sWin = (const float*)(smem + L.sWin);
-    if (live) canny32_win_issue<R>(tid, T, gray + (img0 + __builtin_ctz(live)) * (size_t)(STP_PITCH * STP_PITCH), lds_win);
-#endif
     for (int i = tid; i < nb * 2 * CT_Y; i += nt) sBits[i] = 0ull;
     if (tid == 64) { *sDn = 0; *sOv = 0; }
     const bool yin = (T.ty0 - R - 2 >= 0) && (T.ty0 + CT_Y + R + 1 < S);
@@ -905,22 +866,16 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         __syncthreads();
         c32_rb_tables<R>(tid, nt, T, sW, sB, sRB, sRV, sRC, xin);
     }
-    static_assert((CT_Y + 4) % C32_VRUN == 0, "whole row groups");
-    constexpr int NR1 = ((CT_X + 2 * R + 4) * ((CT_Y + 4) / C32_VRUN) + 255) / 256;
+    static_assert((CT_Y + 4) % C32_VRUN_R(R) == 0, "whole row groups");
+    constexpr int NR1 = ((CT_X + 2 * R + 4) * ((CT_Y + 4) / C32_VRUN_R(R)) + 255) / 256;
     constexpr int NR2 = ((CT_Y + 4) * ((CT_X + 4 + CT_HRUN_R(R) - 1) / CT_HRUN_R(R)) + 255) / 256;
     int it1[NR1], it2[NR2];
     struct { int my_lo, nmh, mx_lo, nmw; } G3;
     {
         const stp_cgeo G = ct_geo<R>(T);
-#if STP_C32_PAIR
-        const stp_c32geo2 G1 = c32_geo2<R>(T);
-#pragma unroll
-        for (int k = 0; k < NR1; k++) it1[k] = c32_p1_decode2(G1, tid + 256 * k);
-#else
         const stp_c32geo1 G1 = c32_geo1<R>(T);
 #pragma unroll
         for (int k = 0; k < NR1; k++) it1[k] = c32_p1_decode(G1, tid + 256 * k);
-#endif
 #pragma unroll
         for (int k = 0; k < NR2; k++) it2[k] = ct_p2_decode<R>(G, tid + 256 * k);
         G3.my_lo = G.my_lo; G3.nmh = G.nmh; G3.mx_lo = G.mx_lo; G3.nmw = (int)G.nmw.d;
@@ -935,11 +890,8 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         live &= live - 1;
         const size_t img = img0 + bi;
         const float* gimg = gray + img * (STP_PITCH * STP_PITCH);
-#if STP_C32_WIN
-        stp_glds_wait();                             // this wave's pieces of the window have landed ...
-#endif
-        __syncthreads();                             // ... and everybody's; the class test of the previous image is done
-                                                     // (sM / sQ alias sV); first pass: the tables are written
+        __syncthreads();                             // the class test of the previous image is done (sM / sQ alias sV);
+                                                     // first pass: the tables are written
         if (tid == 64 && prev >= 0 && *sOv) {        // the previous image overflowed the tile's list: the whole tile-image is redone exactly
             *sOv = 0;
             *sDn = C32_DCAP;
@@ -952,24 +904,12 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
             int it = it1[k];
             asm volatile("" : "+v"(it));              // see k_canny_pipe
             if (it >= 0) {
-                if ((it >> 16) & 1) c32_p1_zero(it & 255, (it >> 8) & 255, sV);
-#if STP_C32_WIN
-                else if (yin) c32_p1_item_win<R, true>(T, it & 255, (it >> 8) & 255, W32, sWin, sV);
-                else c32_p1_item_win<R, false>(T, it & 255, (it >> 8) & 255, W32, sWin, sV);
-#elif STP_C32_PAIR
-                else if (yin) c32_p1_item2<R, true>(T, it & 255, (it >> 8) & 255, (it >> 17) & 1, W32, gimg, sV);
-                else c32_p1_item2<R, false>(T, it & 255, (it >> 8) & 255, (it >> 17) & 1, W32, gimg, sV);
-#else
+                if (it >> 16) c32_p1_zero<R>(it & 255, (it >> 8) & 255, sV);
                 else if (yin) c32_p1_item<R, true>(T, it & 255, (it >> 8) & 255, W32, gimg, sV);
                 else c32_p1_item<R, false>(T, it & 255, (it >> 8) & 255, W32, gimg, sV);
-#endif
             }
         }
         __syncthreads();
-#if STP_C32_WIN
-        // the window is free: the next live image's pieces travel while this image goes through its other phases
-        if (live) canny32_win_issue<R>(tid, T, gray + (img0 + __builtin_ctz(live)) * (size_t)(STP_PITCH * STP_PITCH), lds_win);
-#endif
 #if STP_ABLATE_C32 == 1                  /* timing-only builds: stop after the vertical pass ... */
         if (tid == 0) low[img * (STP_FRAME_MAX * STP_NW)] = (stp_u64)sV[70];
         continue;
