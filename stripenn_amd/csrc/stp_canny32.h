@@ -161,18 +161,32 @@ STP_HD void c32_p1_zero(int xx, int yy0, float* sVT)
 #endif
     for (int q = 0; q < C32_VRUN_R(R); q++) sVT[xx * CT_VP + yy0 + q] = 0.0f;
 }
-// one vertical-pass item from any source: `col` points at the window element (first input row of the item, column xx),
-// `pitch` floats from one row to the next -- the grey image itself (pitch STP_PITCH; the CPU replay and tiles of the
-// round-3 form) or the tile's grey window staged in LDS (c32_win, k_canny_f32)
+// (guard bytes around the grey images: see canny_p1_item.)  On the device the element addresses are formed as the image's
+// wave-uniform base + a 32-bit byte offset per lane (an image is 640 000 bytes), so the loads take the scalar-base form
+// and a new row costs one 32-bit addition instead of a 64-bit one.
 template <int R, bool YIN>
-STP_HD void c32_p1_item_src(stp_tile T, int xx, int yy0, const stp_w32& W, const float* col, int pitch, float* sVT)
+STP_HD void c32_p1_item(stp_tile T, int xx, int yy0, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
 {
     constexpr int VRUN = C32_VRUN_R(R), N = VRUN + 2 * R;
     float raw[N];
 #if defined(__HIP_DEVICE_COMPILE__)
+    // (offsets are taken from STP_GRAY_GUARD bytes in front of the image -- inside the buffer's leading guard -- so that they
+    //  are non-negative for the rows above the first image row too; three rows share one scalar base: 12-bit immediates)
+    const unsigned boff = (unsigned)(STP_GRAY_GUARD + ((T.ty0 - R - 2 + yy0) * STP_PITCH + (T.tx0 - R - 2 + xx)) * 4);
+    const char* base = (const char*)gimg - STP_GRAY_GUARD;
 #pragma unroll
+    for (int k0 = 0; k0 < N; k0 += 2) {
+        unsigned long long bk = (unsigned long long)(base + k0 * (STP_PITCH * 4));
+        asm("" : "+s"(bk));                            // (kept a scalar base: not folded back into a 64-bit address per lane)
+        typedef const __attribute__((address_space(1))) char* stp_gp;
+#pragma unroll
+        for (int k = k0; k < k0 + 2 && k < N; k++)
+            raw[k] = *(const __attribute__((address_space(1))) float*)((stp_gp)bk + (size_t)boff + (k - k0) * (STP_PITCH * 4));
+    }
+#else
+    const float* col = gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + (T.tx0 - R - 2 + xx);
+    for (int k = 0; k < N; k++) raw[k] = col[k * STP_PITCH];
 #endif
-    for (int k = 0; k < N; k++) raw[k] = col[k * pitch];
     if (!YIN) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -200,12 +214,6 @@ STP_HD void c32_p1_item_src(stp_tile T, int xx, int yy0, const stp_w32& W, const
         sVT[xx * CT_VP + yy0 + q] = a0;
         sVT[xx * CT_VP + yy0 + q + 1] = a1;
     }
-}
-template <int R, bool YIN>
-STP_HD void c32_p1_item(stp_tile T, int xx, int yy0, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
-{
-    // guard bytes around the grey images: see canny_p1_item
-    c32_p1_item_src<R, YIN>(T, xx, yy0, W, gimg + (T.ty0 - R - 2 + yy0) * STP_PITCH + (T.tx0 - R - 2 + xx), STP_PITCH, sVT);
 }
 template <int R, bool YIN>
 STP_HD void c32_p1_blk(int tid, int nt, stp_tile T, const stp_w32& W, const float* __restrict__ gimg, float* sVT)
