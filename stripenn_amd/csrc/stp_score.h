@@ -552,9 +552,13 @@ __global__ __launch_bounds__(256) void k_stripe_mean(stp_bandref B, const stp_re
 
 // ---------------------------------------------------------------------------------------------
 // Frame preparation, one workgroup per frame, ONE kernel:
-//   * zero-column removal (getStripe.py:809-821): one lane per column walks the rows in order, so the column sum has
-//     numpy's axis-0 order; consecutive lanes read consecutive band addresses (coalesced, eight row loads in flight);
-//     ballot + prefix give the compaction map nz and S;
+//   * zero-column removal (getStripe.py:809-821).  The reference keeps column c when sum(axis 0) != 0 after NaN -> 0.
+//     Balanced contact values are >= 0, and for non-negative columns "sum != 0" is "some entry > 0", whatever the order
+//     of the additions.  So the rows are read the way HBM likes them (round 4) -- one wave per row, the whole row of a
+//     lane's seven 64-column segments requested before the first use, two rows in flight per wave, sixteen waves -- and a
+//     column's occupancy is the OR of the rows' ballots.  A frame that holds a NEGATIVE value (no balanced map does; the
+//     ABI does not forbid it) is flagged by the same walk and takes the exact column walk instead: one lane per column,
+//     rows in numpy's axis-0 order.
 //   * StripeSearch's medpixel = np.quantile(submat[submat > 0], 0.5) (getStripe.py:885): exact order statistics over
 //     the frame's positive pixels (positive doubles order like their bit patterns).  The SAME walk counts them, tracks
 //     the min / max key and fills an 8192-bin histogram of range-normalised digits; the range is estimated beforehand
@@ -563,28 +567,42 @@ __global__ __launch_bounds__(256) void k_stripe_mean(stp_bandref B, const stp_re
 //     A second pass gathers the keys of the bin that holds the rank (continuous data: a few dozen) into LDS, tracks the
 //     smallest key of the higher bins, and ranks are counted in LDS.
 //     med[f*3 + {0,1,2}] = a[k0], a[k1], N with k0 = (N-1)/2, k1 = N/2 (numpy's lerp is done on the host).
-//   Two passes over the frame instead of the four of k_frame_compact + k_medpixel (count / min / max, histogram, gather)
-//   that this kernel replaces.  Heavily duplicated data (integer counts) or a selected bin with more than STP_MED_CAP
-//   keys falls back to the general radix select: 13 bits of (key - min) per further pass, then a <= / successor pass.
-#define STP_MED_BINS 8192
+//   An exact select needs the second pass (the candidates of the median's bin are unknown until the histogram is
+//   complete), so the frame is read twice.  Heavily duplicated data (integer counts) or a selected bin with more than
+//   STP_MED_CAP keys falls back to the general radix select: 13 bits of (key - min) per further pass, then a <= /
+//   successor pass.
+// Footprint: 1024 threads and 44 KB of LDS (8192 bins, 1024 gathered keys).  These launches run on the auxiliary stream while
+// the main stream is busy with the chain; measured on one box (profiles/r04_ab_prep.txt): a SMALL workgroup (512 threads,
+// 9.5 KB, 1024 bins) finds room beside k_canny_f32's five workgroups per CU and runs at once -- its own interval is shorter,
+// 13.6 instead of 23.9 ms of the step -- but it takes issue slots and LDS bandwidth from the chain (canny 46.1 instead of
+// 44.8 ms), and the step is what counts: 80.5 against 79.0 ms.  The large workgroup waits for a CU to drain and then owns it.
+#ifndef STP_MED_LOG
+#define STP_MED_LOG 13
+#endif
+#define STP_MED_BINS (1 << STP_MED_LOG)
+#ifndef STP_MED_CAP
 #define STP_MED_CAP 1024
-#define STP_PREP_NT 512
+#endif
+#ifndef STP_PREP_NT
+#define STP_PREP_NT 1024
+#endif
+#define STP_PREP_SEG ((STP_FRAME_MAX + 63) / 64)     /* 64-column segments of a frame row: 7 */
 __global__ __launch_bounds__(STP_PREP_NT) void k_frame_prep(stp_bandref B, const int32_t* __restrict__ fstart,
                                                             const int32_t* __restrict__ fn0, int32_t* __restrict__ S_out,
                                                             int16_t* __restrict__ nz_out, double* __restrict__ med, int keep_all)
 {
-    constexpr int NT = STP_PREP_NT, NWV = NT / 64, BPT = STP_MED_BINS / NT;
+    constexpr int NT = STP_PREP_NT, NWV = NT / 64, BPT = STP_MED_BINS / NT, NSEG = STP_PREP_SEG;
     __shared__ unsigned int hist[STP_MED_BINS];
     __shared__ unsigned int part[NT];
     __shared__ unsigned long long cand[STP_MED_CAP];
-    __shared__ unsigned long long s_hi, s_key[2], s_n, s_mn, s_mx;
-    __shared__ unsigned int s_k, s_le, s_cnt, s_m, s_bin;
-    __shared__ int s_wave[NWV];
+    __shared__ unsigned long long s_hi, s_key[2], s_n, s_mn, s_mx, s_occ[NSEG];
+    __shared__ unsigned int s_k, s_le, s_cnt, s_m, s_bin, s_neg;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t st = fstart[f];
     const int n0 = fn0[f];
     for (int i = tid; i < STP_MED_BINS; i += NT) hist[i] = 0;
-    if (tid == 0) { s_le = 0; s_hi = ~0ull; s_m = 0; s_key[0] = s_key[1] = ~0ull; s_n = 0; s_mn = ~0ull; s_mx = 0; }
+    if (tid == 0) { s_le = 0; s_hi = ~0ull; s_m = 0; s_key[0] = s_key[1] = ~0ull; s_n = 0; s_mn = ~0ull; s_mx = 0; s_neg = 0; }
+    if (tid < NSEG) s_occ[tid] = 0ull;
     __syncthreads();
     const double* p = B.d + st * (int64_t)B.W + (tid + B.hw);          // column tid of row 0 of the frame
     // ---- range estimate from eight sampled rows
@@ -613,7 +631,7 @@ __global__ __launch_bounds__(STP_PREP_NT) void k_frame_prep(stp_bandref B, const
     {
         const unsigned long long range = s_mx ? (s_mx - s_mn) : 0ull;
         const int hb = 64 - __clzll((long long)(range | 1ull));          // bits of the sampled range (>= 1)
-        shift1 = hb > 13 ? hb - 13 : 0;
+        shift1 = hb > STP_MED_LOG ? hb - STP_MED_LOG : 0;
     }
     auto digit1 = [&](unsigned long long key) -> unsigned int {          // monotone in key: bin order = key order
         if (key <= smin) return 0u;
@@ -622,45 +640,91 @@ __global__ __launch_bounds__(STP_PREP_NT) void k_frame_prep(stp_bandref B, const
     };
     __syncthreads();                                                      // everyone has read the estimate
     if (tid == 0) { s_mn = ~0ull; s_mx = 0; }
-    // ---- pass 1: column sums + count / min / max + histogram
-    double sum = 0.0;
-    unsigned long long cnt = 0, mn = ~0ull, mx = 0;
-    if (tid < n0) {
-        for (int r0 = 0; r0 < n0; r0 += 8) {
-            double v[8];
+    // one wave walks rows wave, wave + NWV, ...: two rows -- 2 x NSEG coalesced 512-byte loads per lane -- in flight
+    auto scan2 = [&](auto&& fn) {
+        for (int r = wave; r < n0; r += 2 * NWV) {
+            const double* q0 = B.d + (st + r) * (int64_t)B.W + (B.hw - r);
+            const bool two = r + NWV < n0;                                // wave-uniform
+            const double* q1 = q0 + (two ? (int64_t)NWV * (B.W - 1) : 0);
+            double v[2 * NSEG];
 #pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = (r0 + q < n0) ? p[(int64_t)(r0 + q) * (B.W - 1)] : 0.0;
+            for (int q = 0; q < NSEG; q++) { const int c = lane + 64 * q; v[q] = c < n0 ? q0[c] : 0.0; }
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                double x = v[q];
-                if (x > 0.0) {
-                    const unsigned long long key = (unsigned long long)__double_as_longlong(x);
-                    cnt++; mn = key < mn ? key : mn; mx = key > mx ? key : mx;
-                    atomicAdd(&hist[digit1(key)], 1u);
-                }
-                if (x != x) x = 0.0;
-                if (r0 + q < n0) sum += x;
-            }
+            for (int q = 0; q < NSEG; q++) { const int c = lane + 64 * q; v[NSEG + q] = (two && c < n0) ? q1[c] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 2 * NSEG; q++) fn(v[q], q % NSEG);
         }
+    };
+    // ---- pass 1: column occupancy + count / min / max + histogram
+    unsigned long long cnt = 0, mn = ~0ull, mx = 0;
+    {
+        unsigned long long occ[NSEG];
+        bool neg = false;
+#pragma unroll
+        for (int q = 0; q < NSEG; q++) occ[q] = 0ull;
+        scan2([&](double x, int q) {
+            const bool pos = x > 0.0;
+            occ[q] |= __ballot(pos);
+            neg = neg || x < 0.0;
+            if (pos) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(x);
+                cnt++; mn = key < mn ? key : mn; mx = key > mx ? key : mx;
+                atomicAdd(&hist[digit1(key)], 1u);
+            }
+        });
+        if (lane < NSEG) {
+            unsigned long long o = 0ull;
+#pragma unroll
+            for (int q = 0; q < NSEG; q++) o = (lane == q) ? occ[q] : o;
+            if (o) atomicOr(&s_occ[lane], o);
+        }
+        if (__ballot(neg) && lane == 0) s_neg = 1u;
     }
-    const bool flag = (tid < n0) && (keep_all || sum != 0.0);
-    const unsigned long long bal = __ballot(flag);
     for (int o = 32; o > 0; o >>= 1) {
         cnt += __shfl_xor(cnt, o);
         const unsigned long long a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
         mn = a < mn ? a : mn; mx = b > mx ? b : mx;
     }
-    if (lane == 0) s_wave[wave] = __popcll(bal);
     __syncthreads();                                                      // (also orders the reset of s_mn / s_mx)
     if (lane == 0 && cnt) { atomicAdd(&s_n, cnt); atomicMin(&s_mn, mn); atomicMax(&s_mx, mx); }
-    {
-        int base = 0, total = 0;
-        for (int i = 0; i < NWV; i++) {
-            if (i < wave) base += s_wave[i];
-            total += s_wave[i];
+    if (s_neg) {
+        // ---- a negative value: the reference's own test, sum over the rows in order != 0, one lane per column
+        __syncthreads();
+        if (tid < NSEG) s_occ[tid] = 0ull;
+        __syncthreads();
+        double sum = 0.0;
+        if (tid < n0) {
+            for (int r0 = 0; r0 < n0; r0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = (r0 + q < n0) ? p[(int64_t)(r0 + q) * (B.W - 1)] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    double x = v[q];
+                    if (x != x) x = 0.0;
+                    if (r0 + q < n0) sum += x;
+                }
+            }
         }
-        const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-        if (flag) nz_out[f * STP_FRAME_MAX + pos] = (int16_t)tid;
+        const unsigned long long bal = __ballot(tid < n0 && sum != 0.0);
+        if (lane == 0 && wave < NSEG) s_occ[wave] = bal;
+    }
+    __syncthreads();
+    {   // nz = the kept columns in order, S = their number (getStripe.py:812-821)
+        int base = 0, total = 0;
+        unsigned long long mine = 0ull;
+#pragma unroll
+        for (int i = 0; i < NSEG; i++) {
+            unsigned long long o = s_occ[i];
+            if (keep_all) o = ~0ull;
+            const int hi = n0 - 64 * i;                                   // columns of this segment inside the frame
+            o = hi >= 64 ? o : (hi > 0 ? (o & ((1ull << hi) - 1ull)) : 0ull);
+            if (i < wave) base += __popcll(o);
+            if (i == wave) mine = o;
+            total += __popcll(o);
+        }
+        if (wave < NSEG && ((mine >> lane) & 1ull))
+            nz_out[f * STP_FRAME_MAX + base + __popcll(mine & ((1ull << lane) - 1ull))] = (int16_t)tid;
         if (tid == 0) S_out[f] = (keep_all || total > 10) ? total : 0;   // getStripe.py:818
     }
     __syncthreads();
@@ -671,17 +735,8 @@ __global__ __launch_bounds__(STP_PREP_NT) void k_frame_prep(stp_bandref B, const
     }
     const unsigned long long kmin = s_mn, kmax = s_mx;
     const unsigned int k0 = (N - 1) / 2, k1 = N / 2;
-    // one wave walks one frame row at a time (coalesced 512 B segments of the band, no index division)
-    auto scan = [&](auto&& fn) {
-        for (int r = wave; r < n0; r += NWV) {
-            const double* q0 = B.d + (st + r) * (int64_t)B.W + (B.hw - r);
-            double v[7];                        // the whole row (<= 400 pixels) in flight before any use
-#pragma unroll
-            for (int q = 0; q < 7; q++) { const int c = lane + 64 * q; v[q] = c < n0 ? q0[c] : 0.0; }
-#pragma unroll
-            for (int q = 0; q < 7; q++)
-                if (v[q] > 0.0) fn((unsigned long long)__double_as_longlong(v[q]));
-        }
+    auto scan = [&](auto&& fn) {                // the positive keys of the frame (two rows in flight per wave: scan2)
+        scan2([&](double x, int) { if (x > 0.0) fn((unsigned long long)__double_as_longlong(x)); });
     };
     // bin of rank k in the current histogram: BPT bins per lane -> partial sums -> inclusive scan -> locate
     auto find_bin = [&](unsigned int k) {
@@ -738,12 +793,12 @@ __global__ __launch_bounds__(STP_PREP_NT) void k_frame_prep(stp_bandref B, const
         finish_gathered(k);
         return;
     }
-    // ---- general radix select on (key - kmin), 13 bits per pass (heavily duplicated data)
+    // ---- general radix select on (key - kmin), STP_MED_LOG bits per pass (heavily duplicated data)
     unsigned int k = k0;
     unsigned long long prefix = 0;              // in the (key - kmin) domain
     const unsigned long long range = kmax - kmin;
     const int hb = range ? 64 - __clzll((long long)range) : 0;
-    int width = hb < 13 ? hb : 13, shift = hb - width;
+    int width = hb < STP_MED_LOG ? hb : STP_MED_LOG, shift = hb - width;
     bool gathered = false;
     while (width > 0) {
         const int hs = shift + width;           // hs <= 63 here except possibly the very first pass
@@ -763,7 +818,7 @@ __global__ __launch_bounds__(STP_PREP_NT) void k_frame_prep(stp_bandref B, const
         const unsigned int cntb = s_cnt;
         if (shift == 0) break;
         if (cntb <= STP_MED_CAP) { gathered = true; break; }
-        width = shift < 13 ? shift : 13;
+        width = shift < STP_MED_LOG ? shift : STP_MED_LOG;
         shift -= width;
     }
     if (gathered) {

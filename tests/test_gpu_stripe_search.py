@@ -200,3 +200,44 @@ def test_dense_stripes_more_than_64_candidate_columns(hip_ctx):
             int(r['h']), float(r['total'])) for r in recs]
     assert len(got) > 500 and got == exp
     fr.close(); band.close()
+
+
+@pytest.mark.parametrize('kind', ['nonneg_asym', 'negative', 'cancelling'])
+def test_zero_column_rule_on_general_values(hip_ctx, kind):
+    """Zero-column removal keeps column c when sum(axis 0) != 0 after NaN -> 0 (getStripe.py:809-821).  k_frame_prep takes
+    the coalesced shortcut "some entry > 0" only for non-negative frames; a frame with a negative value goes through the
+    exact column walk: columns whose entries cancel exactly, columns with only negative entries, NaN rows, and an
+    asymmetric block (column occupancy != row occupancy) all give numpy's verdict."""
+    rng = np.random.default_rng(11)
+    n, hw = 700, 512
+    A = rng.gamma(0.7, 3.0, (n, n)) * (rng.random((n, n)) < 0.3)
+    A = np.triu(A) + np.triu(A, 1).T
+    empty = rng.choice(n, 40, replace=False)
+    A[empty, :] = 0.0; A[:, empty] = 0.0
+    if kind == 'nonneg_asym':
+        A[:, empty[:10]] = 0.0
+        A[empty[10:20], :] = rng.gamma(1.0, 1.0, (10, n))           # rows filled, their columns still empty
+        A[:, empty[10:20]] = 0.0
+    elif kind == 'negative':
+        A[5, empty[0]] = -2.0                                        # a column with one negative entry only: kept
+        A[7, 33] = -1.0
+    else:
+        c = empty[1]
+        A[10, c] = 1.5; A[20, c] = -1.5                              # cancels exactly: removed
+        c2 = empty[2]
+        A[10, c2] = 1.5; A[20, c2] = -1.0                            # does not cancel: kept
+    A[100, :] = np.nan
+    i = np.arange(n)[:, None]; d = np.arange(-hw, hw)[None, :]
+    j = i + d
+    band_h = np.where((j >= 0) & (j < n) & (np.abs(d) <= 399), A[i, np.clip(j, 0, n - 1)], 0.0)
+    band = hip_ctx.band_upload(np.ascontiguousarray(band_h))
+    st = np.array([0, 100, 300], dtype=np.int32); en = st + 399
+    fr = band.frames(st, en)
+    for f in range(len(st)):
+        D = np.nan_to_num(A[st[f]:en[f] + 1, st[f]:en[f] + 1])
+        nz = np.where(D.sum(axis=0) != 0)[0]
+        assert fr.S[f] == len(nz), (kind, f)
+        assert np.array_equal(fr.nz[f, :len(nz)], nz), (kind, f)
+        Dp = D[D > 0]
+        assert fr.medpixel[f] == np.quantile(Dp, 0.5), (kind, f)
+    fr.close(); band.close()
