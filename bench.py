@@ -37,7 +37,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 N_SIMD = 1024          # 256 CUs x 4 SIMDs
-CLOCK_HZ = 2.4e9       # max clock; an FP64 VALU wave-instruction occupies its SIMD for 4 cycles
+CLOCK_HZ = 2.4e9       # max clock
+VALU_CYCLES_PER_INST = 4.25   # measured: v_fma_f32 / packed f32 / every f64 op per wave and SIMD (f32 add, sub, mul: 2.2)
 MM10 = [195471971, 182113224, 160039680, 156508116, 151834684, 149736546, 145441459, 129401213, 124595110, 130694993,
         122082543, 120129022, 120421639, 124902244, 104043685, 98207768, 94987271, 90702639, 61431566, 171031299]
 MM10_NAMES = ['chr%d' % (i + 1) for i in range(19)] + ['chrX']
@@ -169,6 +170,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end `compute` run (quantile -> TSVs) at N = 1')
     ap.add_argument('--no-score', action='store_true', help='StripeSearch chain only (for very long chromosomes)')
+    ap.add_argument('--no-extras', action='store_true', help='skip the extra measurements of the N = 1 line: the all-f64 kernels on the same workload and the 1 kb chr1-size band')
     ap.add_argument('--allow-stp-lib', action='store_true', help='accept a library named by STP_LIB (profiling builds)')
     ap.add_argument('--emulate-rank', default='', help='R/N: time the share rank R of an N-rank run would get, alone on this GPU (diagnostic: per-rank fixed costs without an N-GPU node; the line is NOT a multi-GPU measurement)')
     args = ap.parse_args()
@@ -243,118 +245,39 @@ def main():
     dev = torch.device('cuda', local_rank)
     rdev = 'cpu' if (rehearse or rehearse_reduce) else 'cuda'      # where the timing scalars are reduced
 
-    from stripenn_amd import synth_device, hip, shard, getStripe as GS, backend as BK
-    hw = 512
-    bs = int(50000 / RESOL)
+    from stripenn_amd import hip, shard, backend as BK
     if args.bins:
-        names, nbins, seeds = ['chr16'], [args.bins], [16]
-        wl = 'configs[4]-like 1kb chr1-size band' if args.bins > 200000 else 'custom chromosome'
+        spec = dict(names=['chr16'], nbins=[args.bins], seeds=[16],
+                    wl='configs[4]-like 1kb chr1-size band' if args.bins > 200000 else 'custom chromosome')
     elif args.workload == 'chr16':
-        names, nbins, seeds = ['chr16'], [CHR16_BINS], [16]
-        wl = 'configs[1]: chr16-size 5kb chromosome'
+        spec = dict(names=['chr16'], nbins=[CHR16_BINS], seeds=[16], wl='configs[1]: chr16-size 5kb chromosome')
     else:
-        names, nbins, seeds = MM10_NAMES, [-(-s // RESOL) for s in MM10], list(range(1, 21))
-        wl = 'configs[2]: mm10-size whole genome at 5kb (20 chromosomes)'
-    sizes = np.array([n * RESOL for n in nbins], dtype=np.int64)
-    nframes = [-(-n // 200) for n in nbins]
-    my_units = shard.frame_spans(nframes, world)[rank]       # (chromosome index, first frame, end frame)
-    if args.emulate_rank:
-        er, en_ = (int(v) for v in args.emulate_rank.split('/'))
-        my_units = shard.frame_spans(nframes, en_)[er]
-    # pipeline stages: pieces of at most one device chunk (3 072 images = 102 frames at 5 levels x 6 brightness), so that
-    # filling and draining the two-deep pipeline costs a chunk's latency, not a chromosome's
-    piece = max(1, int(os.environ.get('STP_BENCH_PIECE', '102')))
-    my_units = [(ci, a, min(a + piece, f1)) for ci, f0, f1 in my_units for a in range(f0, f1, piece)]
-
-    # ---- untimed set-up: every band in HBM, maxpixel quantiles, expected values, background tables
+        spec = dict(names=MM10_NAMES, nbins=[-(-s // RESOL) for s in MM10], seeds=list(range(1, 21)),
+                    wl='configs[2]: mm10-size whole genome at 5kb (20 chromosomes)')
     t_setup = time.time()
     hb = BK.HipBackend(local_rank)       # raises if the HIP extension / GPU is missing: no CPU fallback
     ctx = hb.ctx
-    chroms, tens, bands = {}, {}, {}
-    need_all = not args.no_score         # the background tables sample every chromosome of the genome
-    for ci, nm in enumerate(names):
-        if not need_all and not any(u[0] == ci for u in my_units):
-            continue
-        chroms[nm] = synth_device.DeviceChrom(nbins[ci], seeds[ci], dev)
-        tens[nm] = chroms[nm].band(hw)
-        torch.cuda.synchronize()
-        bands[nm] = ctx.band_wrap(tens[nm].data_ptr(), nbins[ci], hw, keepalive=tens[nm])
-    Ms = {}
-    for ci in sorted({u[0] for u in my_units}):
-        # the reference's getQuantile step (np.quantile(mat[mat > 0], q)) is outside the timed path; on this
-        # band-limited synthetic data the band holds every positive pixel, so the order statistics of the band's
-        # positive entries are those of the dense matrix (sorted on the device, numpy's interpolation on the host)
-        t = tens[names[ci]]
-        v = torch.sort(t[t > 0]).values
-        Ms[ci] = GS.quantile_linear(lambda ranks: v[torch.as_tensor(ranks, device=dev)].cpu().numpy(), int(v.numel()),
-                                    MAXPIXEL)
-        del v
-    sel = _DeviceSelector(chroms, RESOL)
-    obj = GS.getStripe(sel, RESOL, 10, 8, 2.0, names, names, sizes, sizes, 2, 3, 123456789, backend=hb)
-    for nm in bands:
-        obj._bands[nm] = bands[nm]
-    EV = {}
-    if not args.no_score:
-        EVall = obj.mpmean()
-        EV = {ci: np.asarray(EVall[names[ci]]) for ci in {u[0] for u in my_units}}
-        bg = obj.nulldist()
-        hb.set_background(*bg)
-    tabs = {ci: frame_table(nbins[ci]) for ci in {u[0] for u in my_units}}
+    W = _Workload(hb, dev, spec, world, rank, args.emulate_rank, score=not args.no_score)
     setup_s = time.time() - t_setup
-
-    host_prof = [0.0]
-
-    def launch(unit):
-        """frame compaction + medpixel of one unit (small kernels on the context's auxiliary stream) and its whole
-        StripeSearch chain enqueued on the main stream; returns without waiting for the chain"""
-        ci, f0, f1 = unit
-        st, en = tabs[ci]
-        fr = bands[names[ci]].frames(st[f0:f1], en[f0:f1])
-        return unit, fr, fr.stripe_search_begin(Ms[ci])
-
-    def step():
-        """Two searches are kept in flight: while the device runs the chain of unit u+1 (and u+2 is queued behind
-        it), the host collects the records of unit u, builds the score inputs and enqueues its p-value /
-        Stripiness kernels -- the single in-order stream never runs dry."""
-        nrec, px = 0, 0.0
-        todo = list(my_units)[::-1]
-        flight = [launch(todo.pop()) for _ in range(min(2, len(todo)))]
-        while flight:
-            (ci, f0, f1), fr, pend = flight.pop(0)
-            tw = time.perf_counter()
-            recs = pend.wait()
-            host_prof[0] += time.perf_counter() - tw           # time the host spent waiting for the device
-            if todo:
-                flight.append(launch(todo.pop()))
-            if not args.no_score:
-                st = tabs[ci][0]
-                sband = bands[names[ci]]
-                pv, sc = BK.score_inputs(recs, fr.nz, st[f0:f1], nbins[ci], bs)
-                hb.pvalue(sband, bs, pv)
-                hb.stripiness(sband, EV[ci], sc)
-            nrec += len(recs)
-            px += float((fr.S.astype(np.float64) ** 2).sum())
-            fr.close()
-        return nrec, px * len(MAXPIXEL)
+    names, nbins, nframes = W.names, W.nbins, W.nframes
 
     def barrier():
         if world > 1:
             dist.barrier(group=pg)        # pg: the RCCL group when every rank's probe succeeded, else None = gloo
         torch.cuda.synchronize()
-        ctx.synchronize()
+        W.synchronize()
 
     for _ in range(args.warmup):
-        step()
-    ctx.set_profiling(True)
-    ctx.reset_stats()
+        W.step()
+    W.reset_stats()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        nrec, contact_px = step()
+        nrec, contact_px = W.step()
     barrier()
     dt_rank = time.perf_counter() - t0
-    stats = ctx.stats()
-    host_wait_ms = host_prof[0] / (args.steps + args.warmup) * 1e3      # (the warm-up steps count too: same work)
+    stats = W.stats()
+    host_wait_ms = W.host_wait_s / (args.steps + args.warmup) * 1e3      # (the warm-up steps count too: same work)
     dt, total_px, total_rec, rank_ms = dt_rank, contact_px, nrec, [dt_rank / args.steps * 1e3]
     if world > 1:
         tmax = torch.tensor([dt_rank], dtype=torch.float64, device=rdev)
@@ -391,14 +314,23 @@ def main():
             if k.get('valu_insts') is not None and k.get('image_px'):
                 per_px = k['valu_insts'] / k['image_px']
                 step_insts = per_px * image_px                      # wave-instructions of this kernel per step
-                # issue ceiling of the kernel's arithmetic: k_canny_f32 computes in f32 (one wave-instruction per 2 cycles and
-                # SIMD, MI355X_MICROARCH.md), the f64 kernels in FP64 (4 cycles)
-                cyc = 2 if (dom == 'canny' and os.environ.get('STP_CANNY') != 'exact') else 4
+                # issue ceiling of the kernel's arithmetic, measured on this chip (tools/ubench_valu.hip, profiles/r04_ubench_valu.txt):
+                # a v_fma_f32, a packed f32 op and every f64 op hold a SIMD ~4.25 cycles per wave; f32 add / sub / mul ~2.2
+                cyc = VALU_CYCLES_PER_INST
                 valu = {'kernel': 'k_' + dom, 'wave_insts_per_image_px': round(per_px, 3), 'lane_insts_per_image_px': round(per_px * 64, 1),
                         'cycles_per_inst': cyc, 'peak_wave_insts_per_s': N_SIMD * CLOCK_HZ / cyc,
                         'achieved_wave_insts_per_s': round(step_insts / (d['ms'] / args.steps * 1e-3), 0),
                         'frac': round(step_insts / (d['ms'] / args.steps * 1e-3) / (N_SIMD * CLOCK_HZ / cyc), 4),
                         'source': pmc.get('tag')}
+        # every kernel of the step under SURVEY 8(d)'s algorithmic-byte formulas (the library's own byte counters), per launch
+        per_kernel = {}
+        for k, v in stats.items():
+            if k == 'chain_wall' or not v['launches'] or v['ms'] <= 0:
+                continue
+            g = v['alg_bytes'] / (v['ms'] * 1e-3) / 1e9
+            per_kernel['k_' + k] = {'ms_per_step': round(v['ms'] / args.steps, 3), 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
+                                    'alg_GB_per_step': round(v['alg_bytes'] / args.steps / 1e9, 3), 'achieved_GBs': round(g, 1),
+                                    'frac': round(g / HBM_PEAK_GBS, 4)}
         roof = {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'traffic_source': (pmc.get('tag') if traffic is not None else
@@ -410,18 +342,22 @@ def main():
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4), 'launches_per_step': d['launches'] / args.steps,
                 'alg_bytes_per_launch': d['alg_bytes'] / d['launches'],
                 'valu_issue': valu,
+                'kernels': per_kernel,
                 'chain': {'kernels_ms_per_step': {k: round(v['ms'] / args.steps, 4) for k, v in stats.items()},
                           'alg_bytes_per_image_px': 26.0,
                           'achieved_GBs': round(26.0 * image_px * args.steps / (chain_ms * 1e-3) / 1e9, 1),
                           'frac': round(26.0 * image_px * args.steps / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+        exact_env = os.environ.get('STP_CANNY') == 'exact'
         out = {'metric': 'contact-matrix Mpixels/s through compute path', 'value': round(value, 2),
                'unit': 'contact-Mpx/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-               'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+               'scaling': 'strong', 'vs_baseline': None,
+               'dtype': 'f64' if exact_env else 'f64 (Canny classes: certified f32 + f64 resolver; grey: certified f64 shortcut + exact redo)',
+               'data': 'synthetic',
                'emulated_rank': args.emulate_rank or None,
                'config': {'workload': '%s: %d bins, %d frames x %d maxpixel levels (0.95-0.99) x 6 brightness levels; step = frame '
                                       'compaction + medpixel + StripeSearch chain%s, bands resident in HBM'
-                                      % (wl, sum(nbins), sum(nframes), len(MAXPIXEL),
+                                      % (spec['wl'], sum(nbins), sum(nframes), len(MAXPIXEL),
                                          '' if args.no_score else ' + p-value and Stripiness of every candidate stripe'),
                           'chromosomes': len(names), 'frames': int(sum(nframes)), 'levels': len(MAXPIXEL),
                           'images_per_step': int(sum(nframes) * len(MAXPIXEL) * 6),
@@ -429,27 +365,76 @@ def main():
                           'sharding': 'contiguous (chromosome x frame) spans of equal frame count, one process per GPU, '
                                       'no collective on the data path',
                           'rank_ms_per_step': [round(t, 3) for t in rank_ms], 'setup_s': round(setup_s, 1),
-                          'host_wait_ms_per_step': round(host_wait_ms, 2),      # of ms_per_step the host spent waiting for searches: the rest is host work the device may or may not hide
+                          'host_wait_ms_per_step': round(host_wait_ms, 2),      # of ms_per_step the search thread spent waiting for searches: the rest is host work the device may or may not hide
+                          'score_thread': W.hb2 is not None,                     # p-value / Stripiness calls on a host thread and context of their own
 
                           'comm': comm, 'comm_note': comm_note, 'devices': devnames,
                           'library': hip.LIB_PATH,
-                          'arithmetic': ('grey images, line joining, scoring: f64 as the reference; Canny classes: '
-                                         + ('f64 throughout (STP_CANNY=exact)' if os.environ.get('STP_CANNY') == 'exact' else
+                          'arithmetic': ('line joining, scoring: f64 as the reference; grey images: '
+                                         + ('every operation of the reference (STP_GRAY=exact)' if os.environ.get('STP_GRAY') == 'exact' else
+                                            'f64 from shared row sums, certified against float rounding boundaries, flagged lanes redone in the '
+                                            'reference\'s operations (k_gray_c3) -- bit-identical grey images')
+                                         + '; Canny classes: '
+                                         + ('f64 throughout (STP_CANNY=exact)' if exact_env else
                                             'f32 with a proven error budget, the undecidable pixels in the reference\'s f64 '
                                             '(k_canny_f32) -- class maps identical to the f64 kernel and the oracle'))},
                'roofline': roof}
+        if world == 1 and not args.no_extras and not exact_env:
+            # the same workload with every intermediate in the reference's arithmetic (k_gray<1>, k_canny_pipe): 3 steps
+            os.environ['STP_CANNY'] = 'exact'; os.environ['STP_GRAY'] = 'exact'
+            try:
+                W.step()
+                W.reset_stats(); barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    _, px_e = W.step()
+                barrier()
+                dte = time.perf_counter() - t0
+                se = W.stats()
+                out['exact'] = {'what': 'the same workload with STP_CANNY=exact STP_GRAY=exact (every intermediate in the reference\'s f64 '
+                                        'operations; identical records), 3 steps',
+                                'value': round(px_e * 3 / dte / 1e6, 2), 'unit': 'contact-Mpx/s', 'ms_per_step': round(dte / 3 * 1e3, 3),
+                                'canny_ms_per_launch': round(se['canny']['ms'] / se['canny']['launches'], 4),
+                                'gray_ms_per_launch': round(se['gray']['ms'] / se['gray']['launches'], 4),
+                                'kernels_ms_per_step': {k: round(v['ms'] / 3, 3) for k, v in se.items()}}
+            finally:
+                os.environ.pop('STP_CANNY', None); os.environ.pop('STP_GRAY', None)
         if world == 1 and not args.no_cpu_baseline:
-            ci = min({u[0] for u in my_units}, key=lambda c: nbins[c])        # the smallest chromosome held here
-            band_h = bands[names[ci]].download()
-            st, en = tabs[ci]
-            out['cpu_baseline'] = cpu_baseline(band_h, hw, st, en, [float(m) for m in Ms[ci]],
+            ci = min({u[0] for u in W.my_units}, key=lambda c: nbins[c])        # the smallest chromosome held here
+            band_h = W.bands[names[ci]].download()
+            st, en = W.tabs[ci]
+            out['cpu_baseline'] = cpu_baseline(band_h, W.hw, st, en, [float(m) for m in W.Ms[ci]],
                                                '%s (%d bins, %d frames) of the same genome' % (names[ci], nbins[ci], len(st)))
             del band_h
             out['cpu_baseline']['reference_python'] = reference_python_figure()
         else:
             out['cpu_baseline'] = None
         if world == 1 and not args.no_e2e and not args.no_score:
-            out['e2e_compute'] = e2e_compute(names, chroms, total_px, hb)
+            out['e2e_compute'] = e2e_compute(names, W.chroms, total_px, hb)
+        if world == 1 and not args.no_extras and not args.bins and args.workload == 'genome' and not exact_env:
+            # configs[4]: the 1 kb chr1-size band (248 957 bins, 1 245 frames x 5 levels x 6 images), chain only, shipped kernels
+            W.release()
+            try:
+                spec4 = dict(names=['chr1_1kb'], nbins=[248957], seeds=[5], wl='configs[4]: 1kb chr1-size band')
+                W4 = _Workload(hb, dev, spec4, 1, 0, '', score=False)
+                W4.step()
+                ctx.reset_stats(); barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    _, px4 = W4.step()
+                barrier()
+                dt4 = time.perf_counter() - t0
+                s4 = ctx.stats()
+                cw = s4['chain_wall']['ms'] if 'chain_wall' in s4 else sum(v['ms'] for k, v in s4.items() if k in BYTES_PER_IMAGE_PX)
+                out['band_1kb'] = {'what': 'configs[4]: synthetic 1 kb chr1-size band (248 957 bins, 1 245 frames x 5 levels x 6 images), '
+                                           'frame preparation + StripeSearch chain, shipped kernels, 3 steps',
+                                   'value': round(px4 * 3 / dt4 / 1e6, 2), 'unit': 'contact-Mpx/s', 'ms_per_step': round(dt4 / 3 * 1e3, 3),
+                                   'contact_px_per_step': px4,
+                                   'chain_frac_of_hbm_peak': round(26.0 * px4 * 6 * 3 / (cw * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   'kernels_ms_per_step': {k: round(v['ms'] / 3, 3) for k, v in s4.items()}}
+                W4.release()
+            except Exception as e:      # noqa: BLE001 -- an extra line must not cost the metric line
+                out['band_1kb'] = {'error': str(e)[:200]}
         print(json.dumps(out), flush=True)
     hb.close()
     if world > 1:
@@ -457,6 +442,169 @@ def main():
         if comm == 'gloo' and not rehearse:
             os._exit(0)                   # a failed / hung RCCL probe must not hold the exit
         dist.destroy_process_group()
+
+
+class _Workload:
+    """Everything a step needs, resident on the device: the bands of the chromosomes, maxpixel quantiles, expected values,
+    background tables, the frame tables and this rank's units (pieces of at most one device chunk)."""
+
+    def __init__(self, hb, dev, spec, world, rank, emulate_rank, score=True):
+        import torch
+        from stripenn_amd import synth_device, shard, getStripe as GS, backend as BK
+        self.hb, self.ctx, self.score, self.BK = hb, hb.ctx, score, BK
+        self.names, self.nbins, seeds = spec['names'], spec['nbins'], spec['seeds']
+        names, nbins = self.names, self.nbins
+        self.hw = hw = 512
+        self.bs = int(50000 / RESOL)
+        sizes = np.array([n * RESOL for n in nbins], dtype=np.int64)
+        self.nframes = [-(-n // 200) for n in nbins]
+        my_units = shard.frame_spans(self.nframes, world)[rank]       # (chromosome index, first frame, end frame)
+        if emulate_rank:
+            er, en_ = (int(v) for v in emulate_rank.split('/'))
+            my_units = shard.frame_spans(self.nframes, en_)[er]
+        # pipeline stages: pieces of at most one device chunk (3 072 images = 102 frames at 5 levels x 6 brightness), so that
+        # filling and draining the two-deep pipeline costs a chunk's latency, not a chromosome's
+        piece = max(1, int(os.environ.get('STP_BENCH_PIECE', '102')))
+        self.my_units = [(ci, a, min(a + piece, f1)) for ci, f0, f1 in my_units for a in range(f0, f1, piece)]
+        # ---- untimed set-up: every band in HBM, maxpixel quantiles, expected values, background tables
+        self.chroms, self.tens, self.bands = {}, {}, {}
+        need_all = score                      # the background tables sample every chromosome of the genome
+        for ci, nm in enumerate(names):
+            if not need_all and not any(u[0] == ci for u in self.my_units):
+                continue
+            self.chroms[nm] = synth_device.DeviceChrom(nbins[ci], seeds[ci], dev)
+            self.tens[nm] = self.chroms[nm].band(hw)
+            torch.cuda.synchronize()
+            self.bands[nm] = self.ctx.band_wrap(self.tens[nm].data_ptr(), nbins[ci], hw, keepalive=self.tens[nm])
+        self.Ms = {}
+        for ci in sorted({u[0] for u in self.my_units}):
+            # the reference's getQuantile step (np.quantile(mat[mat > 0], q)) is outside the timed path; on this
+            # band-limited synthetic data the band holds every positive pixel, so the order statistics of the band's
+            # positive entries are those of the dense matrix (sorted on the device, numpy's interpolation on the host)
+            t = self.tens[names[ci]]
+            v = torch.sort(t[t > 0]).values
+            self.Ms[ci] = GS.quantile_linear(lambda ranks: v[torch.as_tensor(ranks, device=dev)].cpu().numpy(), int(v.numel()),
+                                             MAXPIXEL)
+            del v
+        self.EV = {}
+        if score:
+            sel = _DeviceSelector(self.chroms, RESOL)
+            obj = GS.getStripe(sel, RESOL, 10, 8, 2.0, names, names, sizes, sizes, 2, 3, 123456789, backend=hb)
+            for nm in self.bands:
+                obj._bands[nm] = self.bands[nm]
+            EVall = obj.mpmean()
+            self.EV = {ci: np.asarray(EVall[names[ci]]) for ci in {u[0] for u in self.my_units}}
+            bg = obj.nulldist()
+            hb.set_background(*bg)
+        self.tabs = {ci: frame_table(nbins[ci]) for ci in {u[0] for u in self.my_units}}
+        self.host_wait_s = 0.0
+        # Scoring on a host thread of its own, through a second context (the ABI's threading model: one context per host
+        # thread; contexts run concurrently): p-value and Stripiness of unit u are two blocking calls whose kernels queue
+        # beside the chain, and on the search thread they kept it from collecting unit u + 1 in time.  The step ends when
+        # every candidate of every unit is scored (step() joins the queue).  Measured (profiles/r04_ab_score_thread.txt): the
+        # search thread then waits 54 of 80 ms instead of 13 -- and the step takes the same 80 ms: it is device-bound either way
+        # (chain 75 ms + pipeline fill / drain), so the single thread stays the default (STP_BENCH_SCORE_THREAD=1 selects this).
+        self.hb2, self.bands2, self._q, self._thr, self._err = None, {}, None, None, []
+        if score and os.environ.get('STP_BENCH_SCORE_THREAD', '0') == '1':
+            import queue
+            import threading
+            self.hb2 = BK.HipBackend(dev.index or 0)
+            self.hb2.set_background(*bg)
+            for nm in self.bands:
+                self.bands2[nm] = self.hb2.ctx.band_wrap(self.tens[nm].data_ptr(), nbins[names.index(nm)], hw, keepalive=self.tens[nm])
+            self._q = queue.Queue()
+            self._thr = threading.Thread(target=self._score_loop, daemon=True)
+            self._thr.start()
+
+    def _score_loop(self):
+        while True:
+            job = self._q.get()
+            try:
+                if job is None:
+                    return
+                ci, recs, nz, st = job
+                pv, sc = self.BK.score_inputs(recs, nz, st, self.nbins[ci], self.bs)
+                sband = self.bands2[self.names[ci]]
+                self.hb2.pvalue(sband, self.bs, pv)
+                self.hb2.stripiness(sband, self.EV[ci], sc)
+            except BaseException as e:      # noqa: BLE001 -- reported by step()
+                self._err.append(e)
+            finally:
+                self._q.task_done()
+
+    def release(self):
+        import torch
+        if self._thr is not None:
+            self._q.put(None)
+            self._thr.join()
+            self._thr = None
+        for b in list(self.bands2.values()) + list(self.bands.values()):
+            b.close()
+        if self.hb2 is not None:
+            self.hb2.close()
+            self.hb2 = None
+        self.bands, self.bands2, self.tens, self.chroms = {}, {}, {}, {}
+        torch.cuda.empty_cache()
+
+    def stats(self):
+        """per-kernel timers of the step: the search context's and, when scoring runs on its own thread, that context's"""
+        st = dict(self.ctx.stats())
+        if self.hb2 is not None:
+            for k, v in self.hb2.ctx.stats().items():
+                if k in st:
+                    st[k] = {a: st[k][a] + v[a] for a in v}
+                else:
+                    st[k] = v
+        return st
+
+    def reset_stats(self, profiling=True):
+        for c in [self.ctx] + ([self.hb2.ctx] if self.hb2 is not None else []):
+            c.set_profiling(profiling)
+            c.reset_stats()
+
+    def synchronize(self):
+        self.ctx.synchronize()
+        if self.hb2 is not None:
+            self.hb2.ctx.synchronize()
+
+    def _launch(self, unit):
+        """frame compaction + medpixel of one unit (small kernels on the context's auxiliary stream) and its whole
+        StripeSearch chain enqueued on the main stream; returns without waiting for the chain"""
+        ci, f0, f1 = unit
+        st, en = self.tabs[ci]
+        fr = self.bands[self.names[ci]].frames(st[f0:f1], en[f0:f1])
+        return unit, fr, fr.stripe_search_begin(self.Ms[ci])
+
+    def step(self):
+        """Two searches are kept in flight: while the device runs the chain of unit u+1 (and u+2 is queued behind
+        it), the host collects the records of unit u, builds the score inputs and enqueues its p-value /
+        Stripiness kernels -- the single in-order stream never runs dry."""
+        nrec, px = 0, 0.0
+        todo = list(self.my_units)[::-1]
+        flight = [self._launch(todo.pop()) for _ in range(min(2, len(todo)))]
+        while flight:
+            (ci, f0, f1), fr, pend = flight.pop(0)
+            tw = time.perf_counter()
+            recs = pend.wait()
+            self.host_wait_s += time.perf_counter() - tw           # time the host spent waiting for the device
+            if todo:
+                flight.append(self._launch(todo.pop()))
+            if self.score and self._q is not None:
+                self._q.put((ci, recs, np.array(fr.nz), self.tabs[ci][0][f0:f1]))
+            elif self.score:
+                st = self.tabs[ci][0]
+                sband = self.bands[self.names[ci]]
+                pv, sc = self.BK.score_inputs(recs, fr.nz, st[f0:f1], self.nbins[ci], self.bs)
+                self.hb.pvalue(sband, self.bs, pv)
+                self.hb.stripiness(sband, self.EV[ci], sc)
+            nrec += len(recs)
+            px += float((fr.S.astype(np.float64) ** 2).sum())
+            fr.close()
+        if self._q is not None:
+            self._q.join()                      # every candidate of the step is scored
+            if self._err:
+                raise self._err[0]
+        return nrec, px * len(MAXPIXEL)
 
 
 class _DeviceSelector:
