@@ -173,6 +173,14 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
                    uint8_t* vert, int32_t* col_t, int32_t* col_end, int32_t* col_ud,
                    uint8_t* testmat_ud1, uint8_t* testmat_ud2);
 
+/* Device-side evidence for the f32 Canny kernel's error budget (k_canny_f32, stp_canny32.h; replaces nothing of the
+ * reference: skimage _canny.py:53-297 is what the kernel's classes must equal): what the tiles of image (f, M, bi) computed in
+ * f32.  planes: 6 x S x S floats -- smoothed value, the two Sobel sums, magnitude, the grey scale g and the Sobel budget E_G
+ * (in units of 2^-24 g) the pixel's tile used; NaN where the tile was skipped as flat.  counts: candidates (magnitude above
+ * the lowered low threshold), pixels sent to the exact f64 resolver, tile-images handed to the all-f64 kernel. */
+int stp_dbg_canny_f32(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, int32_t f, double M, int32_t bi,
+                      float* planes, int64_t* counts);
+
 /* ---- expected values: getStripe.mpmean (getStripe.py:178-235) --------------------------------
  * For every 400-row frame f of the chromosome and diagonal j < 400:
  *   part_sum[f*400 + j] = sum_i M[i][i+j] over the frame's rows i with i + j < nrows (NaN -> 0),

@@ -790,11 +790,16 @@ static __host__ __device__ stp_c32_layout canny32_layout(int R)
     return L;
 }
 
-template <int RT>
+// DBG (stp_dbg_canny_f32 only; the product launches <RT, false>): after the magnitudes of image dbg_bi the tile's own pixels
+// are dumped -- f32 smoothed value, Sobel sums, magnitude, the scale g and the E_G budget (u g) the tile used, six planes of
+// pitch STP_PITCH -- and dbg_cnt counts the image's candidates, the pixels sent to the resolver and the flagged tile-images.
+template <int RT, bool DBG = false>
 __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
                                                     int nf, int nlev, int nb, const double* __restrict__ gw,
                                                     stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_w32 W32,
-                                                    const float2* __restrict__ cells, uint8_t* __restrict__ xflags)
+                                                    const float2* __restrict__ cells, uint8_t* __restrict__ xflags,
+                                                    float* __restrict__ dbg = nullptr, int dbg_bi = -1,
+                                                    unsigned long long* __restrict__ dbg_cnt = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int R = RT;
@@ -937,7 +942,33 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
 #if STP_ABLATE_C32 == 3                  /* ... after the magnitudes and the candidate collection ... */
         continue;
 #endif
+        int dn0 = 0;
+        if (DBG && bi == dbg_bi) {
+            constexpr size_t PL = (size_t)STP_PITCH * STP_PITCH;
+            for (int i = tid; i < CT_Y * CT_X; i += nt) {
+                const int yy = i / CT_X, xx = i - yy * CT_X, y = T.ty0 + yy, x = T.tx0 + xx;
+                if (y < S && x < S) {
+                    const float* c = sS + (yy + 2) * C32_SP + (xx + 2);
+                    float gi, gj;
+                    c32_sobel(c, &gi, &gj);
+                    const size_t o = (size_t)y * STP_PITCH + x;
+                    dbg[o] = c[0]; dbg[PL + o] = gi; dbg[2 * PL + o] = gj;
+                    dbg[3 * PL + o] = sM[(yy + 1) * (CT_X + 2) + xx + 1];
+                    dbg[4 * PL + o] = sG[bi]; dbg[5 * PL + o] = W32.eu[et][0];
+                }
+            }
+            dn0 = *sDn;                               // (everybody reads it before the class test appends: barrier below)
+            if (tid == 0) atomicAdd(&dbg_cnt[0], (unsigned long long)(sQcnt[0] + sQcnt[1] + sQcnt[2] + sQcnt[3]));
+            __syncthreads();
+        }
         canny32_nms_queue(tid, bi, T, E, sS, sM, sQ, sQcnt, sBits + bi * 2 * CT_Y, sD, sDn, sOv);
+        if (DBG && bi == dbg_bi) {
+            __syncthreads();
+            if (tid == 0) {
+                atomicAdd(&dbg_cnt[1], (unsigned long long)(min(*sDn, C32_DCAP) - min(dn0, C32_DCAP)));
+                if (*sOv) atomicAdd(&dbg_cnt[2], 1ull);
+            }
+        }
     }
     __syncthreads();
     if (tid == 64 && prev >= 0 && *sOv) {            // (the last image's overflow)
@@ -2384,6 +2415,73 @@ struct stp_background {
     int* nvalid = nullptr;      // non-NaN count of each of the 1600 rows
     int ncol = 0;
 };
+
+// Device-side evidence for k_canny_f32's error budget (tests): the chain runs as in stp_dbg_stages, then the DBG instance of
+// the kernel is launched on the same grey images and cell table and dumps what the tiles of image bi computed in f32.
+int stp_dbg_canny_f32(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, int32_t f, double M, int32_t bi,
+                      float* planes, int64_t* counts)
+{
+    if (!ctx || !fr || f < 0 || f >= fr->n || !planes || !counts) return STP_E_ARG;
+    int rc = check_params(ctx, prm);
+    if (rc) return rc;
+    const int nb = prm->n_bright, R = prm->gauss_radius;
+    if (bi < 0 || bi >= nb) return STP_E_ARG;
+    if (!canny_tiled_radius(R) || nb > C32_NBMAX || prm->bfilter != 3)
+        return set_err(ctx, STP_E_UNSUPPORTED, "k_canny_f32 runs for the tiled radii, at most 8 brightness levels (cells: bfilter 3)");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int S = fr->h_S[f];
+    if (S == 0) return set_err(ctx, STP_E_ARG, "frame has <= 10 non-empty columns");
+    dev_buf bM, bB, bW, bGray, bLow, bHigh, bRecs, bCnt, bPl, bC, bX;
+    const size_t nimg = nb, PL = (size_t)STP_PITCH * STP_PITCH;
+    HIPCHK(bM.alloc(ctx, sizeof(double)));
+    HIPCHK(bB.alloc(ctx, nb * sizeof(double)));
+    HIPCHK(bW.alloc(ctx, (2 * R + 1) * sizeof(double)));
+    HIPCHK(bGray.alloc(ctx, nimg * PL * sizeof(float) + 2 * STP_GRAY_GUARD));
+    float* dGray = (float*)((char*)bGray.p + STP_GRAY_GUARD);
+    HIPCHK(bLow.alloc(ctx, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
+    HIPCHK(bHigh.alloc(ctx, nimg * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
+    HIPCHK(bRecs.alloc(ctx, nimg * STP_RCAP_MAX * sizeof(stp_drec)));
+    HIPCHK(bCnt.alloc(ctx, nimg * sizeof(int32_t)));
+    HIPCHK(bPl.alloc(ctx, 6 * PL * sizeof(float)));
+    HIPCHK(bC.alloc(ctx, 4 * sizeof(unsigned long long)));
+    const int tiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
+    HIPCHK(bX.alloc(ctx, nimg * tiles));
+    HIPCHK(hipMemcpyAsync(bM.p, &M, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(bB.p, prm->bright, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(bW.p, prm->gauss_w, (2 * R + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    rc = run_chain(ctx, fr, prm, f, 1, &M, (const double*)bM.p, 1, (const double*)bB.p, (const double*)bW.p, dGray,
+                   (stp_u64*)bLow.p, (stp_u64*)bHigh.p, (stp_drec*)bRecs.p, (int32_t*)bCnt.p, 0, nullptr, nullptr, STP_RCAP_MAX);
+    if (rc) return rc;
+    void* p_cells = nullptr;                         // the table run_chain has just filled (same workspace slot, same size)
+    HIPCHK(ws_get(ctx, WS_CELLS, nimg * GC_ROWS * GC_COLS * sizeof(float2), &p_cells));
+    HIPCHK(hipMemsetAsync(bPl.p, 0xFF, 6 * PL * sizeof(float), ctx->stream));        // NaN: pixels of tiles skipped as flat
+    HIPCHK(hipMemsetAsync(bC.p, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    HIPCHK(hipMemsetAsync(bX.p, 0, nimg * tiles, ctx->stream));
+    stp_w32 W32;
+    for (int k = 0; k <= CT_RMAX; k++) W32.w[k] = k <= R ? (float)prm->gauss_w[k] : 0.0f;
+    c32_budget(prm->gauss_w, R, &W32);
+    const size_t smem = canny32_layout(R).total;
+    const unsigned pgrid = (unsigned)(8 * tiles);
+    switch (R) {
+#define STP_X(RR) case RR: \
+        hipLaunchKernelGGL((k_canny_f32<RR, true>), dim3(pgrid), dim3(256), smem, ctx->stream, (const float*)dGray, fr->d_S, f, 1, 1, nb, \
+                           (const double*)bW.p, (stp_u64*)bLow.p, (stp_u64*)bHigh.p, W32, (const float2*)p_cells, (uint8_t*)bX.p, \
+                           (float*)bPl.p, (int)bi, (unsigned long long*)bC.p); \
+        break;
+        STP_CANNY_RADII(STP_X)
+#undef STP_X
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<float> hp(6 * PL);
+    unsigned long long hc[4];
+    HIPCHK(hipMemcpyAsync(hp.data(), bPl.p, hp.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(hc, bC.p, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int q = 0; q < 6; q++)
+        for (int y = 0; y < S; y++) memcpy(planes + ((size_t)q * S + y) * S, hp.data() + q * PL + (size_t)y * STP_PITCH, S * sizeof(float));
+    counts[0] = (int64_t)hc[0]; counts[1] = (int64_t)hc[1]; counts[2] = (int64_t)hc[2];
+    return STP_OK;
+}
 
 static stp_bandref bref(const stp_band* b) { return stp_bandref{b->d, b->nrows, b->W, b->hw}; }
 

@@ -20,7 +20,7 @@ EXPORTS = [
     'stp_version', 'stp_ctx_create', 'stp_ctx_destroy', 'stp_last_error', 'stp_ctx_set_stream',
     'stp_ctx_synchronize', 'stp_band_upload', 'stp_band_pack', 'stp_band_pack_select', 'stp_band_nearest', 'stp_band_download', 'stp_band_wrap_device', 'stp_band_free',
     'stp_frames_create', 'stp_frames_create_ex', 'stp_frames_info', 'stp_frames_free', 'stp_stripe_search', 'stp_stripe_search_begin', 'stp_stripe_search_count', 'stp_stripe_search_fetch',
-    'stp_stripe_search_cancel', 'stp_dbg_stages', 'stp_dbg_set_sweep_slots',
+    'stp_stripe_search_cancel', 'stp_dbg_stages', 'stp_dbg_canny_f32', 'stp_dbg_set_sweep_slots',
     'stp_set_profiling', 'stp_get_stats', 'stp_reset_stats',
 ]
 
@@ -84,6 +84,7 @@ def load():
     L.stp_frames_free.restype = None
     L.stp_stripe_search.argtypes = [vp, vp, C.POINTER(SearchParams), vp, C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64)]
     L.stp_dbg_stages.argtypes = [vp, vp, C.POINTER(SearchParams), C.c_int32, C.c_double, C.c_int32] + [vp] * 9
+    L.stp_dbg_canny_f32.argtypes = [vp, vp, C.POINTER(SearchParams), C.c_int32, C.c_double, C.c_int32, vp, vp]
     L.stp_stripe_search_begin.argtypes = [vp, vp, C.POINTER(SearchParams), vp, C.c_int32, C.POINTER(vp)]
     L.stp_stripe_search_count.argtypes = [vp, vp, C.POINTER(C.c_int64)]
     L.stp_stripe_search_fetch.argtypes = [vp, vp, vp, C.c_int64]
@@ -392,4 +393,22 @@ class Frames:
         self.ctx._chk(self.ctx.L.stp_dbg_stages(self.ctx.h, self.h, C.byref(p), int(f), float(M), int(bi),
                                                  *[_ptr(out[k]) for k in ('gray', 'cls', 'edges', 'vert', 'col_t',
                                                                           'col_end', 'col_ud', 'testmat1', 'testmat2')]))
+        return out
+
+    def dbg_canny_f32(self, f, M, bi, sigma=2.0, bright=None, gauss_w=None):
+        """What k_canny_f32's tiles computed in f32 for one image (stp_dbg_canny_f32): dict of S x S float arrays
+        smoothed / isobel / jsobel / mag / g / eg (NaN in tiles skipped as flat) and the counts candidates / resolved /
+        flagged."""
+        if bright is None:
+            bright = brightness_levels()
+        if gauss_w is None:
+            gauss_w, gr = gauss_weights(sigma)
+        else:
+            gr = (len(gauss_w) - 1) // 2
+        p, keep = self._params(10, 8, 3, bright, gauss_w, gr)
+        S = int(self.S[f])
+        planes = np.zeros((6, S, S), np.float32); cnt = np.zeros(3, np.int64)
+        self.ctx._chk(self.ctx.L.stp_dbg_canny_f32(self.ctx.h, self.h, C.byref(p), int(f), float(M), int(bi), _ptr(planes), _ptr(cnt)))
+        out = dict(zip(('smoothed', 'isobel', 'jsobel', 'mag', 'g', 'eg'), planes))
+        out.update(candidates=int(cnt[0]), resolved=int(cnt[1]), flagged=int(cnt[2]))
         return out
