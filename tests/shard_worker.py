@@ -20,6 +20,20 @@ def _factory(rank):
     return OracleBackend()
 
 
+def _factory_failing_rank1(rank):
+    """as _factory, but rank 1's backend raises in the middle of a run whose Canny sigma is 3.0 (ComputePool failure test)"""
+    b = _factory(rank)
+    if rank == 1:
+        for name in ('stripe_search', 'stripe_search_begin'):
+            if hasattr(b, name):
+                def poisoned(frames, M_levels, sigma, *a, _orig=getattr(b, name), **k):
+                    if sigma == 3.0:
+                        raise RuntimeError('injected failure on rank 1')
+                    return _orig(frames, M_levels, sigma, *a, **k)
+                setattr(b, name, poisoned)
+    return b
+
+
 def run(rank, world, port, outdir, numcores=2):
     warnings.filterwarnings('ignore')
     import torch.distributed as dist

@@ -123,3 +123,29 @@ def test_persistent_pool_serves_several_runs(tmp_path):
             assert got == open(os.path.join(ref, name)).read(), (k, name)
             assert name != 'result_unfiltered.tsv' or len(got.splitlines()) > 5
         assert 'gpus: 2' in open(os.path.join(str(tmp_path), 'pool%d' % k, 'stripenn.log')).read()
+
+
+def test_pool_reports_a_failing_job_and_shuts_down(tmp_path):
+    """A job that fails on ONE rank (rank 1's backend raises in the middle of the run, the other rank is left waiting in a
+    gloo exchange): the pool reports the failure as an exception naming the rank, terminates every rank process -- nothing
+    is re-launched -- and refuses further work; a run before the failure is complete and correct."""
+    import shard_worker
+    a = shard_worker.ARGS
+    pool = shard.ComputePool(2, backend_factory=shard_worker._factory_failing_rank1)
+    procs = list(pool.procs)
+    pids = dict(pool.pids)
+    out0 = os.path.join(str(tmp_path), 'ok')
+    pool.compute(shard_worker.COOL, out0, a['norm'], a['chrom'], 2.0, a['minL'], a['maxW'], '0.97', 2, a['pvalue'], a['mask'],
+                 a['slow'], a['bfilter'], a['seed'])
+    assert len(open(os.path.join(out0, 'result_unfiltered.tsv')).read().splitlines()) > 5
+    with pytest.raises(RuntimeError, match='rank 1 failed.*injected failure'):
+        pool.compute(shard_worker.COOL, os.path.join(str(tmp_path), 'bad'), a['norm'], a['chrom'], 3.0, a['minL'], a['maxW'], '0.97', 2,
+                     a['pvalue'], a['mask'], a['slow'], a['bfilter'], a['seed'], timeout=300)
+    assert pool.procs == [] and pool.pids == pids                  # shut down, and no rank was started in the meantime
+    for p in procs:
+        p.join(20)
+        assert not p.is_alive()
+    assert not os.path.exists(os.path.join(str(tmp_path), 'bad', 'result_unfiltered.tsv'))
+    with pytest.raises(Exception):
+        pool.compute(shard_worker.COOL, os.path.join(str(tmp_path), 'after'), a['norm'], a['chrom'], 2.0, a['minL'], a['maxW'], '0.97', 2,
+                     a['pvalue'], a['mask'], a['slow'], a['bfilter'], a['seed'], timeout=20)
