@@ -179,7 +179,7 @@ class CoolTable:
     packs and searches the current one: the host holds at most two chromosomes' cis columns.
     Same interface as PixelTable as far as PixelSelector and the facade use it."""
 
-    def __init__(self, path, group=None, chunk=1 << 22):
+    def __init__(self, path, group=None, chunk=1 << 20):
         import h5py
         self._h5 = h5py.File(path, 'r')
         g = self._h5[group] if group else self._h5
@@ -221,21 +221,32 @@ class CoolTable:
         return self._nonneg
 
     def _read_cis(self, chrom):
+        """One chromosome's cis pixels.  The three columns are filled piece by piece into arrays allocated once at the row
+        count the index gives (cis + trans rows of the chromosome's bins; trimmed views are returned), so the reader holds
+        one set of columns per chromosome -- with the read-ahead, two chromosomes' -- and never a second copy."""
         lo, hi = self.chrom_bins(chrom)
         a, b = self.rows_slice(lo, hi)
-        p1, p2, pc = [], [], []
+        n = 0
+        o1 = np.empty(b - a, np.int64); o2 = np.empty(b - a, np.int64)
+        cdt = np.dtype(self.count.dtype)                     # (wider integer columns keep their type: _counts decides)
+        oc = np.empty(b - a, np.float64 if cdt.kind == 'f' else (np.int32 if cdt.itemsize <= 4 and cdt.kind == 'i' else cdt))
         for x in range(a, b, self.chunk):
             y = min(x + self.chunk, b)
             self.max_read = max(self.max_read, y - x)
             b2 = np.asarray(self.bin2_id[x:y])
             keep = b2 < hi                                   # cis pixels of this piece (pixels are sorted by bin1 only)
             if keep.all():
-                p1.append(np.asarray(self.bin1_id[x:y])); p2.append(b2); pc.append(np.asarray(self.count[x:y]))
+                m = y - x
+                o2[n:n + m] = b2
+                o1[n:n + m] = self.bin1_id[x:y]
+                oc[n:n + m] = self.count[x:y]
             else:
-                p1.append(np.asarray(self.bin1_id[x:y])[keep]); p2.append(b2[keep]); pc.append(np.asarray(self.count[x:y])[keep])
-        cat = lambda parts, dt: np.ascontiguousarray(np.concatenate(parts)) if parts else np.zeros(0, dt)   # noqa: E731
-        return (np.asarray(cat(p1, np.int64), dtype=np.int64), np.asarray(cat(p2, np.int64), dtype=np.int64),
-                _counts(cat(pc, np.int32)), lo, hi - lo)
+                m = int(keep.sum())
+                o2[n:n + m] = b2[keep]
+                o1[n:n + m] = np.asarray(self.bin1_id[x:y])[keep]
+                oc[n:n + m] = np.asarray(self.count[x:y])[keep]
+            n += m
+        return o1[:n], o2[:n], _counts(oc[:n]), lo, hi - lo
 
     def prefetch(self, chrom):
         """Start reading the chromosome's cis pixels on a host thread (at most one read ahead is kept)."""

@@ -2,7 +2,7 @@
 # collection; + certified class test; whole kernel) and of k_canny_pipe beside it: timing-only ablation builds, one
 # plain run (kernel time from the library's own event timers) and one PMC pass each, chr16-size chain.
 # Run on the GPU box from the repo root: bash tools/ablate_c32.sh
-make -s -C stripenn_amd/csrc ablate32 || exit 1
+ls stripenn_amd/libstp_ablate_c32_1.so > /dev/null 2>&1 || make -s -C stripenn_amd/csrc ablate32 || exit 1
 R=$(pwd); cd /tmp; export TMPDIR=/tmp
 for l in libstp_ablate_c32_1 libstp_ablate_c32_2 libstp_ablate_c32_3 libstp_ablate_c32_4 libstripenn_hip exact; do
   lib=$R/stripenn_amd/$l.so; mode=f32
