@@ -56,7 +56,13 @@
 // kernel arguments (SGPRs): RN32 of the Gaussian weights, w[R] the centre; the tile-wide budget (E_G, E_M, T0 in units
 // of u * g) for interior tiles [0], for tiles whose windows the image border cuts on ONE side at most (every tile of an
 // image of at least 2R+1 pixels) [1], and for any cut [2] (c32_budget)
-struct stp_w32 { float w[CT_RMAX + 1]; float eu[3][3]; };
+struct stp_w32 {
+    float w[CT_RMAX + 1]; float eu[3][3];
+    // the bleed-over factors of a row whose window lies inside the image on both sides, and of an interior column of such a
+    // row (stp_bleed_v / stp_bleed_h: the same for every such row), with their f32 reciprocals (c32_rb_tables): tiles that the
+    // border does not cut vertically fill their tables from these instead of running the 2R+1-step f64 loops per row
+    double vfull, bifull; float rbfull, rvfull;
+};
 
 // rho = 3 + sum_k P_k / W of one pass for the window cut to taps lo .. hi (-R <= lo <= 0 <= hi <= R), see above
 STP_HD double c32_rho(const double* w /* w[R] = centre */, int R, int lo, int hi)
@@ -84,6 +90,11 @@ STP_HD void c32_budget(const double* w, int R, stp_w32* out)
         const double eg = 8.0 * es[t] + 16.1, em = 1.41422 * eg + 17.7, t0 = 2.0 * em + 17.1;
         out->eu[t][0] = (float)(eg * 1.000001); out->eu[t][1] = (float)(em * 1.000001); out->eu[t][2] = (float)(t0 * 1.000001);
     }
+    const int Sbig = 4 * R + 8;                                        // any size with an interior pixel
+    out->vfull = stp_bleed_v(2 * R + 2, Sbig, R, w);
+    out->bifull = stp_bleed_h(out->vfull, 2 * R + 2, Sbig, R, w);
+    out->rbfull = (float)(1.0 / (out->bifull + DBL_EPSILON));
+    out->rvfull = (float)(1.0 / out->vfull);
 }
 // which of the three a tile uses
 STP_HD int c32_budget_of(bool interior, int S, int R) { return interior ? 0 : (S >= 2 * R + 1 ? 1 : 2); }
@@ -181,6 +192,10 @@ STP_HD void c32_p1_item(stp_tile T, int xx, int yy0, const stp_w32& W, const flo
         typedef const __attribute__((address_space(1))) char* stp_gp;
 #pragma unroll
         for (int k = k0; k < k0 + 2 && k < N; k++)
+#if defined(STP_ABLATE_TD)            /* timing-only build: every STP_ABLATE_TD-th row is loaded, the others repeat it (what the
+                                         kernel would gain from fewer load instructions at unchanged arithmetic) */
+            if (k % STP_ABLATE_TD) raw[k] = raw[k - k % STP_ABLATE_TD] * 1.0001f; else
+#endif
             raw[k] = *(const __attribute__((address_space(1))) float*)((stp_gp)bk + (size_t)boff + (k - k0) * (STP_PITCH * 4));
     }
 #else
@@ -232,15 +247,16 @@ STP_HD void c32_p1_blk(int tid, int nt, stp_tile T, const stp_w32& W, const floa
 //   sRV[yy]  = 1 / column factor of the row,  sRC[xx] = 1 / row factor of tile column xx (0 outside the image):
 // the bleed-over of (row, column) is their product up to f64 roundings (stp_bleed_h scales the row sum by the column
 // factor; eps is 2^-52 of it), so border tiles scale by sRV * sRC without a test per output.
-template <int R>
+template <int R, bool ROWS_DONE = false>          // ROWS_DONE: the row tables are filled already (tiles the border does not cut vertically)
 STP_HD void c32_rb_tables(int tid, int nt, stp_tile T, const double* w, const double* sB, float* sRB, float* sRV, float* sRC,
                           bool xin)
 {
     const int VH = CT_Y + 4;
-    for (int i = tid; i < VH; i += nt) {
-        sRB[i] = (float)(1.0 / (sB[VH + i] + DBL_EPSILON));
-        sRV[i] = (float)(1.0 / sB[i]);                          // (rows outside the image: never used)
-    }
+    if (!ROWS_DONE)
+        for (int i = tid; i < VH; i += nt) {
+            sRB[i] = (float)(1.0 / (sB[VH + i] + DBL_EPSILON));
+            sRV[i] = (float)(1.0 / sB[i]);                      // (rows outside the image: never used)
+        }
     if (xin) return;
     for (int i = tid; i < C32_SP; i += nt) {
         const int x = T.tx0 - 2 + i;

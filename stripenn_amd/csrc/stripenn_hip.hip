@@ -785,7 +785,7 @@ static __host__ __device__ stp_c32_layout canny32_layout(int R)
     L.sD = o; o += C32_DCAP * sizeof(uint16_t);
     L.sBits = o; o += (size_t)C32_NBMAX * 2 * CT_Y * sizeof(stp_u64);
     L.sQn = o; o += 32;                                       // four segment fill counts, list length, overflow flag
-    L.sG = o; o += C32_NBMAX * sizeof(float);                 // largest grey value under the tile's window, per image
+    L.sG = o; o += 2 * C32_NBMAX * sizeof(float);             // largest grey value under the tile's window and flat flag, per image
     L.total = o;
     return L;
 }
@@ -831,9 +831,9 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     float* sG = (float*)(smem + L.sG);
     const int tid = threadIdx.x, nt = blockDim.x, wv = tid >> 6, lane = tid & 63;
     const size_t img0 = ((size_t)fl * nlev + lev) * nb;
-    // which images of this tile are live (not flat: STP_FLAT_RANGE) and the largest grey value under the tile's window:
-    // all cell loads of a lane are in flight together; every wave computes the same verdicts
-    unsigned live = nb >= 32 ? ~0u : ((1u << nb) - 1u);
+    // which images of this tile are live (not flat: STP_FLAT_RANGE) and the largest grey value under the tile's window: wave w
+    // reduces the cells of images w and w + 4 (both cell loads of a lane in flight together), the verdicts meet in LDS
+    int* sFlat = (int*)(sG + C32_NBMAX);
     {
         const int wy0 = max(T.ty0 - R - 2, 0), wy1 = min(T.ty0 + CT_Y + R + 2, S);
         const int wx0 = max(T.tx0 - R - 2, 0), wx1 = min(T.tx0 + CT_X + R + 2, S);
@@ -842,35 +842,50 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         if (use_cells) {
             int cell_off = -1;
             if (lane < nr * nc) { const int rr = lane / nc; cell_off = (r0 + rr) * GC_COLS + c0 + (lane - rr * nc); }
-            float2 cv[C32_NBMAX];
+            float2 cv[2];
 #pragma unroll
-            for (int bi = 0; bi < C32_NBMAX; bi++) {
-                cv[bi] = make_float2(INFINITY, -INFINITY);
-                if (bi < nb && cell_off >= 0) cv[bi] = cells[(img0 + bi) * (GC_ROWS * GC_COLS) + cell_off];
+            for (int q = 0; q < 2; q++) {
+                const int bi = wv + 4 * q;
+                cv[q] = make_float2(INFINITY, -INFINITY);
+                if (bi < nb && cell_off >= 0) cv[q] = cells[(img0 + bi) * (GC_ROWS * GC_COLS) + cell_off];
             }
 #pragma unroll
-            for (int bi = 0; bi < C32_NBMAX; bi++) {
-                float mn = cv[bi].x, mx = cv[bi].y;
+            for (int q = 0; q < 2; q++) {
+                const int bi = wv + 4 * q;
+                float mn = cv[q].x, mx = cv[q].y;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
-                if (bi < nb && mx - mn < STP_FLAT_RANGE) live &= ~(1u << bi);   // flat window: no pixel of this tile can reach the low
-                                                                               // threshold (its class words stay 0)
-                if (tid == 0) sG[bi] = mx;
+                if (lane == 0 && bi < C32_NBMAX) {
+                    sG[bi] = mx;
+                    sFlat[bi] = (bi < nb && mx - mn < STP_FLAT_RANGE) ? 1 : 0;   // flat window: no pixel of this tile can reach the
+                                                                                // low threshold (its class words stay 0)
+                }
             }
-        } else if (tid < C32_NBMAX) sG[tid] = 1.0000005f;     // k_gray's grey values never exceed 0.299 + 0.587 + 0.114 (+ 3 roundings)
+        } else if (tid < C32_NBMAX) { sG[tid] = 1.0000005f; sFlat[tid] = 0; }   // k_gray's grey values never exceed 0.299 + 0.587 + 0.114 (+ 3 roundings)
     }
-    live = (unsigned)__builtin_amdgcn_readfirstlane((int)live);
     for (int i = tid; i < nb * 2 * CT_Y; i += nt) sBits[i] = 0ull;
     if (tid == 64) { *sDn = 0; *sOv = 0; }
     const bool yin = (T.ty0 - R - 2 >= 0) && (T.ty0 + CT_Y + R + 1 < S);
     const bool xin = (T.tx0 - 2 - R >= 0) && (T.tx0 + CT_X + 1 + R < S);
     double* sB = (double*)(smem + L.sB);
     {   // f64 bleed-over factors of the tile's rows and their f32 reciprocal tables
+        constexpr int VH = CT_Y + 4;
         if (tid < 2 * R + 1) sW[tid] = gw[tid];
-        canny_p1b(tid, nt, T, R, gw, sB);
-        __syncthreads();
-        c32_rb_tables<R>(tid, nt, T, sW, sB, sRB, sRV, sRC, xin);
+        if (yin) {                                   // every row's window inside the image: one value for all (stp_w32)
+            if (tid < VH) { sB[tid] = W32.vfull; sB[VH + tid] = W32.bifull; sRB[tid] = W32.rbfull; sRV[tid] = W32.rvfull; }
+            __syncthreads();
+            if (!xin) c32_rb_tables<R, true>(tid, nt, T, sW, sB, sRB, sRV, sRC, xin);
+        } else {
+            canny_p1b(tid, nt, T, R, gw, sB);
+            __syncthreads();
+            c32_rb_tables<R, false>(tid, nt, T, sW, sB, sRB, sRV, sRC, xin);
+        }
     }
+    unsigned live = 0;
+    __syncthreads();                                 // the verdicts of all four waves
+#pragma unroll
+    for (int bi = 0; bi < C32_NBMAX; bi++) live |= (bi < nb && !sFlat[bi]) ? (1u << bi) : 0u;
+    live = (unsigned)__builtin_amdgcn_readfirstlane((int)live);
     static_assert((CT_Y + 4) % C32_VRUN_R(R) == 0, "whole row groups");
     constexpr int NR1 = ((CT_X + 2 * R + 4) * ((CT_Y + 4) / C32_VRUN_R(R)) + 255) / 256;
     constexpr int NR2 = ((CT_Y + 4) * ((CT_X + 4 + CT_HRUN_R(R) - 1) / CT_HRUN_R(R)) + 255) / 256;
