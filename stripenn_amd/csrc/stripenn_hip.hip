@@ -672,7 +672,6 @@ __device__ __forceinline__ void canny32_mag_rows(int tid, stp_cwin C, int my_lo,
         const bool colin = X >= mx_lo && X < mx_lo + nmw;
         const bool xcand = colin && (unsigned)(X - C.x0) < (unsigned)C.nx;
         uint16_t* q = sQ + wv * C32_QSEG;
-        const stp_u64 lt = (1ull << lane) - 1ull;
         // all rows of the strip in one go (round 4): the RMAX + 2 smoothed rows are requested together -- one LDS
         // round trip per image instead of one per row -- and the walk is unrolled (no register rotation, no
         // pointer arithmetic per row); rows beyond the strip repeat its last row and are not used
@@ -690,7 +689,8 @@ __device__ __forceinline__ void canny32_mag_rows(int tid, stp_cwin C, int my_lo,
                 if (colin) sM[Y * MW + X] = m;
                 const bool isq = xcand && (unsigned)(Y - C.y0) < (unsigned)C.ny && m >= thr;
                 const stp_u64 bq = __ballot(isq);
-                if (isq) q[cnt + __popcll(bq & lt)] = (uint16_t)((Y - 1) * 64 + (X - 1));
+                if (isq) q[cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bq, 0u))] =
+                             (uint16_t)((Y - 1) * 64 + (X - 1));
                 cnt += __popcll(bq);
             }
         }
@@ -710,6 +710,8 @@ __device__ __forceinline__ void canny32_nms_queue(int tid, int bi, stp_tile T, s
     stp_u64* lowB = sBits;
     stp_u64* highB = sBits + CT_Y;
     const int n0 = sQcnt[0], n1 = n0 + sQcnt[1], n2 = n1 + sQcnt[2], n = n2 + sQcnt[3];
+    // (measured and dropped in round 4: every wave testing its own segment -- no search for the segment, 12 instructions
+    //  less per candidate -- took the same time: the strips' candidate counts differ and the slowest wave sets the pace)
     for (int k = tid; k < n; k += 256) {                             // candidate k of the four wave segments, in order
         const int seg = (k >= n0) + (k >= n1) + (k >= n2);
         const int idx = k - (seg == 0 ? 0 : (seg == 1 ? n0 : (seg == 2 ? n1 : n2)));

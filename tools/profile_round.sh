@@ -17,12 +17,13 @@ if [ "$WL" = "chr16" ]; then STEPS=20; PSTEPS=2; fi
 B="$R/bench.py --workload $WL"
 timeout 600 python3 $B --steps $STEPS --warmup 1 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
+B="$B --no-extras"
 timeout 400 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/${TAG}_kt -o kt -- python3 $B --steps $STEPS --warmup 1 --no-cpu-baseline --no-e2e > $OUT/${TAG}_kt.log 2>&1 || exit 1
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 400 rocprofv3 --output-format csv --pmc $C -d $OUT/${TAG}_pmc_$C -o pmc -- python3 $B --steps $PSTEPS --warmup 0 --no-cpu-baseline --no-e2e > $OUT/${TAG}_pmc_$C.log 2>&1 || exit 1
 done
 timeout 400 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $OUT/${TAG}_pmc_SQ -o pmc -- python3 $B --steps $PSTEPS --warmup 0 --no-cpu-baseline --no-e2e > $OUT/${TAG}_pmc_SQ.log 2>&1 || exit 1
-timeout 400 rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY -d $OUT/${TAG}_pmc_SQ2 -o pmc -- python3 $B --steps $PSTEPS --warmup 0 --no-cpu-baseline --no-e2e > $OUT/${TAG}_pmc_SQ2.log 2>&1 || exit 1
+timeout 400 rocprofv3 --output-format csv --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/${TAG}_pmc_SQ2 -o pmc -- python3 $B --steps $PSTEPS --warmup 0 --no-cpu-baseline --no-e2e > $OUT/${TAG}_pmc_SQ2.log 2>&1 || exit 1
 cd $R
 python3 tools/summarize_profile.py $TAG $WL
 # the raw traces are large (gpurun copies back at most 64 MiB): keep the summaries only
