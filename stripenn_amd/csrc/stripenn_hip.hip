@@ -14,6 +14,12 @@
 #ifndef STP_ABLATE_C32
 #define STP_ABLATE_C32 0   /* 1..4: timing-only builds of k_canny_f32 (make ablate32), never shipped */
 #endif
+#ifndef STP_PV_NT
+#define STP_PV_NT 256      /* threads per stripe of k_pvalue / k_stripiness */
+#endif
+#ifndef STP_SC_NT
+#define STP_SC_NT 128
+#endif
 #include "stp_score.h"
 #include "stp_select.h"
 
@@ -2657,10 +2663,10 @@ int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pvalue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
         if (!big)
-            hipLaunchKernelGGL(k_pvalue<false>, dim3((unsigned)n), dim3(256), lds, ctx->aux, bref(band), (const double*)bg->sorted,
+            hipLaunchKernelGGL(k_pvalue<false>, dim3((unsigned)n), dim3(STP_PV_NT), lds, ctx->aux, bref(band), (const double*)bg->sorted,
                                (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p, hmax);
         else
-            hipLaunchKernelGGL(k_pvalue<true>, dim3((unsigned)n), dim3(256), lds, ctx->aux, bref(band), (const double*)bg->sorted,
+            hipLaunchKernelGGL(k_pvalue<true>, dim3((unsigned)n), dim3(STP_PV_NT), lds, ctx->aux, bref(band), (const double*)bg->sorted,
                                (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p, hmax);
     }
     HIPCHK(hipGetLastError());
@@ -2710,10 +2716,10 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stripiness<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
         if (!big)
-            hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)n), dim3(128), lds, ctx->aux, bref(band), (const double*)bE.p,
+            hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)n), dim3(STP_SC_NT), lds, ctx->aux, bref(band), (const double*)bE.p,
                                (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n), HR, CW);
         else
-            hipLaunchKernelGGL(k_stripiness<true>, dim3((unsigned)n), dim3(128), lds, ctx->aux, bref(band), (const double*)bE.p,
+            hipLaunchKernelGGL(k_stripiness<true>, dim3((unsigned)n), dim3(STP_SC_NT), lds, ctx->aux, bref(band), (const double*)bE.p,
                                (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n), HR, CW);
     }
     HIPCHK(hipGetLastError());
