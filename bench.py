@@ -581,7 +581,8 @@ class _Workload:
         Stripiness kernels -- the single in-order stream never runs dry."""
         nrec, px = 0, 0.0
         todo = list(self.my_units)[::-1]
-        flight = [self._launch(todo.pop()) for _ in range(min(2, len(todo)))]
+        depth = int(os.environ.get('STP_BENCH_FLIGHT', '2'))
+        flight = [self._launch(todo.pop()) for _ in range(min(depth, len(todo)))]
         while flight:
             (ci, f0, f1), fr, pend = flight.pop(0)
             tw = time.perf_counter()
