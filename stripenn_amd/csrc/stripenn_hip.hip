@@ -14,6 +14,9 @@
 #ifndef STP_ABLATE_C32
 #define STP_ABLATE_C32 0   /* 1..4: timing-only builds of k_canny_f32 (make ablate32), never shipped */
 #endif
+#ifndef STP_GRAY_LEVRUNS
+#define STP_GRAY_LEVRUNS 1    /* workgroups per tile of k_gray_c3, each walking a run of the maxpixel levels (measured: 1 -> 17.0, 2 -> 17.5, 5 -> 19.9 ms per genome step) */
+#endif
 #ifndef STP_PV_NT
 #define STP_PV_NT 256      /* threads per stripe of k_pvalue / k_stripiness */
 #endif
@@ -208,9 +211,11 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
     const bool xin = x < S;
     const int nrows = min(GS_ROWS, S - y0);                                  // rows of the strip inside the image (wave-uniform)
     const double* g0 = sg + (strip * GS_ROWS) * WW + lane;                   // g~ of (strip row -1, columns x-1 .. x+1)
-    for (int lev = 0; lev < nlev; lev++) {
+    // (gridDim.y workgroups may share a tile's levels -- STP_GRAY_LEVRUNS; one workgroup for all of them measured fastest)
+    const int lev_lo = (int)((long long)nlev * blockIdx.y / gridDim.y), lev_hi = (int)((long long)nlev * (blockIdx.y + 1) / gridDim.y);
+    for (int lev = lev_lo; lev < lev_hi; lev++) {
         const double M = Mlev[lev], rM = 1.0 / M;
-        if (lev) __syncthreads();                                            // everybody is done with the previous level's plane
+        if (lev > lev_lo) __syncthreads();                                   // everybody is done with the previous level's plane
 #pragma unroll
         for (int k = 0; k < IT; k++) {
             const int i = tid + k * 256;
@@ -249,6 +254,9 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
                 } else if (nrows == GS_ROWS) {                                // (whole strip inside the image: no test per row)
 #pragma unroll
                     for (int j = 0; j < GS_ROWS; j++) {
+#if defined(STP_ABLATE_GRAY_ST)        /* timing-only build: a quarter of the store instructions */
+                        if (j % 4 == 0)
+#endif
                         gimg[j * STP_PITCH] = out[j];
                         const unsigned bits = __float_as_uint(out[j]);       // grey values are >= +0: their bit patterns order like the values
                         vmn = min(vmn, bits); vmx = max(vmx, bits);
@@ -2052,7 +2060,7 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         const char* gray_env = getenv("STP_GRAY");        // read per call: the tests compare both kernels in one process
         const bool gray_exact = (gray_env && strcmp(gray_env, "exact") == 0) || !levels_normal;
         if (a == 1 && !gray_exact)
-            hipLaunchKernelGGL(k_gray_c3, dim3(tiles, 1, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
+            hipLaunchKernelGGL(k_gray_c3, dim3(tiles, STP_GRAY_LEVRUNS < nlev ? STP_GRAY_LEVRUNS : nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
                                fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (float2*)p_cells);
         else if (a == 1)
             hipLaunchKernelGGL(k_gray<1>, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
