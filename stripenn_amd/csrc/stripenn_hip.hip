@@ -1187,6 +1187,15 @@ __global__ __launch_bounds__(512, RCAP == STP_RCAP ? 6 : 4) void k_lines(const s
     lines_load(tid, nt, S, limg, himg, bufA, bufB);
     __syncthreads();
     if (dbg_stop == 1) { if (tid == 0) rec_count[img] = (int)(bufB[3] & 0); return; }      // timing-only ablation
+    if (!want_dbg) {   // an image without a single strong pixel has no edges (hysteresis keeps only components that hold
+                       // one: _canny.py:286-296), hence no vertical lines and no records: nothing left to do
+        stp_u64 any = 0ull;
+        for (int i = tid; i < S * STP_NW; i += nt) any |= bufB[i];
+        if (!__syncthreads_or(any != 0ull)) {
+            if (tid == 0) rec_count[img] = 0;
+            return;
+        }
+    }
     {   // hysteresis closure: one (8-row strip x word) item per lane, rows held in registers across sweeps
         const int nitem = ((S + STP_HYST_STRIP - 1) / STP_HYST_STRIP) * STP_NW;       // <= 350 < blockDim
         const bool has = tid < nitem;
