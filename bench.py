@@ -170,6 +170,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the end-to-end `compute` run (quantile -> TSVs) at N = 1')
     ap.add_argument('--no-score', action='store_true', help='StripeSearch chain only (for very long chromosomes)')
+    ap.add_argument('--canny', type=float, default=2.0, help='Canny sigma (2.0 = the reference default; `score` passes 2.5)')
     ap.add_argument('--no-extras', action='store_true', help='skip the extra measurements of the N = 1 line: the all-f64 kernels on the same workload and the 1 kb chr1-size band')
     ap.add_argument('--allow-stp-lib', action='store_true', help='accept a library named by STP_LIB (profiling builds)')
     ap.add_argument('--emulate-rank', default='', help='R/N: time the share rank R of an N-rank run would get, alone on this GPU (diagnostic: per-rank fixed costs without an N-GPU node; the line is NOT a multi-GPU measurement)')
@@ -257,7 +258,7 @@ def main():
     t_setup = time.time()
     hb = BK.HipBackend(local_rank)       # raises if the HIP extension / GPU is missing: no CPU fallback
     ctx = hb.ctx
-    W = _Workload(hb, dev, spec, world, rank, args.emulate_rank, score=not args.no_score)
+    W = _Workload(hb, dev, spec, world, rank, args.emulate_rank, score=not args.no_score, sigma=args.canny)
     setup_s = time.time() - t_setup
     names, nbins, nframes = W.names, W.nbins, W.nframes
 
@@ -359,7 +360,7 @@ def main():
                                       'compaction + medpixel + StripeSearch chain%s, bands resident in HBM'
                                       % (spec['wl'], sum(nbins), sum(nframes), len(MAXPIXEL),
                                          '' if args.no_score else ' + p-value and Stripiness of every candidate stripe'),
-                          'chromosomes': len(names), 'frames': int(sum(nframes)), 'levels': len(MAXPIXEL),
+                          'chromosomes': len(names), 'frames': int(sum(nframes)), 'levels': len(MAXPIXEL), 'canny_sigma': args.canny,
                           'images_per_step': int(sum(nframes) * len(MAXPIXEL) * 6),
                           'contact_px_per_step': total_px, 'stripe_records_per_step': int(total_rec),
                           'sharding': 'contiguous (chromosome x frame) spans of equal frame count, one process per GPU, '
@@ -416,7 +417,7 @@ def main():
             W.release()
             try:
                 spec4 = dict(names=['chr1_1kb'], nbins=[248957], seeds=[5], wl='configs[4]: 1kb chr1-size band')
-                W4 = _Workload(hb, dev, spec4, 1, 0, '', score=False)
+                W4 = _Workload(hb, dev, spec4, 1, 0, '', score=False, sigma=args.canny)
                 W4.step()
                 ctx.reset_stats(); barrier()
                 t0 = time.perf_counter()
@@ -448,10 +449,10 @@ class _Workload:
     """Everything a step needs, resident on the device: the bands of the chromosomes, maxpixel quantiles, expected values,
     background tables, the frame tables and this rank's units (pieces of at most one device chunk)."""
 
-    def __init__(self, hb, dev, spec, world, rank, emulate_rank, score=True):
+    def __init__(self, hb, dev, spec, world, rank, emulate_rank, score=True, sigma=2.0):
         import torch
         from stripenn_amd import synth_device, shard, getStripe as GS, backend as BK
-        self.hb, self.ctx, self.score, self.BK = hb, hb.ctx, score, BK
+        self.hb, self.ctx, self.score, self.BK, self.sigma = hb, hb.ctx, score, BK, float(sigma)
         self.names, self.nbins, seeds = spec['names'], spec['nbins'], spec['seeds']
         names, nbins = self.names, self.nbins
         self.hw = hw = 512
@@ -508,7 +509,11 @@ class _Workload:
         if score and os.environ.get('STP_BENCH_SCORE_THREAD', '0') == '1':
             import queue
             import threading
+            prio = os.environ.get('STP_BENCH_SCORE_PRIORITY')      # stream priority of the scoring context (measurement hook)
+            if prio:
+                os.environ['STP_AUX_PRIORITY'] = prio
             self.hb2 = BK.HipBackend(dev.index or 0)
+            os.environ.pop('STP_AUX_PRIORITY', None)
             self.hb2.set_background(*bg)
             for nm in self.bands:
                 self.bands2[nm] = self.hb2.ctx.band_wrap(self.tens[nm].data_ptr(), nbins[names.index(nm)], hw, keepalive=self.tens[nm])
@@ -573,7 +578,7 @@ class _Workload:
         ci, f0, f1 = unit
         st, en = self.tabs[ci]
         fr = self.bands[self.names[ci]].frames(st[f0:f1], en[f0:f1])
-        return unit, fr, fr.stripe_search_begin(self.Ms[ci])
+        return unit, fr, fr.stripe_search_begin(self.Ms[ci], sigma=self.sigma)
 
     def step(self):
         """Two searches are kept in flight: while the device runs the chain of unit u+1 (and u+2 is queued behind

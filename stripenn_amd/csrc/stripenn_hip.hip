@@ -1631,7 +1631,9 @@ int stp_ctx_create(int device_ordinal, stp_ctx** out)
         // highest priority, so its kernels get compute units as soon as the chain's workgroups retire
         int plo = 0, phi = 0;
         (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
-        if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, phi) != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return STP_E_HIP; }
+        const char* ap = getenv("STP_AUX_PRIORITY");          // measurement hook: "low" / "normal" instead of the highest
+        const int prio = (ap && strcmp(ap, "low") == 0) ? plo : ((ap && strcmp(ap, "normal") == 0) ? (plo + phi) / 2 : phi);
+        if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, prio) != hipSuccess) { (void)hipStreamDestroy(ctx->stream); delete ctx; return STP_E_HIP; }
     }
     if (hipStreamCreateWithFlags(&ctx->io, hipStreamNonBlocking) != hipSuccess) {
         (void)hipStreamDestroy(ctx->aux); (void)hipStreamDestroy(ctx->stream); delete ctx; return STP_E_HIP;
