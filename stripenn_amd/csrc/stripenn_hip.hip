@@ -637,7 +637,7 @@ template <int RT>
 __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe_list(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
                                                      int nf, int nlev, int nb, const double* __restrict__ gw,
                                                      stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_fastdiv fd,
-                                                     const uint8_t* __restrict__ xflags)
+                                                     uint8_t* __restrict__ xflags)
 {
     constexpr int TPI = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);   // 91
     const int n = nf * nlev * nb * TPI;
@@ -655,6 +655,7 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe_list(const
                 m[w] &= m[w] - 1;
                 const int img = k / TPI, tile = k - img * TPI;
                 canny_pipe_tile<RT>(gray, fS, f0, nf, nlev, nb, gw, low, high, fd, nullptr, img / nb, tile, img % nb, img % nb + 1);
+                if (threadIdx.x == 0) xflags[k] = 0;                      // served: the buffer is all zero again after this launch
                 __syncthreads();
             }
     }
@@ -1454,6 +1455,7 @@ struct stp_ctx {
     std::vector<std::pair<std::vector<double>, stp_fastdiv>> fd_cache;   // verified interior bleed-over divisions
     int sweep_slots = STP_RCAP;            // record slots per image in the first pass (stp_dbg_set_sweep_slots)
     std::vector<std::pair<size_t, void*>> pin_free;   // pinned staging buffers of finished searches, recycled
+    void* c32q_zero = nullptr; size_t c32q_zero_bytes = 0;   // the flag buffer known to be all zero (k_canny_pipe_list clears what it reads)
 };
 
 struct stp_band {
@@ -2097,7 +2099,12 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
             const size_t nflags = nimg * tiles;       // tile-images k_canny_f32 hands over to the exact kernel (see there)
             void* p_x = nullptr;
             HIPCHK(ws_get(ctx, WS_C32Q, nflags, &p_x));
-            HIPCHK(hipMemsetAsync(p_x, 0, nflags, ctx->stream));
+            // the flags are zero between launches: k_canny_pipe_list clears every flag it has served, so the buffer is
+            // cleared here only when it is new (no fill kernel -- two launch gaps -- between k_gray and the Canny kernel)
+            if (ctx->c32q_zero != p_x || ctx->c32q_zero_bytes < ctx->ws_bytes[WS_C32Q]) {
+                HIPCHK(hipMemsetAsync(p_x, 0, ctx->ws_bytes[WS_C32Q], ctx->stream));
+                ctx->c32q_zero = p_x; ctx->c32q_zero_bytes = ctx->ws_bytes[WS_C32Q];
+            }
             const stp_fastdiv fd = make_fastdiv(ctx, prm->gauss_w, R);
             const size_t smem = canny32_layout(R).total, smem_x = canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES;
             const unsigned xgrid = (unsigned)std::min<size_t>(2048, (nflags + 255) / 256);
@@ -2106,7 +2113,7 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
                 hipLaunchKernelGGL(k_canny_f32<RR>, dim3(pgrid), dim3(256), smem, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, d_w, \
                                    d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x); \
                 hipLaunchKernelGGL(k_canny_pipe_list<RR>, dim3(xgrid), dim3(256), smem_x, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, \
-                                   d_w, d_low, d_high, fd, (const uint8_t*)p_x); \
+                                   d_w, d_low, d_high, fd, (uint8_t*)p_x); \
                 break;
                 STP_CANNY_RADII(STP_X)
 #undef STP_X
