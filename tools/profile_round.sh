@@ -14,7 +14,7 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 STEPS=5; PSTEPS=1
 if [ "$WL" = "chr16" ]; then STEPS=20; PSTEPS=2; fi
-B="$R/bench.py --workload $WL"
+B="$R/bench.py --workload $WL ${STP_PROFILE_BENCH_ARGS:-}"
 timeout 600 python3 $B --steps $STEPS --warmup 1 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 B="$B --no-extras"

@@ -39,7 +39,7 @@ for d in sorted(glob.glob('%s/%s_pmc_*' % (out, tag))):
 with open('%s/%s_pmc.csv' % (out, tag), 'w') as fh:
     fh.write('kernel,counter,launches,mean_per_launch\n')
     for r in rows:
-        fh.write('%s,%s,%d,%.1f\n' % r)
+        fh.write('"%s",%s,%d,%.1f\n' % r)
 print('wrote %s/%s_kernel_stats.csv and %s/%s_pmc.csv (%d rows)' % (out, tag, out, tag, len(rows)))
 
 # bench.py's view: per launch means keyed by the library's own kernel names
