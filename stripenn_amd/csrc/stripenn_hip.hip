@@ -1414,6 +1414,33 @@ __global__ __launch_bounds__(256) void k_band_pack(const int64_t* __restrict__ b
 // ============================================================================================
 // host side
 // ============================================================================================
+// STP_LOG_ALLOC=1 (diagnostics): every device allocation / release and every host range pinned in place is written to
+// stderr with the source line that asked for it, so that a faulting address can be placed among the buffers
+static bool stp_log_on() { static const bool on = getenv("STP_LOG_ALLOC") != nullptr; return on; }
+static hipError_t stp_dmalloc(int line, void** p, size_t n)
+{
+    const hipError_t e = hipMalloc(p, n);
+    if (stp_log_on()) fprintf(stderr, "[stp] malloc L%d %p .. %p (%zu B) rc %d\n", line, *p, (void*)((char*)*p + n), n, (int)e);
+    return e;
+}
+static hipError_t stp_dfree(int line, void* p)
+{
+    if (stp_log_on()) fprintf(stderr, "[stp] free   L%d %p\n", line, p);
+    return hipFree(p);
+}
+static hipError_t stp_hreg(int line, void* p, size_t n, unsigned flags)
+{
+    const hipError_t e = hipHostRegister(p, n, flags);
+    if (stp_log_on()) fprintf(stderr, "[stp] hreg   L%d %p .. %p (%zu B) rc %d\n", line, p, (void*)((char*)p + n), n, (int)e);
+    return e;
+}
+static hipError_t stp_hunreg(int line, void* p)
+{
+    const hipError_t e = hipHostUnregister(p);
+    if (stp_log_on()) fprintf(stderr, "[stp] hunreg L%d %p rc %d\n", line, p, (int)e);
+    return e;
+}
+
 struct stp_kstat {
     std::string name;
     int64_t launches = 0;
@@ -1486,10 +1513,10 @@ static hipError_t ws_get(stp_ctx* ctx, int slot, size_t bytes, void** out)
         if (ctx->ws[slot]) {
             hipError_t es = hipStreamSynchronize(ctx->stream);
             if (es != hipSuccess) return es;
-            (void)hipFree(ctx->ws[slot]);
+            (void)stp_dfree(__LINE__, ctx->ws[slot]);
         }
         ctx->ws[slot] = nullptr; ctx->ws_bytes[slot] = 0;
-        hipError_t e = hipMalloc(&ctx->ws[slot], bytes);
+        hipError_t e = stp_dmalloc(__LINE__, &ctx->ws[slot], bytes);
         if (e != hipSuccess) return e;
         ctx->ws_bytes[slot] = bytes;
     }
@@ -1514,13 +1541,13 @@ static hipError_t pool_alloc(stp_ctx* ctx, size_t bytes, void** out)
             ctx->pool_bytes -= r;
             return hipSuccess;
         }
-    return hipMalloc(out, r);
+    return stp_dmalloc(__LINE__, out, r);
 }
 static void pool_release(stp_ctx* ctx, void* p, size_t bytes)
 {
     if (!p) return;
     const size_t r = pool_round(bytes ? bytes : 1);
-    if (ctx->pool_bytes + r > ((size_t)4 << 30)) { (void)hipFree(p); return; }   // keep at most 4 GiB idle (of 288)
+    if (ctx->pool_bytes + r > ((size_t)4 << 30)) { (void)stp_dfree(__LINE__, p); return; }   // keep at most 4 GiB idle (of 288)
     ctx->pool_free.push_back(std::make_pair(r, p));
     ctx->pool_bytes += r;
 }
@@ -1531,6 +1558,7 @@ static hipError_t pin_get(stp_ctx* ctx, size_t bytes, void** out)
         if (ctx->pin) (void)hipHostFree(ctx->pin);
         ctx->pin = nullptr; ctx->pin_bytes = 0;
         hipError_t e = hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault);
+        if (stp_log_on()) fprintf(stderr, "[stp] hostmalloc ctx %p (%zu B)\n", ctx->pin, bytes);
         if (e != hipSuccess) return e;
         ctx->pin_bytes = bytes;
     }
@@ -1652,8 +1680,8 @@ void stp_ctx_destroy(stp_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     resolve_pending(ctx);
-    for (int i = 0; i < WS_NSLOTS; i++) if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
-    for (auto& e : ctx->pool_free) (void)hipFree(e.second);
+    for (int i = 0; i < WS_NSLOTS; i++) if (ctx->ws[i]) (void)stp_dfree(__LINE__, ctx->ws[i]);
+    for (auto& e : ctx->pool_free) (void)stp_dfree(__LINE__, e.second);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& e : ctx->pin_free) (void)hipHostFree(e.second);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -1706,14 +1734,14 @@ struct host_pin {
         static const bool off = getenv("STP_NO_PIN") != nullptr;
         st = stream;
         if (off || !ptr || bytes < ((size_t)1 << 20)) return;
-        if (hipHostRegister((void*)ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = (void*)ptr;
+        if (stp_hreg(__LINE__, (void*)ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = (void*)ptr;
         else (void)hipGetLastError();                       // clear the sticky error: pageable copies from here on
     }
     ~host_pin()
     {
         if (!p) return;
         (void)hipStreamSynchronize(st);
-        if (hipHostUnregister(p) != hipSuccess) (void)hipGetLastError();
+        if (stp_hunreg(__LINE__, p) != hipSuccess) (void)hipGetLastError();
     }
 };
 
@@ -1728,7 +1756,7 @@ int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_
     b->nrows = nrows; b->hw = hw; b->W = 2 * hw; b->owned = true;
     double* d = nullptr;
     size_t bytes = (size_t)nrows * b->W * sizeof(double);
-    hipError_t e = hipMalloc((void**)&d, bytes);
+    hipError_t e = stp_dmalloc(__LINE__, (void**)&d, bytes);
     if (e != hipSuccess) { delete b; return set_err(ctx, STP_E_NOMEM, "hipMalloc(band) failed"); }
     {
         host_pin pin;
@@ -1736,7 +1764,7 @@ int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_
         e = hipMemcpyAsync(d, band_host, bytes, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
-    if (e != hipSuccess) { (void)hipFree(d); delete b; return set_err(ctx, STP_E_HIP, "band upload failed"); }
+    if (e != hipSuccess) { (void)stp_dfree(__LINE__, d); delete b; return set_err(ctx, STP_E_HIP, "band upload failed"); }
     b->d = d;
     *out = b;
     return STP_OK;
@@ -1758,8 +1786,8 @@ void stp_band_free(stp_ctx* ctx, stp_band* b)
 {
     if (!b) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    if (b->owned && b->d) (void)hipFree((void*)b->d);
-    if (b->near) (void)hipFree(b->near);
+    if (b->owned && b->d) (void)stp_dfree(__LINE__, (void*)b->d);
+    if (b->near) (void)stp_dfree(__LINE__, b->near);
     delete b;
 }
 
@@ -1872,7 +1900,7 @@ struct dev_buf {                      // per-call device buffer, recycled throug
     void* p = nullptr;
     size_t n = 0;
     stp_ctx* c = nullptr;
-    ~dev_buf() { if (p) { if (c) pool_release(c, p, n); else (void)hipFree(p); } }
+    ~dev_buf() { if (p) { if (c) pool_release(c, p, n); else (void)stp_dfree(__LINE__, p); } }
     hipError_t alloc(stp_ctx* ctx, size_t bytes) { c = ctx; n = bytes; return pool_alloc(ctx, bytes, &p); }
 };
 
@@ -1906,7 +1934,7 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
     b->nrows = nrows; b->hw = hw; b->W = 2 * hw; b->owned = true;
     double* d = nullptr;
     const size_t bytes = (size_t)nrows * b->W * sizeof(double);
-    if (hipMalloc((void**)&d, bytes) != hipSuccess) { delete b; return set_err(ctx, STP_E_NOMEM, "hipMalloc(band) failed"); }
+    if (stp_dmalloc(__LINE__, (void**)&d, bytes) != hipSuccess) { delete b; return set_err(ctx, STP_E_NOMEM, "hipMalloc(band) failed"); }
     // (measured and dropped in round 3: two pinned staging sets filled by eight host threads, 40 MB pieces, DMA of piece
     //  k beside the host copy of piece k + 1 -- 0.34 s for the 5.3 GB of the mm10-size table against 0.26 s for the
     //  runtime's own pageable path; what does pay is pinning the caller's columns IN PLACE for the call: host_pin)
@@ -1918,8 +1946,8 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
     pin2.pin(bin2, (size_t)npix * sizeof(int64_t), ctx->io);
     pinc.pin(count, (size_t)npix * csz, ctx->io);
     int32_t* near = nullptr;
-    if (hipMalloc((void**)&near, (size_t)nrows * 2 * sizeof(int32_t)) != hipSuccess) {
-        (void)hipFree(d); delete b;
+    if (stp_dmalloc(__LINE__, (void**)&near, (size_t)nrows * 2 * sizeof(int32_t)) != hipSuccess) {
+        (void)stp_dfree(__LINE__, d); delete b;
         return set_err(ctx, STP_E_NOMEM, "hipMalloc(band nearest-pixel table) failed");
     }
     hipError_t e = hipMemsetD32Async((hipDeviceptr_t)near, 0x7FFFFFFF, (size_t)nrows * 2, ctx->io);
@@ -1977,7 +2005,7 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->io);
     if (e != hipSuccess) {
-        (void)hipFree(d); (void)hipFree(near); delete b;
+        (void)stp_dfree(__LINE__, d); (void)stp_dfree(__LINE__, near); delete b;
         return set_err(ctx, e == hipErrorOutOfMemory ? STP_E_NOMEM : STP_E_HIP, std::string("band pack: ") + hipGetErrorString(e));
     }
     b->d = d;
@@ -2226,6 +2254,7 @@ static int search_enqueue(stp_ctx* ctx, stp_search* s)
                 }
             if (!s->pin) {
                 HIPCHK(hipHostMalloc(&s->pin, pb, hipHostMallocDefault));
+                if (stp_log_on()) fprintf(stderr, "[stp] hostmalloc search %p (%zu B)\n", s->pin, pb);
                 s->pin_bytes = pb;
             }
         }
@@ -2610,16 +2639,16 @@ int stp_background_upload(stp_ctx* ctx, const double* lu, const double* ru, cons
     stp_background* bg = new (std::nothrow) stp_background();
     if (!bg) return STP_E_NOMEM;
     const size_t tn = (size_t)STP_NDIAG * ncol;
-    if (hipMalloc((void**)&bg->d, 4 * tn * sizeof(double)) != hipSuccess) { delete bg; return set_err(ctx, STP_E_NOMEM, "hipMalloc(background)"); }
+    if (stp_dmalloc(__LINE__, (void**)&bg->d, 4 * tn * sizeof(double)) != hipSuccess) { delete bg; return set_err(ctx, STP_E_NOMEM, "hipMalloc(background)"); }
     bg->ncol = ncol;
     const double* src[4] = {lu, ru, ld, rd};
     for (int t = 0; t < 4; t++) {
         hipError_t e = hipMemcpyAsync(bg->d + t * tn, src[t], tn * sizeof(double), hipMemcpyHostToDevice, ctx->aux);
-        if (e != hipSuccess) { (void)hipFree(bg->d); delete bg; return set_err(ctx, STP_E_HIP, "background upload failed"); }
+        if (e != hipSuccess) { (void)stp_dfree(__LINE__, bg->d); delete bg; return set_err(ctx, STP_E_HIP, "background upload failed"); }
     }
-    if (ncol > STP_BG_MAXCOL) { (void)hipFree(bg->d); delete bg; return set_err(ctx, STP_E_UNSUPPORTED, "background tables wider than 2048 columns"); }
-    if (hipMalloc((void**)&bg->sorted, 4 * tn * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&bg->nvalid, 4 * STP_NDIAG * sizeof(int)) != hipSuccess) {
+    if (ncol > STP_BG_MAXCOL) { (void)stp_dfree(__LINE__, bg->d); delete bg; return set_err(ctx, STP_E_UNSUPPORTED, "background tables wider than 2048 columns"); }
+    if (stp_dmalloc(__LINE__, (void**)&bg->sorted, 4 * tn * sizeof(double)) != hipSuccess ||
+        stp_dmalloc(__LINE__, (void**)&bg->nvalid, 4 * STP_NDIAG * sizeof(int)) != hipSuccess) {
         stp_background_free(ctx, bg);
         return set_err(ctx, STP_E_NOMEM, "hipMalloc(sorted background)");
     }
@@ -2638,9 +2667,9 @@ void stp_background_free(stp_ctx* ctx, stp_background* bg)
 {
     if (!bg) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    if (bg->d) (void)hipFree(bg->d);
-    if (bg->sorted) (void)hipFree(bg->sorted);
-    if (bg->nvalid) (void)hipFree(bg->nvalid);
+    if (bg->d) (void)stp_dfree(__LINE__, bg->d);
+    if (bg->sorted) (void)stp_dfree(__LINE__, bg->sorted);
+    if (bg->nvalid) (void)stp_dfree(__LINE__, bg->nvalid);
     delete bg;
 }
 
@@ -2817,7 +2846,7 @@ int stp_select_create(stp_ctx* ctx, stp_select** out)
     HIPCHK(hipSetDevice(ctx->device));
     stp_select* s = new (std::nothrow) stp_select();
     if (!s) return STP_E_NOMEM;
-    if (hipMalloc((void**)&s->state, sizeof(stp_sel_state)) != hipSuccess) { delete s; return set_err(ctx, STP_E_NOMEM, "hipMalloc(select state)"); }
+    if (stp_dmalloc(__LINE__, (void**)&s->state, sizeof(stp_sel_state)) != hipSuccess) { delete s; return set_err(ctx, STP_E_NOMEM, "hipMalloc(select state)"); }
     *out = s;
     return STP_OK;
 }
@@ -2826,8 +2855,8 @@ void stp_select_free(stp_ctx* ctx, stp_select* s)
 {
     if (!s) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    for (auto& c : s->chunks) { if (ctx) pool_release(ctx, c.first, (size_t)c.second * sizeof(double)); else (void)hipFree(c.first); }
-    if (s->state) (void)hipFree(s->state);
+    for (auto& c : s->chunks) { if (ctx) pool_release(ctx, c.first, (size_t)c.second * sizeof(double)); else (void)stp_dfree(__LINE__, c.first); }
+    if (s->state) (void)stp_dfree(__LINE__, s->state);
     delete s;
 }
 

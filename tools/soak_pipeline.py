@@ -15,6 +15,8 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 t0 = time.time(); bad = 0; rows = 0; nexc = 0
 for seed in range(first, first + count):
+    if os.environ.get('STP_SOAK_VERBOSE'):
+        print('seed', seed, flush=True)
     rng = np.random.default_rng(seed)
     resol = int(rng.choice([5000, 5000, 10000]))
     nchr = int(rng.integers(1, 4))
