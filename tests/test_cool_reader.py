@@ -126,3 +126,33 @@ def test_compute_from_the_mcool_file_equals_compute_from_the_table(tmp_path, mon
                          force=True, backend=OracleBackend(gauss_w=gw))
         outs.append([open(os.path.join(out, f)).read() for f in ('result_unfiltered.tsv', 'result_filtered.tsv')])
     assert outs[0] == outs[1] and outs[0][0].count('\n') > 5
+
+
+@pytest.mark.parametrize('layout', ['gzip', 'gzip+shuffle', 'plain', 'lzf', 'gzip+fletcher32'])
+def test_chunk_decoder_equals_hdf5s_filter_pipeline(tmp_path, layout):
+    """The pixel columns of the usual cooler layouts (chunked 1-d, deflate with or without byte shuffle) are inflated
+    outside HDF5 on host threads (pixels._ChunkReader); every other layout goes through h5py's ordinary read.  Both routes
+    give the table's columns, whatever the piece boundaries (pieces that start and end inside HDF5 chunks, a short last
+    chunk), for int32 and float64 counts."""
+    names, chroms, t = _table(float_counts=(layout == 'gzip'))
+    path = str(tmp_path / 'l.mcool')
+    _write(path, t)
+    kw = {'gzip': dict(compression='gzip'), 'gzip+shuffle': dict(compression='gzip', shuffle=True, compression_opts=6),
+          'plain': dict(), 'lzf': dict(compression='lzf'), 'gzip+fletcher32': dict(compression='gzip', fletcher32=True)}[layout]
+    with h5py.File(path, 'a') as f:
+        g = f[GROUP]
+        for k, v in (('bin1_id', t.bin1_id), ('bin2_id', t.bin2_id), ('count', t.count)):
+            del g['pixels/' + k]
+            g.create_dataset('pixels/' + k, data=v, chunks=(1000,), **kw)
+    direct = layout in ('gzip', 'gzip+shuffle')
+    for threads in (4, 1):
+        lazy = pixels.CoolTable(path, GROUP, chunk=2345)
+        lazy.threads = threads
+        for nm in names:
+            a, b = lazy.chrom_pixels(nm), t.chrom_pixels(nm)
+            assert all(np.array_equal(x, y) and x.dtype == y.dtype for x, y in zip(a[:3], b[:3])), (layout, threads, nm)
+        n = len(t.count)
+        p = lazy._read_piece(n - 1500, n)                   # the short last chunk
+        assert np.array_equal(p[0], t.bin1_id[n - 1500:]) and np.array_equal(p[2], t.count[n - 1500:])
+        assert (lazy.direct_reads > 0) == (direct and threads > 1), (layout, threads, lazy.direct_reads)
+        lazy.close()
