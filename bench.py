@@ -279,6 +279,7 @@ def main():
     dt_rank = time.perf_counter() - t0
     stats = W.stats()
     host_wait_ms = W.host_wait_s / (args.steps + args.warmup) * 1e3      # (the warm-up steps count too: same work)
+    host_call_ms = W.host_call_s / (args.steps + args.warmup) * 1e3
     dt, total_px, total_rec, rank_ms = dt_rank, contact_px, nrec, [dt_rank / args.steps * 1e3]
     if world > 1:
         tmax = torch.tensor([dt_rank], dtype=torch.float64, device=rdev)
@@ -366,7 +367,8 @@ def main():
                           'sharding': 'contiguous (chromosome x frame) spans of equal frame count, one process per GPU, '
                                       'no collective on the data path',
                           'rank_ms_per_step': [round(t, 3) for t in rank_ms], 'setup_s': round(setup_s, 1),
-                          'host_wait_ms_per_step': round(host_wait_ms, 2),      # of ms_per_step the search thread spent waiting for searches: the rest is host work the device may or may not hide
+                          'host_wait_ms_per_step': round(host_wait_ms, 2),      # of ms_per_step the search thread spent waiting for searches ...
+                          'host_blocked_ms_per_step': round(host_wait_ms + host_call_ms, 2),   # ... and inside every blocking device call (searches, frame preparation, p-value, Stripiness); the rest is Python / numpy work (score inputs, bookkeeping)
                           'score_thread': W.hb2 is not None,                     # p-value / Stripiness calls on a host thread and context of their own
 
                           'comm': comm, 'comm_note': comm_note, 'devices': devnames,
@@ -499,6 +501,7 @@ class _Workload:
             hb.set_background(*bg)
         self.tabs = {ci: frame_table(nbins[ci]) for ci in {u[0] for u in self.my_units}}
         self.host_wait_s = 0.0
+        self.host_call_s = 0.0          # time inside the other blocking device calls of the step (frames, p-value, Stripiness)
         # Scoring on a host thread of its own, through a second context (the ABI's threading model: one context per host
         # thread; contexts run concurrently): p-value and Stripiness of unit u are two blocking calls whose kernels queue
         # beside the chain, and on the search thread they kept it from collecting unit u + 1 in time.  The step ends when
@@ -587,22 +590,28 @@ class _Workload:
         nrec, px = 0, 0.0
         todo = list(self.my_units)[::-1]
         depth = int(os.environ.get('STP_BENCH_FLIGHT', '2'))
+        tw = time.perf_counter()
         flight = [self._launch(todo.pop()) for _ in range(min(depth, len(todo)))]
+        self.host_call_s += time.perf_counter() - tw
         while flight:
             (ci, f0, f1), fr, pend = flight.pop(0)
             tw = time.perf_counter()
             recs = pend.wait()
             self.host_wait_s += time.perf_counter() - tw           # time the host spent waiting for the device
             if todo:
+                tw = time.perf_counter()
                 flight.append(self._launch(todo.pop()))
+                self.host_call_s += time.perf_counter() - tw       # frame preparation (blocking: S / nz / medpixel come back) + enqueue
             if self.score and self._q is not None:
                 self._q.put((ci, recs, np.array(fr.nz), self.tabs[ci][0][f0:f1]))
             elif self.score:
                 st = self.tabs[ci][0]
                 sband = self.bands[self.names[ci]]
                 pv, sc = self.BK.score_inputs(recs, fr.nz, st[f0:f1], self.nbins[ci], self.bs)
+                tw = time.perf_counter()
                 self.hb.pvalue(sband, self.bs, pv)
                 self.hb.stripiness(sband, self.EV[ci], sc)
+                self.host_call_s += time.perf_counter() - tw       # two blocking calls: copy in, kernel, copy out
             nrec += len(recs)
             px += float((fr.S.astype(np.float64) ** 2).sum())
             fr.close()

@@ -1723,25 +1723,64 @@ static int check_hw(stp_ctx* ctx, int64_t nrows, int32_t hw)
 
 // The caller's (pageable) host array pinned in place for the duration of one call: the copies out of it then run as DMA at
 // PCIe speed (57 GB/s measured on the MI355X box) instead of through the runtime's staging copies (11-20 GB/s);
-// registering 2 GiB of touched pages takes 17 ms.  Failing to register (range already registered, overlapping pages,
-// STP_NO_PIN=1) is not an error: the copies fall back to the pageable path.  The stream is drained before the range
-// is released.
+// registering 2 GiB of touched pages takes 17 ms.  Only the WHOLE PAGES inside the range are registered (round 4): two
+// ranges -- the three columns of a small table that sit next to each other in the heap, the slices of consecutive
+// chromosomes out of one column, somebody else's buffer behind the array -- then never share a page, so releasing one
+// range cannot touch a page another transfer still reads; the ragged head and tail (< 4 KB each) travel as pageable
+// copies of their own (copy()).  A range whose pages are pinned already (the caller's own registration) is used as it
+// is and left alone.  Failing to register (STP_NO_PIN=1, the runtime refusing) is not an error: the copies fall back to
+// the pageable path.  The stream is drained before the range is released.
+// (Measured and dropped in round 4: the driver pinning the NEXT chromosome's columns from a second host thread while the
+//  current ones cross PCIe -- band packing stayed at 0.15-0.16 s for the 5.3 GB of the mm10-size table: the transfers,
+//  not the page pinning between them, set that time.)
+#define STP_PIN_PAGE ((uintptr_t)4096)
+static bool stp_pin_body(const void* ptr, size_t bytes, char** lo, char** hi)
+{
+    static const bool off = getenv("STP_NO_PIN") != nullptr;
+    if (off || !ptr || bytes < ((size_t)1 << 20)) return false;
+    const uintptr_t a = ((uintptr_t)ptr + STP_PIN_PAGE - 1) & ~(STP_PIN_PAGE - 1), b = ((uintptr_t)ptr + bytes) & ~(STP_PIN_PAGE - 1);
+    if (b <= a) return false;
+    *lo = (char*)a; *hi = (char*)b;
+    return true;
+}
+static bool stp_is_pinned(const void* p)
+{
+    hipPointerAttribute_t at;          // (hipHostGetFlags answers for hipHostMalloc memory only)
+    if (hipPointerGetAttributes(&at, p) == hipSuccess) return at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    return false;
+}
 struct host_pin {
-    void* p = nullptr;
+    char *lo = nullptr, *hi = nullptr;    // the pinned pages [lo, hi) inside the caller's range (none: lo == hi)
+    bool mine = false;                    // registered here (released by the destructor)
     hipStream_t st = nullptr;
     void pin(const void* ptr, size_t bytes, hipStream_t stream)
     {
-        static const bool off = getenv("STP_NO_PIN") != nullptr;
         st = stream;
-        if (off || !ptr || bytes < ((size_t)1 << 20)) return;
-        if (stp_hreg(__LINE__, (void*)ptr, bytes, hipHostRegisterDefault) == hipSuccess) p = (void*)ptr;
+        char *a, *b;
+        if (!stp_pin_body(ptr, bytes, &a, &b)) return;
+        if (stp_is_pinned(a) && stp_is_pinned(b - 1)) { lo = a; hi = b; return; }      // the caller's registration: nothing to do or undo
+        if (stp_hreg(__LINE__, a, (size_t)(b - a), hipHostRegisterDefault) == hipSuccess) { lo = a; hi = b; mine = true; }
         else (void)hipGetLastError();                       // clear the sticky error: pageable copies from here on
+    }
+    // host -> device copy of [src, src + bytes) out of the range given to pin(): the pinned pages as one transfer (DMA),
+    // what lies before and after them as pageable copies of their own
+    hipError_t copy(void* dst, const void* src, size_t bytes, hipStream_t stream) const
+    {
+        const char *s0 = (const char*)src, *s1 = s0 + bytes;
+        const char *b0 = s0 > lo ? s0 : lo, *b1 = s1 < hi ? s1 : hi;
+        if (lo == hi || b0 >= b1) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+        hipError_t e = hipSuccess;
+        if (s0 < b0) e = hipMemcpyAsync(dst, s0, (size_t)(b0 - s0), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync((char*)dst + (b0 - s0), b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess && b1 < s1) e = hipMemcpyAsync((char*)dst + (b1 - s0), b1, (size_t)(s1 - b1), hipMemcpyHostToDevice, stream);
+        return e;
     }
     ~host_pin()
     {
-        if (!p) return;
+        if (!mine) return;
         (void)hipStreamSynchronize(st);
-        if (stp_hunreg(__LINE__, p) != hipSuccess) (void)hipGetLastError();
+        if (stp_hunreg(__LINE__, lo) != hipSuccess) (void)hipGetLastError();
     }
 };
 
@@ -1761,7 +1800,7 @@ int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_
     {
         host_pin pin;
         pin.pin(band_host, bytes, ctx->stream);
-        e = hipMemcpyAsync(d, band_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+        e = pin.copy(d, band_host, bytes, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
     if (e != hipSuccess) { (void)stp_dfree(__LINE__, d); delete b; return set_err(ctx, STP_E_HIP, "band upload failed"); }
@@ -1966,9 +2005,11 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
     }
     for (int64_t p0 = 0; e == hipSuccess && p0 < npix; p0 += CH) {
         const int64_t n = npix - p0 < CH ? npix - p0 : CH;
-        e = hipMemcpyAsync(b1.p, bin1 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->io);
-        if (e == hipSuccess) e = hipMemcpyAsync(b2.p, bin2 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->io);
-        if (e == hipSuccess) e = hipMemcpyAsync(bc.p, count + (size_t)p0 * csz, (size_t)n * csz, hipMemcpyHostToDevice, ctx->io);
+        // (measured and dropped in round 4: bin2_id on a second upload stream, i.e. a second copy engine -- the 5.3 GB of the
+        //  mm10-size table took the same 0.15-0.16 s: ~35 GB/s is what this host's memory feeds the link)
+        e = pin1.copy(b1.p, bin1 + p0, (size_t)n * sizeof(int64_t), ctx->io);
+        if (e == hipSuccess) e = pin2.copy(b2.p, bin2 + p0, (size_t)n * sizeof(int64_t), ctx->io);
+        if (e == hipSuccess) e = pinc.copy(bc.p, count + (size_t)p0 * csz, (size_t)n * csz, ctx->io);
         if (e != hipSuccess) break;
         {
             prof_scope ps(ctx, "band_pack", (double)n * 36.0, ctx->io);    // 20 B of table read + two 8 B cells written
@@ -2908,9 +2949,9 @@ int stp_select_append_pixels_ex(stp_ctx* ctx, stp_select* s, const int64_t* bin1
         const int64_t n = npix - p0 < CH ? npix - p0 : CH;
         double* out = nullptr;
         HIPCHK(pool_alloc(ctx, (size_t)n * 2 * sizeof(double), (void**)&out));
-        hipError_t e = hipMemcpyAsync(d1.p, bin1 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->io);
-        if (e == hipSuccess) e = hipMemcpyAsync(d2.p, bin2 + p0, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->io);
-        if (e == hipSuccess) e = hipMemcpyAsync(dc.p, count + (size_t)p0 * csz, (size_t)n * csz, hipMemcpyHostToDevice, ctx->io);
+        hipError_t e = pin1.copy(d1.p, bin1 + p0, (size_t)n * sizeof(int64_t), ctx->io);
+        if (e == hipSuccess) e = pin2.copy(d2.p, bin2 + p0, (size_t)n * sizeof(int64_t), ctx->io);
+        if (e == hipSuccess) e = pinc.copy(dc.p, count + (size_t)p0 * csz, (size_t)n * csz, ctx->io);
         if (e == hipSuccess) {
             prof_scope ps(ctx, "select_pixels", 36.0 * n, ctx->io);
             if (count_type == STP_COUNT_F64)
