@@ -8,6 +8,7 @@
 #include <vector>
 #include <algorithm>
 #include <new>
+#include <mutex>
 #include "../../include/stripenn_hip.h"
 #include "stp_phases.h"
 #include "stp_canny32.h"
@@ -1479,7 +1480,6 @@ struct stp_ctx {
     bool profiling = false;
     std::vector<stp_kstat> stats;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<std::pair<std::vector<double>, stp_fastdiv>> fd_cache;   // verified interior bleed-over divisions
     int sweep_slots = STP_RCAP;            // record slots per image in the first pass (stp_dbg_set_sweep_slots)
     std::vector<std::pair<size_t, void*>> pin_free;   // pinned staging buffers of finished searches, recycled
     void* c32q_zero = nullptr; size_t c32q_zero_bytes = 0;   // the flag buffer known to be all zero (k_canny_pipe_list clears what it reads)
@@ -2081,9 +2081,14 @@ int stp_band_download(stp_ctx* ctx, const stp_band* band, double* out_host)
 // multiply + 2 FMA division by it for every float mantissa (cached per weight vector).
 static stp_fastdiv make_fastdiv(stp_ctx* ctx, const double* w, int R)
 {
-    // cached per context (contexts may be driven from different host threads) and per weight vector: a few
-    // vectors are kept so that alternating sigmas do not re-run the 8 M-iteration verification
-    for (auto& e : ctx->fd_cache)
+    // cached per process and per weight vector (contexts may be driven from different host threads: one lock around the
+    // look-up and the 8 M-iteration verification, ~20 ms, which every new context of a process used to pay again); a few
+    // vectors are kept so that alternating sigmas do not re-run it
+    static std::mutex fd_mutex;
+    static std::vector<std::pair<std::vector<double>, stp_fastdiv>> fd_cache;
+    std::lock_guard<std::mutex> fd_lock(fd_mutex);
+    (void)ctx;
+    for (auto& e : fd_cache)
         if ((int)e.first.size() == 2 * R + 1 && memcmp(e.first.data(), w, (2 * R + 1) * sizeof(double)) == 0) return e.second;
     stp_fastdiv fd;
     const int S = 4 * R + 8;                                       // any size with an interior pixel
@@ -2098,8 +2103,8 @@ static stp_fastdiv make_fastdiv(stp_ctx* ctx, const double* w, int R)
         const double q = stp_div_const((double)f, fd.c, fd.rc), t = (double)f / fd.c;
         if (memcmp(&q, &t, 8) != 0) fd.ok = 0;
     }
-    if (ctx->fd_cache.size() >= 8) ctx->fd_cache.erase(ctx->fd_cache.begin());
-    ctx->fd_cache.push_back(std::make_pair(std::vector<double>(w, w + 2 * R + 1), fd));
+    if (fd_cache.size() >= 8) fd_cache.erase(fd_cache.begin());
+    fd_cache.push_back(std::make_pair(std::vector<double>(w, w + 2 * R + 1), fd));
     return fd;
 }
 
@@ -2394,7 +2399,9 @@ int stp_stripe_search_count(stp_ctx* ctx, stp_search* s, int64_t* out_count)
             break;
         }
         if ((size_t)s->n * sizeof(stp_stripe_rec) > s->out_bytes) return set_err(ctx, STP_E_CAPACITY, "record compaction overran its buffer");
-        ctx->rec_guess = s->n + s->n / 4 + 64;
+        // (a slowly decaying maximum: a search that finds more records than the speculative copy brought needs a second
+        //  round trip, and units of one genome differ by more than 25 % from one to the next)
+        ctx->rec_guess = std::max(s->n + s->n / 4 + 64, ctx->rec_guess - ctx->rec_guess / 16);
     }
     *out_count = s->n;
     return STP_OK;
@@ -2410,9 +2417,11 @@ int stp_stripe_search_fetch(stp_ctx* ctx, stp_search* s, stp_stripe_rec* out, in
         const size_t have = std::min((size_t)n, s->guess);
         memcpy(out, (char*)s->pin + s->rec_off, have * sizeof(stp_stripe_rec));
         if ((size_t)n > have) {
+            // the rest comes over the upload stream: this search is complete (its event), and on ctx->stream the copy would
+            // wait behind every later search already queued -- the pipeline would drain for it
             hipError_t e = hipMemcpyAsync(out + have, (stp_stripe_rec*)s->d_out + have, ((size_t)n - have) * sizeof(stp_stripe_rec),
-                                          hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                                          hipMemcpyDeviceToHost, ctx->io);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->io);
             if (e != hipSuccess) rc = set_err(ctx, STP_E_HIP, std::string("record copy: ") + hipGetErrorString(e));
         }
     }
