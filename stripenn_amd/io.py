@@ -4,7 +4,7 @@ a synthetic genome for tests / benchmarks ("synth:" URIs), or cooler's tables as
 
     synth:chr1=7000000,chr2=4500000;resol=5000;seed=31
     pixels:/path/table.npz            (PixelTable.save)
-    pixels:/path/file.mcool::resolutions/5000   (h5py, when importable)
+    pixels:/path/file.mcool::resolutions/5000   (h5py when importable, else stripenn_amd.h5lite)
 """
 import numpy as np
 import pandas as pd
@@ -62,12 +62,9 @@ def open_matrix(cool):
         return pixel_matrix(table)
     try:
         import cooler
-    except ImportError as e:
-        try:                                   # no cooler: read the file's tables directly (cooler URI "path::group")
-            import h5py  # noqa: F401
-        except ImportError:
-            raise ImportError('cooler or h5py is required to open %r (only "synth:" / "pixels:*.npz" inputs work '
-                              'without them)' % cool) from e
+    except ImportError:
+        # no cooler: read the file's tables directly (cooler URI "path::group") -- through h5py when it is there, else
+        # through the package's own reader of the HDF5 subset cooler files use (stripenn_amd/h5lite.py)
         from . import pixels
         path, _, group = str(cool).partition('::')
         return pixel_matrix(pixels.CoolTable(path, group.lstrip('/') or None))      # lazy: pixel columns stay in the file

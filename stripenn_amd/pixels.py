@@ -15,7 +15,7 @@ on the host, and ``chrom_pixels`` hands the cis pixels of one chromosome to the 
 cooler is absent from the build image (parity of this reader against cooler itself is unpinned); the
 arithmetic above restates cooler's `matrix()` dense branch (`arr * np.outer(bias1, bias2)`, `bias = 1 / bias`
 under `divisive_weights`, which defaults to `balance in {"KR", "VC", "SQRT_VC"}`).  Tables travel as .npz (``save`` / ``load``); a
-.cool / .mcool group is read through h5py when it is importable.
+.cool / .mcool group is read through h5py when it is importable, else through stripenn_amd.h5lite.
 """
 import os
 
@@ -38,6 +38,20 @@ def _counts(count):
     if c.size and (c.min() < -2**31 or c.max() > 2**31 - 1):
         return np.ascontiguousarray(c, dtype=np.float64)            # exact below 2^53
     return np.ascontiguousarray(c, dtype=np.int32)
+
+
+def open_hdf5(path, backend=None):
+    """The file through h5py when it is importable, else through the package's own reader of the HDF5 subset cooler
+    files use (stripenn_amd.h5lite); `backend` = 'h5py' / 'h5lite' forces one (tests)."""
+    if backend in (None, 'h5py'):
+        try:
+            import h5py
+            return h5py.File(path, 'r')
+        except ImportError:
+            if backend == 'h5py':
+                raise
+    from . import h5lite
+    return h5lite.File(path)
 
 
 class PixelTable:
@@ -130,9 +144,8 @@ class PixelTable:
 
     @classmethod
     def from_cool(cls, path, group=None):
-        """Read the tables of a .cool file / an .mcool resolution group with h5py (no cooler needed)."""
-        import h5py
-        with h5py.File(path, 'r') as f:
+        """Read the tables of a .cool file / an .mcool resolution group (h5py, or the built-in reader: no cooler needed)."""
+        with open_hdf5(path) as f:
             g = f[group] if group else f
             names = [c.decode() if isinstance(c, bytes) else str(c) for c in g['chroms/name'][:]]
             sizes = g['chroms/length'][:]
@@ -214,7 +227,7 @@ class _ChunkReader:
 
 
 class CoolTable:
-    """cooler's tables read LAZILY from the .cool file / .mcool resolution group (h5py): what replaces
+    """cooler's tables read LAZILY from the .cool file / .mcool resolution group (h5py or h5lite): what replaces
     `cooler.Cooler(cool)` + `matrix(balance=norm)` (stripenn.py:80, 118) when cooler is absent, at real file sizes.
 
     Only the small tables are read at once (chromosome names / lengths, `indexes/chrom_offset`, `indexes/bin1_offset`,
@@ -226,9 +239,8 @@ class CoolTable:
     packs and searches the current one: the host holds at most two chromosomes' cis columns.
     Same interface as PixelTable as far as PixelSelector and the facade use it."""
 
-    def __init__(self, path, group=None, chunk=1 << 20):
-        import h5py
-        self._h5 = h5py.File(path, 'r')
+    def __init__(self, path, group=None, chunk=1 << 20, backend=None):
+        self._h5 = open_hdf5(path, backend)
         g = self._h5[group] if group else self._h5
         self._g = g
         self.chromnames = [c.decode() if isinstance(c, bytes) else str(c) for c in g['chroms/name'][:]]
@@ -239,6 +251,9 @@ class CoolTable:
         self.weights = {k: np.ascontiguousarray(g['bins'][k][:], dtype=np.float64)
                         for k in g['bins'].keys() if k not in ('chrom', 'start', 'end')}
         self.bin1_id, self.bin2_id, self.count = g['pixels/bin1_id'], g['pixels/bin2_id'], g['pixels/count']
+        for d in (self.bin1_id, self.bin2_id, self.count):     # (the built-in reader indexes a column's chunks on first use:
+            if hasattr(d, '_chunk_index') and getattr(d, 'chunks', None):      #  done here, before reader threads exist)
+                d._chunk_index()
         self.chunk = int(chunk)
         self.max_read = 0            # largest single read of a pixel column, in pixels (tests)
         self.threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)))

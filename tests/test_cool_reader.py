@@ -19,48 +19,13 @@ from oracle_backend import OracleBackend          # noqa: E402
 from stripenn_amd import io as sio, pixels, stripenn, synth   # noqa: E402
 
 warnings.filterwarnings('ignore')
-RESOL = 5000
-GROUP = 'resolutions/5000'
-
-
-def _table(float_counts=False):
-    names = ['chrA', 'chrB', 'chrC']
-    chroms = {n: synth.SynthChrom(nb, 51 + k, stripe_every=90, stripe_gain=3.0) for k, (n, nb) in enumerate(zip(names, (900, 700, 450)))}
-    t = pixels.PixelTable.from_synth(names, chroms, RESOL)
-    # trans pixels (cooler stores them in the same table, sorted by (bin1, bin2)): a few per bin of chrA / chrB
-    rng = np.random.default_rng(5)
-    off = t.chrom_offset
-    tb1 = np.concatenate([rng.integers(off[0], off[1], 4000), rng.integers(off[1], off[2], 2500)])
-    tb2 = np.concatenate([rng.integers(off[1], off[3], 4000), rng.integers(off[2], off[3], 2500)])
-    key = np.unique(tb1 * (1 << 32) + tb2)
-    tb1, tb2 = key >> 32, key & ((1 << 32) - 1)
-    b1 = np.concatenate([t.bin1_id, tb1]); b2 = np.concatenate([t.bin2_id, tb2])
-    cn = np.concatenate([t.count, rng.integers(1, 4, len(tb1)).astype(np.int32)])
-    order = np.lexsort((b2, b1))
-    cnt = cn[order] * 0.25 if float_counts else cn[order]
-    kr = 1.0 / (t.weights['weight'] * 1.37)                   # a divisive column as hic2cool writes it
-    full = pixels.PixelTable(names, t.chromsizes, RESOL, off, b1[order], b2[order], cnt, {'weight': t.weights['weight'], 'KR': kr})
-    return names, chroms, full
+import cool_fixture as CF                          # noqa: E402
+RESOL, GROUP = CF.RESOL, CF.GROUP
+_table = CF.table
 
 
 def _write(path, t):
-    with h5py.File(path, 'w') as f:
-        g = f.create_group(GROUP)
-        g.attrs['bin-size'] = t.binsize
-        g.create_dataset('chroms/name', data=np.array(t.chromnames, dtype='S'))
-        g.create_dataset('chroms/length', data=t.chromsizes)
-        nb = int(t.chrom_offset[-1])
-        g.create_dataset('bins/chrom', data=np.repeat(np.arange(len(t.chromnames)), np.diff(t.chrom_offset)))
-        start = np.concatenate([np.arange(n) * t.binsize for n in np.diff(t.chrom_offset)])
-        g.create_dataset('bins/start', data=start)
-        g.create_dataset('bins/end', data=start + t.binsize)
-        for k, v in t.weights.items():
-            g.create_dataset('bins/' + k, data=v)
-        g.create_dataset('pixels/bin1_id', data=t.bin1_id, chunks=(4096,), compression='gzip')
-        g.create_dataset('pixels/bin2_id', data=t.bin2_id, chunks=(4096,), compression='gzip')
-        g.create_dataset('pixels/count', data=t.count, chunks=(4096,), compression='gzip')
-        g.create_dataset('indexes/chrom_offset', data=t.chrom_offset)
-        g.create_dataset('indexes/bin1_offset', data=np.searchsorted(t.bin1_id, np.arange(nb + 1), side='left'))
+    CF.write(path, t, h5py)
 
 
 def test_lazy_reader_equals_the_in_memory_table(tmp_path):

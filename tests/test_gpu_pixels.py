@@ -109,3 +109,31 @@ def test_quantile_from_pixel_table_equals_dense_quantile():
         for nm in names:
             D = sel.fetch(nm)
             assert np.array_equal(MP[nm], np.quantile(D[D > 0], qs)), (balance, nm)
+
+
+def test_compute_from_a_cooler_file_on_the_device(tmp_path, monkeypatch):
+    """`stripenn compute tests/golden/cool_tiny.mcool::resolutions/5000` -- the committed cooler-schema file read by the
+    package's own HDF5 reader (stripenn_amd/h5lite.py: this interpreter has neither cooler nor h5py), its columns packed
+    into bands on the device, default (HIP) backend -- writes the TSVs that the oracle backend writes for the same genome
+    held as an in-memory table (stripenn.py:80-118 + the whole driver), byte for byte."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cool_fixture as CF
+    from oracle import oracle as O
+    from oracle_backend import OracleBackend
+    names, chroms, t = CF.table(small=True)
+    fixture = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cool_tiny.mcool') + '::' + CF.GROUP
+    monkeypatch.setitem(sys.modules, 'cooler', None)
+    info = sio.open_matrix(fixture)
+    assert list(info.chromnames) == names
+    outs = []
+    for src in ('file+hip', 'table+oracle'):
+        out = str(tmp_path / src.replace('+', '_'))
+        if src == 'table+oracle':
+            monkeypatch.setattr(stripenn, 'open_matrix', lambda cool: sio.pixel_matrix(t))
+            stripenn.compute(fixture, out, 'KR', 'all', 2.0, 10, 8, '0.97,0.99', 2, 0.5, '0', False, 3, 7, force=True,
+                             backend=OracleBackend(gauss_w=O.gauss_weights(2.0)[0]))
+        else:
+            stripenn.compute(fixture, out, 'KR', 'all', 2.0, 10, 8, '0.97,0.99', 2, 0.5, '0', False, 3, 7, force=True)
+        outs.append([open(os.path.join(out, f)).read() for f in ('result_unfiltered.tsv', 'result_filtered.tsv')])
+    assert outs[0] == outs[1] and outs[0][0].count('\n') > 5
