@@ -9,6 +9,9 @@
 #include <algorithm>
 #include <new>
 #include <mutex>
+#include <dlfcn.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
 #include "../../include/stripenn_hip.h"
 #include "stp_phases.h"
 #include "stp_canny32.h"
@@ -1415,28 +1418,115 @@ __global__ __launch_bounds__(256) void k_band_pack(const int64_t* __restrict__ b
 // ============================================================================================
 // host side
 // ============================================================================================
-// STP_LOG_ALLOC=1 (diagnostics): every device allocation / release and every host range pinned in place is written to
-// stderr with the source line that asked for it, so that a faulting address can be placed among the buffers
+// Diagnostics.  STP_LOG_ALLOC=1: every device allocation / release and every host range pinned in place is written to stderr
+// with the source line that asked for it.  Always: the same events are kept in a small registry, and a handler registered
+// with the HSA runtime (hsa_amd_register_system_event_handler, looked up at run time) writes a GPU memory fault's address
+// and reason to stderr -- and to the file STP_FAULT_LOG names, which survives a test runner's capture -- together with the
+// buffer of this library the address falls into (or the nearest ones, or a recently released one), before the runtime's
+// own handler aborts the process.  STP_NO_FAULT_REPORT=1 leaves the runtime's handler alone.
 static bool stp_log_on() { static const bool on = getenv("STP_LOG_ALLOC") != nullptr; return on; }
+struct stp_alloc_rec { const char* p; size_t n; int line; char kind; };     // kind: 'd' device, 'h' pinned host range
+static std::mutex g_reg_mutex;
+static std::vector<stp_alloc_rec> g_live, g_dead;                             // g_dead: the last releases (ring of 64)
+static void reg_add(void* p, size_t n, int line, char kind)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    g_live.push_back(stp_alloc_rec{(const char*)p, n, line, kind});
+}
+static void reg_del(void* p, int line)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    for (size_t i = g_live.size(); i-- > 0;)
+        if (g_live[i].p == (const char*)p) {
+            stp_alloc_rec r = g_live[i];
+            r.line = line;                                                    // (where it was released)
+            g_live[i] = g_live.back(); g_live.pop_back();
+            if (g_dead.size() >= 64) g_dead.erase(g_dead.begin());
+            g_dead.push_back(r);
+            return;
+        }
+}
+static void fault_report(FILE* f, unsigned long long va, unsigned reason, int type)
+{
+    fprintf(f, "[stp] GPU %s: address 0x%llx, reason mask 0x%x%s%s%s%s\n", type == 0 ? "memory fault" : (type == 1 ? "hardware exception" : "memory error"),
+            va, reason, (reason & 1) ? " (page not present)" : "", (reason & 2) ? " (write to a read-only page)" : "",
+            (reason & 8) ? " (host-only page)" : "", (reason & 32) ? " (imprecise address)" : "");
+    const stp_alloc_rec *in = nullptr, *below = nullptr, *above = nullptr;
+    for (const auto& r : g_live) {
+        const unsigned long long a = (unsigned long long)(uintptr_t)r.p, b = a + r.n;
+        if (va >= a && va < b) in = &r;
+        else if (b <= va && (!below || (unsigned long long)(uintptr_t)below->p + below->n < b)) below = &r;
+        else if (a > va && (!above || (unsigned long long)(uintptr_t)above->p > a)) above = &r;
+    }
+    if (in) fprintf(f, "[stp]   inside the %s buffer of line %d: %p + %llu of %zu bytes\n", in->kind == 'd' ? "device" : "pinned host", in->line, (const void*)in->p,
+                    va - (unsigned long long)(uintptr_t)in->p, in->n);
+    if (!in && below) fprintf(f, "[stp]   %llu bytes past the end of the %s buffer of line %d (%p, %zu bytes)\n",
+                              va - ((unsigned long long)(uintptr_t)below->p + below->n), below->kind == 'd' ? "device" : "pinned host", below->line, (const void*)below->p, below->n);
+    if (!in && above) fprintf(f, "[stp]   %llu bytes before the %s buffer of line %d (%p, %zu bytes)\n",
+                              (unsigned long long)(uintptr_t)above->p - va, above->kind == 'd' ? "device" : "pinned host", above->line, (const void*)above->p, above->n);
+    for (const auto& r : g_dead) {
+        const unsigned long long a = (unsigned long long)(uintptr_t)r.p;
+        if (va >= a && va < a + r.n) fprintf(f, "[stp]   inside a %s buffer RELEASED at line %d: %p + %llu of %zu bytes\n", r.kind == 'd' ? "device" : "pinned host", r.line,
+                                               (const void*)r.p, va - a, r.n);
+    }
+    fprintf(f, "[stp]   %zu live buffers of this library\n", g_live.size());
+    fflush(f);
+}
+static hsa_status_t stp_hsa_event(const hsa_amd_event_t* ev, void*)
+{
+    unsigned long long va = 0; unsigned reason = 0;
+    if (ev->event_type == HSA_AMD_GPU_MEMORY_FAULT_EVENT) { va = ev->memory_fault.virtual_address; reason = ev->memory_fault.fault_reason_mask; }
+    else if (ev->event_type == HSA_AMD_GPU_MEMORY_ERROR_EVENT) { va = ev->memory_error.virtual_address; reason = ev->memory_error.error_reason_mask; }
+    else if (ev->event_type == HSA_AMD_GPU_HW_EXCEPTION_EVENT) reason = (unsigned)ev->hw_exception.reset_cause;
+    else return HSA_STATUS_ERROR;
+    std::unique_lock<std::mutex> lk(g_reg_mutex, std::try_to_lock);           // (a faulting process: report even without the lock)
+    fault_report(stderr, va, reason, (int)ev->event_type);
+    if (const char* path = getenv("STP_FAULT_LOG"))
+        if (FILE* f = fopen(path, "a")) { fault_report(f, va, reason, (int)ev->event_type); fclose(f); }
+    return HSA_STATUS_ERROR;                                                  // not handled: the runtime's own report and abort follow
+}
+static void stp_install_fault_report()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (getenv("STP_NO_FAULT_REPORT")) return;
+        void* h = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_NOLOAD);    // the runtime HIP has loaded already
+        if (!h) return;
+        typedef hsa_status_t (*reg_t)(hsa_amd_system_event_callback_t, void*);
+        reg_t reg = (reg_t)dlsym(h, "hsa_amd_register_system_event_handler");
+        const int rc = reg ? (int)reg(&stp_hsa_event, nullptr) : -1;          // (fails when somebody else has one: theirs stays)
+        if (stp_log_on()) fprintf(stderr, "[stp] GPU fault report handler: %s (%d)\n", rc == 0 ? "installed" : "not installed", rc);
+    });
+}
 static hipError_t stp_dmalloc(int line, void** p, size_t n)
 {
     const hipError_t e = hipMalloc(p, n);
+    if (e == hipSuccess) reg_add(*p, n, line, 'd');
     if (stp_log_on()) fprintf(stderr, "[stp] malloc L%d %p .. %p (%zu B) rc %d\n", line, *p, (void*)((char*)*p + n), n, (int)e);
     return e;
 }
 static hipError_t stp_dfree(int line, void* p)
 {
     if (stp_log_on()) fprintf(stderr, "[stp] free   L%d %p\n", line, p);
+    reg_del(p, line);
     return hipFree(p);
 }
 static hipError_t stp_hreg(int line, void* p, size_t n, unsigned flags)
 {
     const hipError_t e = hipHostRegister(p, n, flags);
+    if (e == hipSuccess) reg_add(p, n, line, 'h');
     if (stp_log_on()) fprintf(stderr, "[stp] hreg   L%d %p .. %p (%zu B) rc %d\n", line, p, (void*)((char*)p + n), n, (int)e);
     return e;
 }
+static hipError_t stp_hfree(int line, void* p)
+{
+    reg_del(p, line);
+    return hipHostFree(p);
+}
 static hipError_t stp_hunreg(int line, void* p)
 {
+    reg_del(p, line);
     const hipError_t e = hipHostUnregister(p);
     if (stp_log_on()) fprintf(stderr, "[stp] hunreg L%d %p rc %d\n", line, p, (int)e);
     return e;
@@ -1482,6 +1572,7 @@ struct stp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int sweep_slots = STP_RCAP;            // record slots per image in the first pass (stp_dbg_set_sweep_slots)
     std::vector<std::pair<size_t, void*>> pin_free;   // pinned staging buffers of finished searches, recycled
+    std::vector<std::pair<size_t, void*>> stage_free; // pinned staging buffers of stp_xfer (power-of-two sizes), recycled
     void* c32q_zero = nullptr; size_t c32q_zero_bytes = 0;   // the flag buffer known to be all zero (k_canny_pipe_list clears what it reads)
 };
 
@@ -1555,9 +1646,10 @@ static void pool_release(stp_ctx* ctx, void* p, size_t bytes)
 static hipError_t pin_get(stp_ctx* ctx, size_t bytes, void** out)
 {
     if (ctx->pin_bytes < bytes) {
-        if (ctx->pin) (void)hipHostFree(ctx->pin);
+        if (ctx->pin) (void)stp_hfree(__LINE__, ctx->pin);
         ctx->pin = nullptr; ctx->pin_bytes = 0;
         hipError_t e = hipHostMalloc(&ctx->pin, bytes, hipHostMallocDefault);
+        reg_add(ctx->pin, bytes, __LINE__, 'h');
         if (stp_log_on()) fprintf(stderr, "[stp] hostmalloc ctx %p (%zu B)\n", ctx->pin, bytes);
         if (e != hipSuccess) return e;
         ctx->pin_bytes = bytes;
@@ -1670,6 +1762,7 @@ int stp_ctx_create(int device_ordinal, stp_ctx** out)
     }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
+    stp_install_fault_report();
     *out = ctx;
     return STP_OK;
 }
@@ -1682,8 +1775,9 @@ void stp_ctx_destroy(stp_ctx* ctx)
     resolve_pending(ctx);
     for (int i = 0; i < WS_NSLOTS; i++) if (ctx->ws[i]) (void)stp_dfree(__LINE__, ctx->ws[i]);
     for (auto& e : ctx->pool_free) (void)stp_dfree(__LINE__, e.second);
-    if (ctx->pin) (void)hipHostFree(ctx->pin);
-    for (auto& e : ctx->pin_free) (void)hipHostFree(e.second);
+    if (ctx->pin) (void)stp_hfree(__LINE__, ctx->pin);
+    for (auto& e : ctx->pin_free) (void)stp_hfree(__LINE__, e.second);
+    for (auto& e : ctx->stage_free) (void)stp_hfree(__LINE__, e.second);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1737,7 +1831,7 @@ static int check_hw(stp_ctx* ctx, int64_t nrows, int32_t hw)
 static bool stp_pin_body(const void* ptr, size_t bytes, char** lo, char** hi)
 {
     static const bool off = getenv("STP_NO_PIN") != nullptr;
-    if (off || !ptr || bytes < ((size_t)1 << 20)) return false;
+    if (off || !ptr || bytes < ((size_t)1 << 20)) return false;        // (smaller buffers travel through the library's staging: stp_xfer)
     const uintptr_t a = ((uintptr_t)ptr + STP_PIN_PAGE - 1) & ~(STP_PIN_PAGE - 1), b = ((uintptr_t)ptr + bytes) & ~(STP_PIN_PAGE - 1);
     if (b <= a) return false;
     *lo = (char*)a; *hi = (char*)b;
@@ -1763,17 +1857,19 @@ struct host_pin {
         if (stp_hreg(__LINE__, a, (size_t)(b - a), hipHostRegisterDefault) == hipSuccess) { lo = a; hi = b; mine = true; }
         else (void)hipGetLastError();                       // clear the sticky error: pageable copies from here on
     }
-    // host -> device copy of [src, src + bytes) out of the range given to pin(): the pinned pages as one transfer (DMA),
-    // what lies before and after them as pageable copies of their own
-    hipError_t copy(void* dst, const void* src, size_t bytes, hipStream_t stream) const
+    // copy between the range given to pin() and device memory: the pinned pages as one transfer (DMA), what lies before and
+    // after them as small pageable copies of their own (the runtime stages those)
+    hipError_t copy(void* dst, const void* src, size_t bytes, hipStream_t stream, hipMemcpyKind kind = hipMemcpyHostToDevice) const
     {
-        const char *s0 = (const char*)src, *s1 = s0 + bytes;
-        const char *b0 = s0 > lo ? s0 : lo, *b1 = s1 < hi ? s1 : hi;
-        if (lo == hi || b0 >= b1) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+        const bool up = kind == hipMemcpyHostToDevice;
+        const char *h0 = (const char*)(up ? src : dst), *h1 = h0 + bytes;        // the host side
+        const char *b0 = h0 > lo ? h0 : lo, *b1 = h1 < hi ? h1 : hi;
+        if (lo == hi || b0 >= b1) return hipMemcpyAsync(dst, src, bytes, kind, stream);
         hipError_t e = hipSuccess;
-        if (s0 < b0) e = hipMemcpyAsync(dst, s0, (size_t)(b0 - s0), hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess) e = hipMemcpyAsync((char*)dst + (b0 - s0), b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess && b1 < s1) e = hipMemcpyAsync((char*)dst + (b1 - s0), b1, (size_t)(s1 - b1), hipMemcpyHostToDevice, stream);
+        const size_t n0 = (size_t)(b0 - h0), n1 = (size_t)(b1 - b0), n2 = (size_t)(h1 - b1);
+        if (n0) e = hipMemcpyAsync(dst, src, n0, kind, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync((char*)dst + n0, (const char*)src + n0, n1, kind, stream);
+        if (e == hipSuccess && n2) e = hipMemcpyAsync((char*)dst + n0 + n1, (const char*)src + n0 + n1, n2, kind, stream);
         return e;
     }
     ~host_pin()
@@ -1782,6 +1878,119 @@ struct host_pin {
         (void)hipStreamSynchronize(st);
         if (stp_hunreg(__LINE__, lo) != hipSuccess) (void)hipGetLastError();
     }
+};
+
+// Every transfer between the caller's (pageable) host memory and the device goes through here (round 4).  Handing pageable
+// memory to hipMemcpyAsync lets the runtime pin it on the fly, and the runtime keeps such pins in a small per-queue cache
+// keyed by the HOST ADDRESS: a buffer the caller has freed since -- numpy recycles heap addresses all the time -- still has its
+// stale pin there, and a later transfer to a new buffer at the same address takes it.  A pin made for an upload is read-only
+// to the device: the first download into the recycled address faulted ("write access to a read-only page", reported
+// through STP_FAULT_LOG; three aborted runs in round 4 before the report caught it).  So the runtime never sees the
+// caller's pointers unless the library has registered them itself:
+//   * < 64 KB: the runtime's own staging path (no pinning at that size);
+//   * up to 8 MB: through a pinned staging buffer of the context (one host copy; buffers are recycled);
+//   * larger: the caller's pages registered in place for the call (host_pin), DMA straight from / to them.
+// finish() drains the stream and completes the staged downloads; the destructor does it on the error paths.
+#define STP_XFER_SMALL ((size_t)64 << 10)
+#define STP_XFER_STAGED ((size_t)8 << 20)
+struct stp_xfer {
+    stp_ctx* ctx;
+    hipStream_t st;
+    struct piece { void* stage; size_t cap; void* user; size_t bytes; };        // user != null: a download to complete
+    std::vector<piece> pieces;
+    std::vector<host_pin*> pins;
+    bool done = false;
+    stp_xfer(stp_ctx* c, hipStream_t s) : ctx(c), st(s) {}
+    void* stage_get(size_t bytes, size_t* cap)
+    {
+        const size_t r = pool_round(bytes);
+        for (size_t i = 0; i < ctx->stage_free.size(); i++)
+            if (ctx->stage_free[i].first == r) {
+                void* p = ctx->stage_free[i].second;
+                ctx->stage_free[i] = ctx->stage_free.back(); ctx->stage_free.pop_back();
+                *cap = r;
+                return p;
+            }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, r, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        reg_add(p, r, __LINE__, 'h');
+        if (stp_log_on()) fprintf(stderr, "[stp] hostmalloc stage %p (%zu B)\n", p, r);
+        *cap = r;
+        return p;
+    }
+    hipError_t h2d(void* dst, const void* src, size_t bytes)
+    {
+        if (!bytes) return hipSuccess;
+        if (bytes < STP_XFER_SMALL) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+        if (bytes <= STP_XFER_STAGED) {
+            size_t cap = 0;
+            void* p = stage_get(bytes, &cap);
+            if (!p) return hipErrorOutOfMemory;
+            memcpy(p, src, bytes);
+            pieces.push_back(piece{p, cap, nullptr, 0});
+            return hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, st);
+        }
+        host_pin* hp = new host_pin();
+        pins.push_back(hp);
+        hp->pin(src, bytes, st);
+        if (hp->lo != hp->hi) return hp->copy(dst, src, bytes, st, hipMemcpyHostToDevice);
+        return piecewise(dst, src, bytes, true);               // the pages could not be registered (STP_NO_PIN, the runtime refusing)
+    }
+    // a large buffer that cannot be pinned in place: through one staging buffer, piece by piece (slow path, synchronous)
+    hipError_t piecewise(void* dst, const void* src, size_t bytes, bool up)
+    {
+        size_t cap = 0;
+        void* p = stage_get(STP_XFER_STAGED, &cap);
+        if (!p) return hipErrorOutOfMemory;
+        hipError_t e = hipSuccess;
+        for (size_t o = 0; o < bytes && e == hipSuccess; o += STP_XFER_STAGED) {
+            const size_t n = bytes - o < STP_XFER_STAGED ? bytes - o : STP_XFER_STAGED;
+            if (up) {
+                memcpy(p, (const char*)src + o, n);
+                e = hipMemcpyAsync((char*)dst + o, p, n, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+            } else {
+                e = hipMemcpyAsync(p, (const char*)src + o, n, hipMemcpyDeviceToHost, st);
+                if (e == hipSuccess) e = hipStreamSynchronize(st);
+                if (e == hipSuccess) memcpy((char*)dst + o, p, n);
+            }
+        }
+        pieces.push_back(piece{p, cap, nullptr, 0});
+        return e;
+    }
+    hipError_t d2h(void* dst, const void* src, size_t bytes)
+    {
+        if (!bytes) return hipSuccess;
+        if (bytes < STP_XFER_SMALL) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+        if (bytes <= STP_XFER_STAGED) {
+            size_t cap = 0;
+            void* p = stage_get(bytes, &cap);
+            if (!p) return hipErrorOutOfMemory;
+            pieces.push_back(piece{p, cap, dst, bytes});
+            return hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToHost, st);
+        }
+        host_pin* hp = new host_pin();
+        pins.push_back(hp);
+        hp->pin(dst, bytes, st);
+        if (hp->lo != hp->hi) return hp->copy(dst, src, bytes, st, hipMemcpyDeviceToHost);
+        return piecewise(dst, src, bytes, false);
+    }
+    hipError_t finish()
+    {
+        if (done) return hipSuccess;
+        done = true;
+        const hipError_t e = hipStreamSynchronize(st);
+        for (auto& pc : pieces) {
+            if (e == hipSuccess && pc.user) memcpy(pc.user, pc.stage, pc.bytes);
+            if (ctx->stage_free.size() < 32) ctx->stage_free.push_back(std::make_pair(pc.cap, pc.stage));
+            else (void)stp_hfree(__LINE__, pc.stage);
+        }
+        pieces.clear();
+        for (host_pin* hp : pins) delete hp;                                    // (drains the stream -- done -- and releases the pages)
+        pins.clear();
+        return e;
+    }
+    ~stp_xfer() { (void)finish(); }
 };
 
 int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_t hw, stp_band** out)
@@ -1798,10 +2007,9 @@ int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_
     hipError_t e = stp_dmalloc(__LINE__, (void**)&d, bytes);
     if (e != hipSuccess) { delete b; return set_err(ctx, STP_E_NOMEM, "hipMalloc(band) failed"); }
     {
-        host_pin pin;
-        pin.pin(band_host, bytes, ctx->stream);
-        e = pin.copy(d, band_host, bytes, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        stp_xfer x(ctx, ctx->stream);
+        e = x.h2d(d, band_host, bytes);
+        if (e == hipSuccess) e = x.finish();
     }
     if (e != hipSuccess) { (void)stp_dfree(__LINE__, d); delete b; return set_err(ctx, STP_E_HIP, "band upload failed"); }
     b->d = d;
@@ -1874,8 +2082,9 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
     FRCHK(pool_alloc(ctx, n * sizeof(int32_t), (void**)&fr->d_n0));
     FRCHK(pool_alloc(ctx, n * sizeof(int32_t), (void**)&fr->d_S));
     FRCHK(pool_alloc(ctx, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), (void**)&fr->d_nz));
-    FRCHK(hipMemcpyAsync(fr->d_start, fr->h_start.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->aux));
-    FRCHK(hipMemcpyAsync(fr->d_n0, fr->h_n0.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->aux));
+    stp_xfer x(ctx, ctx->aux);
+    FRCHK(x.h2d(fr->d_start, fr->h_start.data(), n * sizeof(int32_t)));
+    FRCHK(x.h2d(fr->d_n0, fr->h_n0.data(), n * sizeof(int32_t)));
     FRCHK(hipMemsetAsync(fr->d_nz, 0, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), ctx->aux));
     double* d_med = nullptr;
     FRCHK(pool_alloc(ctx, (size_t)n * 3 * sizeof(double), (void**)&d_med));
@@ -1895,11 +2104,10 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
         FRCHK(el);
     }
     std::vector<double> hm((size_t)n * 3);
-    hipError_t e1 = hipMemcpyAsync(hm.data(), d_med, hm.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->aux);
-    if (e1 == hipSuccess) e1 = hipMemcpyAsync(fr->h_S.data(), fr->d_S, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->aux);
-    if (e1 == hipSuccess) e1 = hipMemcpyAsync(fr->h_nz.data(), fr->d_nz, (size_t)n * STP_FRAME_MAX * sizeof(int16_t),
-                                              hipMemcpyDeviceToHost, ctx->aux);
-    if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->aux);
+    hipError_t e1 = x.d2h(hm.data(), d_med, hm.size() * sizeof(double));
+    if (e1 == hipSuccess) e1 = x.d2h(fr->h_S.data(), fr->d_S, n * sizeof(int32_t));
+    if (e1 == hipSuccess) e1 = x.d2h(fr->h_nz.data(), fr->d_nz, (size_t)n * STP_FRAME_MAX * sizeof(int16_t));
+    if (e1 == hipSuccess) e1 = x.finish();
     pool_release(ctx, d_med, (size_t)n * 3 * sizeof(double));
     FRCHK(e1);
     for (int i = 0; i < n; i++) {
@@ -1984,6 +2192,10 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
     pin1.pin(bin1, (size_t)npix * sizeof(int64_t), ctx->io);
     pin2.pin(bin2, (size_t)npix * sizeof(int64_t), ctx->io);
     pinc.pin(count, (size_t)npix * csz, ctx->io);
+    stp_xfer x(ctx, ctx->io);                               // columns too small to pin (< 1 MB), the weights: staged
+    auto up = [&](const host_pin& pin, void* dst, const void* src, size_t n) {
+        return pin.lo != pin.hi ? pin.copy(dst, src, n, ctx->io) : x.h2d(dst, src, n);
+    };
     int32_t* near = nullptr;
     if (stp_dmalloc(__LINE__, (void**)&near, (size_t)nrows * 2 * sizeof(int32_t)) != hipSuccess) {
         (void)stp_dfree(__LINE__, d); delete b;
@@ -1995,7 +2207,7 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
     if (e == hipSuccess && nch) e = bc.alloc(ctx, (size_t)nch * csz);
     if (e == hipSuccess && weight) e = bw.alloc(ctx, (size_t)nrows * sizeof(double));
     if (e == hipSuccess && weight)
-        e = hipMemcpyAsync(bw.p, weight + lo, (size_t)nrows * sizeof(double), hipMemcpyHostToDevice, ctx->io);
+        e = x.h2d(bw.p, weight + lo, (size_t)nrows * sizeof(double));
     if (e == hipSuccess && weight) {
         prof_scope ps(ctx, "band_init", (double)bytes, ctx->io);
         hipLaunchKernelGGL(k_band_init, dim3(256 * 16), dim3(256), 0, ctx->io, (const double*)bw.p, nrows, b->W, hw, d);
@@ -2007,9 +2219,9 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
         const int64_t n = npix - p0 < CH ? npix - p0 : CH;
         // (measured and dropped in round 4: bin2_id on a second upload stream, i.e. a second copy engine -- the 5.3 GB of the
         //  mm10-size table took the same 0.15-0.16 s: ~35 GB/s is what this host's memory feeds the link)
-        e = pin1.copy(b1.p, bin1 + p0, (size_t)n * sizeof(int64_t), ctx->io);
-        if (e == hipSuccess) e = pin2.copy(b2.p, bin2 + p0, (size_t)n * sizeof(int64_t), ctx->io);
-        if (e == hipSuccess) e = pinc.copy(bc.p, count + (size_t)p0 * csz, (size_t)n * csz, ctx->io);
+        e = up(pin1, b1.p, bin1 + p0, (size_t)n * sizeof(int64_t));
+        if (e == hipSuccess) e = up(pin2, b2.p, bin2 + p0, (size_t)n * sizeof(int64_t));
+        if (e == hipSuccess) e = up(pinc, bc.p, count + (size_t)p0 * csz, (size_t)n * csz);
         if (e != hipSuccess) break;
         {
             prof_scope ps(ctx, "band_pack", (double)n * 36.0, ctx->io);    // 20 B of table read + two 8 B cells written
@@ -2061,10 +2273,10 @@ int stp_band_nearest(stp_ctx* ctx, const stp_band* band, int32_t* right_out, int
     if (!band->near)
         return set_err(ctx, STP_E_UNSUPPORTED, "nearest-pixel table: only bands built by stp_band_pack carry one");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMemcpyAsync(right_out, band->near, (size_t)band->nrows * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(left_out, band->near + band->nrows, (size_t)band->nrows * sizeof(int32_t), hipMemcpyDeviceToHost,
-                          ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    stp_xfer x(ctx, ctx->stream);
+    HIPCHK(x.d2h(right_out, band->near, (size_t)band->nrows * sizeof(int32_t)));
+    HIPCHK(x.d2h(left_out, band->near + band->nrows, (size_t)band->nrows * sizeof(int32_t)));
+    HIPCHK(x.finish());
     return STP_OK;
 }
 
@@ -2072,8 +2284,9 @@ int stp_band_download(stp_ctx* ctx, const stp_band* band, double* out_host)
 {
     if (!ctx || !band || !out_host) return STP_E_ARG;
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMemcpyAsync(out_host, band->d, (size_t)band->nrows * band->W * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    stp_xfer x(ctx, ctx->stream);
+    HIPCHK(x.d2h(out_host, band->d, (size_t)band->nrows * band->W * sizeof(double)));
+    HIPCHK(x.finish());
     return STP_OK;
 }
 
@@ -2251,7 +2464,7 @@ static void search_release(stp_ctx* ctx, stp_search* s)
     pool_release(ctx, s->d_tot, s->tot_bytes);
     if (s->pin) {
         if (ctx->pin_free.size() < 8) ctx->pin_free.push_back(std::make_pair(s->pin_bytes, s->pin));
-        else (void)hipHostFree(s->pin);
+        else (void)stp_hfree(__LINE__, s->pin);
     }
     if (s->done) (void)hipEventDestroy(s->done);
     delete s;
@@ -2290,7 +2503,7 @@ static int search_enqueue(stp_ctx* ctx, stp_search* s)
     {
         const size_t pb = 64 + phdr + std::max(s->guess, (size_t)1024) * sizeof(stp_stripe_rec);
         if (s->pin_bytes < pb) {
-            if (s->pin) (void)hipHostFree(s->pin);
+            if (s->pin) (void)stp_hfree(__LINE__, s->pin);
             s->pin = nullptr; s->pin_bytes = 0;
             for (size_t i = 0; i < ctx->pin_free.size(); i++)
                 if (ctx->pin_free[i].first >= pb) {
@@ -2300,6 +2513,7 @@ static int search_enqueue(stp_ctx* ctx, stp_search* s)
                 }
             if (!s->pin) {
                 HIPCHK(hipHostMalloc(&s->pin, pb, hipHostMallocDefault));
+                reg_add(s->pin, pb, __LINE__, 'h');
                 if (stp_log_on()) fprintf(stderr, "[stp] hostmalloc search %p (%zu B)\n", s->pin, pb);
                 s->pin_bytes = pb;
             }
@@ -2419,9 +2633,9 @@ int stp_stripe_search_fetch(stp_ctx* ctx, stp_search* s, stp_stripe_rec* out, in
         if ((size_t)n > have) {
             // the rest comes over the upload stream: this search is complete (its event), and on ctx->stream the copy would
             // wait behind every later search already queued -- the pipeline would drain for it
-            hipError_t e = hipMemcpyAsync(out + have, (stp_stripe_rec*)s->d_out + have, ((size_t)n - have) * sizeof(stp_stripe_rec),
-                                          hipMemcpyDeviceToHost, ctx->io);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->io);
+            stp_xfer x(ctx, ctx->io);
+            hipError_t e = x.d2h(out + have, (stp_stripe_rec*)s->d_out + have, ((size_t)n - have) * sizeof(stp_stripe_rec));
+            if (e == hipSuccess) e = x.finish();
             if (e != hipSuccess) rc = set_err(ctx, STP_E_HIP, std::string("record copy: ") + hipGetErrorString(e));
         }
     }
@@ -2494,10 +2708,10 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
     HIPCHK(bDbg.alloc(ctx, nimg * 4 * STP_FRAME_MAX * STP_NW * sizeof(stp_u64)));
     HIPCHK(bDbgc.alloc(ctx, nimg * 3 * STP_FRAME_MAX * sizeof(int16_t)));
     HIPCHK(hipMemsetAsync(bDbg.p, 0, nimg * 4 * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), ctx->stream));
-    HIPCHK(hipMemcpyAsync(bM.p, &M, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(bB.p, prm->bright, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(bW.p, prm->gauss_w, (2 * prm->gauss_radius + 1) * sizeof(double), hipMemcpyHostToDevice,
-                          ctx->stream));
+    stp_xfer x(ctx, ctx->stream);
+    HIPCHK(x.h2d(bM.p, &M, sizeof(double)));
+    HIPCHK(x.h2d(bB.p, prm->bright, nb * sizeof(double)));
+    HIPCHK(x.h2d(bW.p, prm->gauss_w, (2 * prm->gauss_radius + 1) * sizeof(double)));
     rc = run_chain(ctx, fr, prm, f, 1, &M, (const double*)bM.p, 1, (const double*)bB.p, (const double*)bW.p, dGray,
                    (stp_u64*)bLow.p, (stp_u64*)bHigh.p, (stp_drec*)bRecs.p, (int32_t*)bCnt.p, 1, (stp_u64*)bDbg.p,
                    (int16_t*)bDbgc.p, STP_RCAP_MAX);
@@ -2506,14 +2720,12 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
     std::vector<float> hg((size_t)STP_PITCH * STP_PITCH);
     std::vector<stp_u64> hl(BW), hh(BW), hd(4 * BW);
     std::vector<int16_t> hc(3 * STP_FRAME_MAX);
-    HIPCHK(hipMemcpyAsync(hg.data(), dGray + (size_t)bi * STP_PITCH * STP_PITCH, hg.size() * sizeof(float),
-                          hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(hl.data(), (stp_u64*)bLow.p + bi * BW, BW * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(hh.data(), (stp_u64*)bHigh.p + bi * BW, BW * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(hd.data(), (stp_u64*)bDbg.p + (size_t)bi * 4 * BW, 4 * BW * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(hc.data(), (int16_t*)bDbgc.p + (size_t)bi * 3 * STP_FRAME_MAX, hc.size() * 2,
-                          hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(x.d2h(hg.data(), dGray + (size_t)bi * STP_PITCH * STP_PITCH, hg.size() * sizeof(float)));
+    HIPCHK(x.d2h(hl.data(), (stp_u64*)bLow.p + bi * BW, BW * 8));
+    HIPCHK(x.d2h(hh.data(), (stp_u64*)bHigh.p + bi * BW, BW * 8));
+    HIPCHK(x.d2h(hd.data(), (stp_u64*)bDbg.p + (size_t)bi * 4 * BW, 4 * BW * 8));
+    HIPCHK(x.d2h(hc.data(), (int16_t*)bDbgc.p + (size_t)bi * 3 * STP_FRAME_MAX, hc.size() * 2));
+    HIPCHK(x.finish());
     if (gray)
         for (int y = 0; y < S; y++) memcpy(gray + (size_t)y * S, hg.data() + (size_t)y * STP_PITCH, S * sizeof(float));
     if (cls) {
@@ -2574,9 +2786,10 @@ int stp_dbg_canny_f32(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
     HIPCHK(bC.alloc(ctx, 4 * sizeof(unsigned long long)));
     const int tiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
     HIPCHK(bX.alloc(ctx, nimg * tiles));
-    HIPCHK(hipMemcpyAsync(bM.p, &M, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(bB.p, prm->bright, nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(bW.p, prm->gauss_w, (2 * R + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    stp_xfer x(ctx, ctx->stream);
+    HIPCHK(x.h2d(bM.p, &M, sizeof(double)));
+    HIPCHK(x.h2d(bB.p, prm->bright, nb * sizeof(double)));
+    HIPCHK(x.h2d(bW.p, prm->gauss_w, (2 * R + 1) * sizeof(double)));
     rc = run_chain(ctx, fr, prm, f, 1, &M, (const double*)bM.p, 1, (const double*)bB.p, (const double*)bW.p, dGray,
                    (stp_u64*)bLow.p, (stp_u64*)bHigh.p, (stp_drec*)bRecs.p, (int32_t*)bCnt.p, 0, nullptr, nullptr, STP_RCAP_MAX);
     if (rc) return rc;
@@ -2602,9 +2815,9 @@ int stp_dbg_canny_f32(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
     HIPCHK(hipGetLastError());
     std::vector<float> hp(6 * PL);
     unsigned long long hc[4];
-    HIPCHK(hipMemcpyAsync(hp.data(), bPl.p, hp.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(hc, bC.p, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(x.d2h(hp.data(), bPl.p, hp.size() * sizeof(float)));
+    HIPCHK(x.d2h(hc, bC.p, sizeof(hc)));
+    HIPCHK(x.finish());
     for (int q = 0; q < 6; q++)
         for (int y = 0; y < S; y++) memcpy(planes + ((size_t)q * S + y) * S, hp.data() + q * PL + (size_t)y * STP_PITCH, S * sizeof(float));
     counts[0] = (int64_t)hc[0]; counts[1] = (int64_t)hc[1]; counts[2] = (int64_t)hc[2];
@@ -2627,9 +2840,10 @@ int stp_diag_sums(stp_ctx* ctx, const stp_band* band, double* part_sum, int64_t*
         hipLaunchKernelGGL(k_diag_sums, dim3(n400), dim3(448), 0, ctx->aux, bref(band), (double*)bs.p, (long long*)bc.p);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(part_sum, bs.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipMemcpyAsync(part_cnt, bc.p, n * sizeof(long long), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipStreamSynchronize(ctx->aux));
+    stp_xfer x(ctx, ctx->aux);
+    HIPCHK(x.d2h(part_sum, bs.p, n * sizeof(double)));
+    HIPCHK(x.d2h(part_cnt, bc.p, n * sizeof(long long)));
+    HIPCHK(x.finish());
     return STP_OK;
 }
 
@@ -2651,15 +2865,16 @@ int stp_null_windows(stp_ctx* ctx, const stp_band* band, const double* unit_matr
     }
     HIPCHK(hipSetDevice(ctx->device));
     dev_buf bS, bO, bD;
+    stp_xfer x(ctx, ctx->aux);
     const size_t tn = (size_t)STP_NDIAG * n;
     if (unit_matrix) {
         const size_t mb = (size_t)samples[0].nrow * samples[0].ncol * sizeof(double);
         HIPCHK(bD.alloc(ctx, mb));
-        HIPCHK(hipMemcpyAsync(bD.p, unit_matrix, mb, hipMemcpyHostToDevice, ctx->aux));
+        HIPCHK(x.h2d(bD.p, unit_matrix, mb));
     }
     HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_null_sample)));
     HIPCHK(bO.alloc(ctx, 4 * tn * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(bS.p, samples, (size_t)n * sizeof(stp_null_sample), hipMemcpyHostToDevice, ctx->aux));
+    HIPCHK(x.h2d(bS.p, samples, (size_t)n * sizeof(stp_null_sample)));
     double* o = (double*)bO.p;
     {
         prof_scope ps(ctx, "null_windows", 8.0 * (3.0 * bs) * (800.0 + bs) * n, ctx->aux);
@@ -2673,11 +2888,11 @@ int stp_null_windows(stp_ctx* ctx, const stp_band* band, const double* unit_matr
                                o + 2 * tn, o + 3 * tn);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(lu, o, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipMemcpyAsync(ru, o + tn, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipMemcpyAsync(ld, o + 2 * tn, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipMemcpyAsync(rd, o + 3 * tn, tn * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipStreamSynchronize(ctx->aux));
+    HIPCHK(x.d2h(lu, o, tn * sizeof(double)));
+    HIPCHK(x.d2h(ru, o + tn, tn * sizeof(double)));
+    HIPCHK(x.d2h(ld, o + 2 * tn, tn * sizeof(double)));
+    HIPCHK(x.d2h(rd, o + 3 * tn, tn * sizeof(double)));
+    HIPCHK(x.finish());
     return STP_OK;
 }
 
@@ -2692,8 +2907,9 @@ int stp_background_upload(stp_ctx* ctx, const double* lu, const double* ru, cons
     if (stp_dmalloc(__LINE__, (void**)&bg->d, 4 * tn * sizeof(double)) != hipSuccess) { delete bg; return set_err(ctx, STP_E_NOMEM, "hipMalloc(background)"); }
     bg->ncol = ncol;
     const double* src[4] = {lu, ru, ld, rd};
+    stp_xfer x(ctx, ctx->aux);
     for (int t = 0; t < 4; t++) {
-        hipError_t e = hipMemcpyAsync(bg->d + t * tn, src[t], tn * sizeof(double), hipMemcpyHostToDevice, ctx->aux);
+        hipError_t e = x.h2d(bg->d + t * tn, src[t], tn * sizeof(double));
         if (e != hipSuccess) { (void)stp_dfree(__LINE__, bg->d); delete bg; return set_err(ctx, STP_E_HIP, "background upload failed"); }
     }
     if (ncol > STP_BG_MAXCOL) { (void)stp_dfree(__LINE__, bg->d); delete bg; return set_err(ctx, STP_E_UNSUPPORTED, "background tables wider than 2048 columns"); }
@@ -2708,7 +2924,7 @@ int stp_background_upload(stp_ctx* ctx, const double* lu, const double* ru, cons
                            bg->nvalid);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->aux));
+    HIPCHK(x.finish());
     *out = bg;
     return STP_OK;
 }
@@ -2751,7 +2967,8 @@ int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int
     dev_buf bS, bO;
     HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_pv_stripe)));
     HIPCHK(bO.alloc(ctx, (size_t)n * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(bS.p, st, (size_t)n * sizeof(stp_pv_stripe), hipMemcpyHostToDevice, ctx->aux));
+    stp_xfer x(ctx, ctx->aux);
+    HIPCHK(x.h2d(bS.p, st, (size_t)n * sizeof(stp_pv_stripe)));
     {
         double bytes = 0;
         for (int64_t i = 0; i < n; i++) bytes += (8.0 * (st[i].col1 - st[i].col0) + 16000.0) * (st[i].row1 - st[i].row0);
@@ -2775,8 +2992,8 @@ int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int
                                (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p, hmax);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_p, bO.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipStreamSynchronize(ctx->aux));
+    HIPCHK(x.d2h(out_p, bO.p, (size_t)n * sizeof(double)));
+    HIPCHK(x.finish());
     return STP_OK;
 }
 
@@ -2796,8 +3013,9 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
     HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_score_stripe)));
     HIPCHK(bE.alloc(ctx, STP_NDIAG * sizeof(double)));
     HIPCHK(bO.alloc(ctx, (size_t)n * 3 * sizeof(double) + (size_t)n * sizeof(int)));
-    HIPCHK(hipMemcpyAsync(bS.p, st, (size_t)n * sizeof(stp_score_stripe), hipMemcpyHostToDevice, ctx->aux));
-    HIPCHK(hipMemcpyAsync(bE.p, exval400, STP_NDIAG * sizeof(double), hipMemcpyHostToDevice, ctx->aux));
+    stp_xfer x(ctx, ctx->aux);
+    HIPCHK(x.h2d(bS.p, st, (size_t)n * sizeof(stp_score_stripe)));
+    HIPCHK(x.h2d(bE.p, exval400, STP_NDIAG * sizeof(double)));
     double* o = (double*)bO.p;
     {
         double bytes = 0;
@@ -2828,11 +3046,11 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
                                (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n), HR, CW);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_g, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipMemcpyAsync(out_mean, o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipMemcpyAsync(out_total, o + 2 * n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
-    if (out_status) HIPCHK(hipMemcpyAsync(out_status, o + 3 * n, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipStreamSynchronize(ctx->aux));
+    HIPCHK(x.d2h(out_g, o, (size_t)n * sizeof(double)));
+    HIPCHK(x.d2h(out_mean, o + n, (size_t)n * sizeof(double)));
+    HIPCHK(x.d2h(out_total, o + 2 * n, (size_t)n * sizeof(double)));
+    if (out_status) HIPCHK(x.d2h(out_status, o + 3 * n, (size_t)n * sizeof(int)));
+    HIPCHK(x.finish());
     return STP_OK;
 }
 
@@ -2848,7 +3066,8 @@ int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rc, int6
     dev_buf bS, bO;
     HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_rect)));
     HIPCHK(bO.alloc(ctx, (size_t)n * 2 * sizeof(double)));
-    HIPCHK(hipMemcpyAsync(bS.p, rc, (size_t)n * sizeof(stp_rect), hipMemcpyHostToDevice, ctx->aux));
+    stp_xfer x(ctx, ctx->aux);
+    HIPCHK(x.h2d(bS.p, rc, (size_t)n * sizeof(stp_rect)));
     double* o = (double*)bO.p;
     {
         double bytes = 0;
@@ -2857,9 +3076,9 @@ int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rc, int6
         hipLaunchKernelGGL(k_stripe_mean, dim3((unsigned)n), dim3(256), 0, ctx->aux, bref(band), (const stp_rect*)bS.p, o, o + n);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out_mean, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipMemcpyAsync(out_sum, o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipStreamSynchronize(ctx->aux));
+    HIPCHK(x.d2h(out_mean, o, (size_t)n * sizeof(double)));
+    HIPCHK(x.d2h(out_sum, o + n, (size_t)n * sizeof(double)));
+    HIPCHK(x.finish());
     return STP_OK;
 }
 
@@ -2882,8 +3101,9 @@ int stp_window_plane(stp_ctx* ctx, const stp_band* band, int64_t row0, int32_t n
                            nrows, col0, ncols, M, (double*)bO.p);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, bO.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->aux));
-    HIPCHK(hipStreamSynchronize(ctx->aux));
+    stp_xfer x(ctx, ctx->aux);
+    HIPCHK(x.d2h(out, bO.p, n * sizeof(double)));
+    HIPCHK(x.finish());
     return STP_OK;
 }
 
@@ -2917,8 +3137,9 @@ int stp_select_append(stp_ctx* ctx, stp_select* s, const double* values_host, in
     HIPCHK(hipSetDevice(ctx->device));
     double* d = nullptr;
     HIPCHK(pool_alloc(ctx, (size_t)n * sizeof(double), (void**)&d));
-    hipError_t e = hipMemcpyAsync(d, values_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->io);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->io);
+    stp_xfer x(ctx, ctx->io);
+    hipError_t e = x.h2d(d, values_host, (size_t)n * sizeof(double));
+    if (e == hipSuccess) e = x.finish();
     if (e != hipSuccess) { pool_release(ctx, d, (size_t)n * sizeof(double)); return set_err(ctx, STP_E_HIP, "select append: upload failed"); }
     s->chunks.push_back(std::make_pair(d, (long long)n));
     s->npos = -1;
@@ -2947,20 +3168,24 @@ int stp_select_append_pixels_ex(stp_ctx* ctx, stp_select* s, const int64_t* bin1
     pin1.pin(bin1, (size_t)npix * sizeof(int64_t), ctx->io);
     pin2.pin(bin2, (size_t)npix * sizeof(int64_t), ctx->io);
     pinc.pin(count, (size_t)npix * csz, ctx->io);
+    stp_xfer x(ctx, ctx->io);                               // columns too small to pin (< 1 MB), the weights: staged
+    auto up = [&](const host_pin& pin, void* dst, const void* src, size_t n) {
+        return pin.lo != pin.hi ? pin.copy(dst, src, n, ctx->io) : x.h2d(dst, src, n);
+    };
     HIPCHK(d1.alloc(ctx, (size_t)nch * sizeof(int64_t)));
     HIPCHK(d2.alloc(ctx, (size_t)nch * sizeof(int64_t)));
     HIPCHK(dc.alloc(ctx, (size_t)nch * csz));
     if (weight) {
         HIPCHK(dw.alloc(ctx, (size_t)nbins_total * sizeof(double)));
-        HIPCHK(hipMemcpyAsync(dw.p, weight, (size_t)nbins_total * sizeof(double), hipMemcpyHostToDevice, ctx->io));
+        HIPCHK(x.h2d(dw.p, weight, (size_t)nbins_total * sizeof(double)));
     }
     for (int64_t p0 = 0; p0 < npix; p0 += CH) {
         const int64_t n = npix - p0 < CH ? npix - p0 : CH;
         double* out = nullptr;
         HIPCHK(pool_alloc(ctx, (size_t)n * 2 * sizeof(double), (void**)&out));
-        hipError_t e = pin1.copy(d1.p, bin1 + p0, (size_t)n * sizeof(int64_t), ctx->io);
-        if (e == hipSuccess) e = pin2.copy(d2.p, bin2 + p0, (size_t)n * sizeof(int64_t), ctx->io);
-        if (e == hipSuccess) e = pinc.copy(dc.p, count + (size_t)p0 * csz, (size_t)n * csz, ctx->io);
+        hipError_t e = up(pin1, d1.p, bin1 + p0, (size_t)n * sizeof(int64_t));
+        if (e == hipSuccess) e = up(pin2, d2.p, bin2 + p0, (size_t)n * sizeof(int64_t));
+        if (e == hipSuccess) e = up(pinc, dc.p, count + (size_t)p0 * csz, (size_t)n * csz);
         if (e == hipSuccess) {
             prof_scope ps(ctx, "select_pixels", 36.0 * n, ctx->io);
             if (count_type == STP_COUNT_F64)
@@ -3074,10 +3299,11 @@ int stp_remove_redundant(stp_ctx* ctx, int64_t n, const int64_t* pos1, const int
     long long* dp = (long long*)bP.p;
     int* di = (int*)bI.p;
     const int64_t* ps[4] = {pos1, pos2, pos3, pos4};
-    for (int k = 0; k < 4; k++) HIPCHK(hipMemcpyAsync(dp + k * n, ps[k], (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    stp_xfer x(ctx, ctx->stream);
+    for (int k = 0; k < 4; k++) HIPCHK(x.h2d(dp + k * n, ps[k], (size_t)n * 8));
     const int32_t* is[6] = {h, w, order, b0, b1, b2};
-    for (int k = 0; k < 6; k++) HIPCHK(hipMemcpyAsync(di + k * n, is[k], (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (key) HIPCHK(hipMemcpyAsync(bK.p, key, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (int k = 0; k < 6; k++) HIPCHK(x.h2d(di + k * n, is[k], (size_t)n * 4));
+    if (key) HIPCHK(x.h2d(bK.p, key, (size_t)n * 8));
     HIPCHK(hipMemsetAsync(bD.p, 0, (size_t)n * sizeof(unsigned int), ctx->stream));
     {
         prof_scope ps2(ctx, "remove_redundant", 48.0 * n);
@@ -3087,8 +3313,8 @@ int stp_remove_redundant(stp_ctx* ctx, int64_t n, const int64_t* pos1, const int
     }
     HIPCHK(hipGetLastError());
     std::vector<unsigned int> hd((size_t)n);
-    HIPCHK(hipMemcpyAsync(hd.data(), bD.p, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(x.d2h(hd.data(), bD.p, (size_t)n * sizeof(unsigned int)));
+    HIPCHK(x.finish());
     for (int64_t i = 0; i < n; i++) keep[i] = hd[i] ? 0 : 1;
     return STP_OK;
 }

@@ -137,3 +137,32 @@ def test_compute_from_a_cooler_file_on_the_device(tmp_path, monkeypatch):
             stripenn.compute(fixture, out, 'KR', 'all', 2.0, 10, 8, '0.97,0.99', 2, 0.5, '0', False, 3, 7, force=True)
         outs.append([open(os.path.join(out, f)).read() for f in ('result_unfiltered.tsv', 'result_filtered.tsv')])
     assert outs[0] == outs[1] and outs[0][0].count('\n') > 5
+
+
+def test_downloads_into_recycled_host_addresses(hip_ctx):
+    """Large pageable uploads followed by large downloads into freshly allocated arrays -- numpy hands the freed upload
+    buffers' addresses out again.  The HIP runtime keeps the pins it makes for pageable transfers in a cache keyed by the
+    host address, and a pin made for an upload is read-only to the device: before round 4 such a download could die with
+    "write access to a read-only page" (three aborted runs; tools/soak_misc.py seed 489).  The library now stages or
+    registers every host buffer itself (stp_xfer), the runtime never sees the caller's pointers."""
+    hb = BK.HipBackend(0)
+    rng = np.random.default_rng(12)
+    ch = synth.SynthChrom(1500, 77)
+    band_h = ch.band(512)
+    for it in range(12):
+        sel = hb.select_open()
+        vals = rng.random(int(rng.integers(900_000, 1_600_000))) + 0.5          # 7-13 MB, a new buffer every round
+        hb.select_append(sel, vals)
+        n = hb.select_count(sel)
+        assert n == len(vals)
+        k = int(rng.integers(0, n))
+        assert hb.select_ranks(sel, [k])[0] == np.partition(vals, k)[k]
+        hb.select_close(sel)
+        del vals
+        band = hb.open_chrom(band_h)
+        out = band.download()                                                   # 12 MB into a fresh array
+        assert np.array_equal(out, band_h, equal_nan=True)
+        del out
+        r, l = hb.diag_sums(band)
+        band.close()
+    hb.close()

@@ -23,6 +23,8 @@ def same(a, b):
     return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 t0 = time.time()
 for seed in range(first, first + count):
+    if os.environ.get('STP_SOAK_VERBOSE'):
+        print('seed', seed, flush=True)
     rng = np.random.default_rng(seed)
     nb = int(rng.integers(700, 3000))
     kind = int(rng.integers(0, 3))
