@@ -30,7 +30,11 @@ def _run():
     with contextlib.redirect_stdout(_io.StringIO()):
         stripenn.compute('pixels:in-memory', 'gpurun_out/genome_out', 'weight', 'all', 2.0, 10, 8, '0.95,0.96,0.97,0.98,0.99', 8,
                          0.1, '0', False, 3, 123456789, force=True)
-if os.environ.get('STP_PROBE_PROFILE') == '1':          # host-side hot spots of a second run (library / workspaces warm)
+if os.environ.get('STP_PROBE_PROFILE') == 'first':      # host-side hot spots of the FIRST run of the process
+    import cProfile, pstats
+    pr = cProfile.Profile(); t0 = time.time(); pr.enable(); _run(); pr.disable(); total = time.time() - t0
+    pstats.Stats(pr).sort_stats('tottime').print_stats(25)
+elif os.environ.get('STP_PROBE_PROFILE') == '1':          # host-side hot spots of a second run (library / workspaces warm)
     import cProfile, pstats
     _run(); acc.clear()
     pr = cProfile.Profile(); t0 = time.time(); pr.enable(); _run(); pr.disable(); total = time.time() - t0
