@@ -325,14 +325,29 @@ def main():
                         'frac': round(step_insts / (d['ms'] / args.steps * 1e-3) / (N_SIMD * CLOCK_HZ / cyc), 4),
                         'source': pmc.get('tag')}
         # every kernel of the step under SURVEY 8(d)'s algorithmic-byte formulas (the library's own byte counters), per launch
+        # Beside each contract fraction (`frac`: SURVEY 8(d)'s numerator, which a kernel that keeps its data on chip or
+        # searches instead of streaming can undercut -- then `frac` exceeds what the hardware moved and is marked
+        # `model_exceeds_work`, not roofline evidence) the bytes the memory system really moved: `traffic_frac` =
+        # (2 x FETCH_SIZE + WRITE_SIZE) per launch from the committed counters / the launch time measured here / HBM peak.
         per_kernel = {}
         for k, v in stats.items():
             if k == 'chain_wall' or not v['launches'] or v['ms'] <= 0:
                 continue
             g = v['alg_bytes'] / (v['ms'] * 1e-3) / 1e9
-            per_kernel['k_' + k] = {'ms_per_step': round(v['ms'] / args.steps, 3), 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
-                                    'alg_GB_per_step': round(v['alg_bytes'] / args.steps / 1e9, 3), 'achieved_GBs': round(g, 1),
-                                    'frac': round(g / HBM_PEAK_GBS, 4)}
+            e = {'ms_per_step': round(v['ms'] / args.steps, 3), 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
+                 'alg_GB_per_step': round(v['alg_bytes'] / args.steps / 1e9, 3), 'achieved_GBs': round(g, 1),
+                 'frac': round(g / HBM_PEAK_GBS, 4)}
+            pk = pmc.get('kernels', {}).get(k) if pmc_fresh else None
+            if pk and pk.get('fetch_kb') is not None and pk.get('write_kb') is not None:
+                tb = (2.0 * pk['fetch_kb'] + pk['write_kb']) * 1024.0           # bytes per launch
+                tg = tb / (v['ms'] / v['launches'] * 1e-3) / 1e9
+                e.update(traffic_GB_per_launch=round(tb / 1e9, 4), traffic_GBs=round(tg, 1), traffic_frac=round(tg / HBM_PEAK_GBS, 4),
+                         alg_over_traffic=round(v['alg_bytes'] / v['launches'] / tb, 2) if tb > 0 else None)
+            else:
+                e.update(traffic_frac=None)
+            if g / HBM_PEAK_GBS > 1.0:
+                e['model_exceeds_work'] = True
+            per_kernel['k_' + k] = e
         roof = {'bound': 'hbm', 'kernel': 'k_' + dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'traffic_source': (pmc.get('tag') if traffic is not None else
@@ -348,13 +363,19 @@ def main():
                 'chain': {'kernels_ms_per_step': {k: round(v['ms'] / args.steps, 4) for k, v in stats.items()},
                           'alg_bytes_per_image_px': 26.0,
                           'achieved_GBs': round(26.0 * image_px * args.steps / (chain_ms * 1e-3) / 1e9, 1),
-                          'frac': round(26.0 * image_px * args.steps / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
-        exact_env = os.environ.get('STP_CANNY') == 'exact'
+                          'frac': round(26.0 * image_px * args.steps / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          # the three chain kernels' counter bytes per step over the chain's wall time
+                          'traffic_frac': (round(sum(per_kernel['k_' + k]['traffic_GB_per_launch'] * stats[k]['launches'] for k in BYTES_PER_IMAGE_PX)
+                                                 / (chain_ms * 1e-3) / HBM_PEAK_GBS, 4)
+                                           if all(per_kernel.get('k_' + k, {}).get('traffic_GB_per_launch') is not None for k in BYTES_PER_IMAGE_PX) else None)}}
+        canny_exact_env, gray_exact_env = os.environ.get('STP_CANNY') == 'exact', os.environ.get('STP_GRAY') == 'exact'
+        exact_env = canny_exact_env or gray_exact_env       # (any non-default kernel selection: no `exact` companion, no stale counters)
         out = {'metric': 'contact-matrix Mpixels/s through compute path', 'value': round(value, 2),
                'unit': 'contact-Mpx/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
                'scaling': 'strong', 'vs_baseline': None,
-               'dtype': 'f64' if exact_env else 'f64 (Canny classes: certified f32 + f64 resolver; grey: certified f64 shortcut + exact redo)',
+               'dtype': 'f64 (%s; %s)' % ('Canny: every intermediate f64' if canny_exact_env else 'Canny classes: certified f32 + f64 resolver',
+                                          'grey: every operation of the reference' if gray_exact_env else 'grey: certified f64 shortcut + exact redo'),
                'data': 'synthetic',
                'emulated_rank': args.emulate_rank or None,
                'config': {'workload': '%s: %d bins, %d frames x %d maxpixel levels (0.95-0.99) x 6 brightness levels; step = frame '
@@ -378,15 +399,20 @@ def main():
                                             'f64 from shared row sums, certified against float rounding boundaries, flagged lanes redone in the '
                                             'reference\'s operations (k_gray_c3) -- bit-identical grey images')
                                          + '; Canny classes: '
-                                         + ('f64 throughout (STP_CANNY=exact)' if exact_env else
+                                         + ('f64 throughout (STP_CANNY=exact)' if canny_exact_env else
                                             'f32 with a proven error budget, the undecidable pixels in the reference\'s f64 '
                                             '(k_canny_f32) -- class maps identical to the f64 kernel and the oracle'))},
                'roofline': roof}
         if world == 1 and not args.no_extras and not exact_env:
             # the same workload with every intermediate in the reference's arithmetic (k_gray<1>, k_canny_pipe): 3 steps
+            import hashlib
+            h_def = hashlib.sha256()
+            W.step(digest=h_def)                      # the record buffers of one (untimed) step of the shipped kernels, unit by unit
+            saved_env = {k: os.environ.get(k) for k in ('STP_CANNY', 'STP_GRAY')}
             os.environ['STP_CANNY'] = 'exact'; os.environ['STP_GRAY'] = 'exact'
             try:
-                W.step()
+                h_ex = hashlib.sha256()
+                W.step(digest=h_ex)                   # ... and of the all-f64 kernels (also their warm-up)
                 W.reset_stats(); barrier()
                 t0 = time.perf_counter()
                 for _ in range(3):
@@ -395,13 +421,20 @@ def main():
                 dte = time.perf_counter() - t0
                 se = W.stats()
                 out['exact'] = {'what': 'the same workload with STP_CANNY=exact STP_GRAY=exact (every intermediate in the reference\'s f64 '
-                                        'operations; identical records), 3 steps',
+                                        'operations), 3 steps; records_equal: sha256 of every unit\'s record buffer of one step, shipped '
+                                        'kernels vs these',
+                                'records_equal': h_def.hexdigest() == h_ex.hexdigest(),
+                                'records_sha256': {'shipped': h_def.hexdigest()[:16], 'exact': h_ex.hexdigest()[:16]},
                                 'value': round(px_e * 3 / dte / 1e6, 2), 'unit': 'contact-Mpx/s', 'ms_per_step': round(dte / 3 * 1e3, 3),
                                 'canny_ms_per_launch': round(se['canny']['ms'] / se['canny']['launches'], 4),
                                 'gray_ms_per_launch': round(se['gray']['ms'] / se['gray']['launches'], 4),
                                 'kernels_ms_per_step': {k: round(v['ms'] / 3, 3) for k, v in se.items()}}
             finally:
-                os.environ.pop('STP_CANNY', None); os.environ.pop('STP_GRAY', None)
+                for k, v in saved_env.items():        # (a user-set selection stays in force for the measurements below)
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
         if world == 1 and not args.no_cpu_baseline:
             ci = min({u[0] for u in W.my_units}, key=lambda c: nbins[c])        # the smallest chromosome held here
             band_h = W.bands[names[ci]].download()
@@ -583,7 +616,7 @@ class _Workload:
         fr = self.bands[self.names[ci]].frames(st[f0:f1], en[f0:f1])
         return unit, fr, fr.stripe_search_begin(self.Ms[ci], sigma=self.sigma)
 
-    def step(self):
+    def step(self, digest=None):
         """Two searches are kept in flight: while the device runs the chain of unit u+1 (and u+2 is queued behind
         it), the host collects the records of unit u, builds the score inputs and enqueues its p-value /
         Stripiness kernels -- the single in-order stream never runs dry."""
@@ -612,6 +645,8 @@ class _Workload:
                 self.hb.pvalue(sband, self.bs, pv)
                 self.hb.stripiness(sband, self.EV[ci], sc)
                 self.host_call_s += time.perf_counter() - tw       # two blocking calls: copy in, kernel, copy out
+            if digest is not None:
+                digest.update(np.ascontiguousarray(recs[:len(recs)]).tobytes())
             nrec += len(recs)
             px += float((fr.S.astype(np.float64) ** 2).sum())
             fr.close()

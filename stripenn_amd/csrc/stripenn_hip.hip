@@ -1975,13 +1975,17 @@ struct stp_xfer {
         if (hp->lo != hp->hi) return hp->copy(dst, src, bytes, st, hipMemcpyDeviceToHost);
         return piecewise(dst, src, bytes, false);
     }
-    hipError_t finish()
+    // finish(): the explicit, successful end of a call -- the stream is drained and the staged downloads are delivered into the
+    // caller's buffers.  The destructor alone (an early error return) only drains the stream and recycles the staging buffers:
+    // by then a download's destination may be gone (a vector declared after the transfer object, a frames object already
+    // deleted), so nothing is copied into `piece.user`.
+    hipError_t finish(bool deliver = true)
     {
         if (done) return hipSuccess;
         done = true;
         const hipError_t e = hipStreamSynchronize(st);
         for (auto& pc : pieces) {
-            if (e == hipSuccess && pc.user) memcpy(pc.user, pc.stage, pc.bytes);
+            if (deliver && e == hipSuccess && pc.user) memcpy(pc.user, pc.stage, pc.bytes);
             if (ctx->stage_free.size() < 32) ctx->stage_free.push_back(std::make_pair(pc.cap, pc.stage));
             else (void)stp_hfree(__LINE__, pc.stage);
         }
@@ -1990,7 +1994,7 @@ struct stp_xfer {
         pins.clear();
         return e;
     }
-    ~stp_xfer() { (void)finish(); }
+    ~stp_xfer() { (void)finish(false); }
 };
 
 int stp_band_upload(stp_ctx* ctx, const double* band_host, int64_t nrows, int32_t hw, stp_band** out)
@@ -2405,7 +2409,13 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
                 STP_CANNY_RADII(STP_X)
 #undef STP_X
             }
-            HIPCHK(hipGetLastError());
+            // "the flag buffer is all zero" holds only if k_canny_pipe_list really ran behind k_canny_f32 (it clears what it
+            // serves).  When a launch is refused the claim is withdrawn, so the next search clears the buffer again.  (A flag
+            // left standing would only make the exact kernel redo a tile whose f32 result is already the exact one --
+            // identical bits -- but that safety should not be what the invariant rests on.)
+            const hipError_t launch_err = hipGetLastError();
+            if (launch_err != hipSuccess) { ctx->c32q_zero = nullptr; ctx->c32q_zero_bytes = 0; }
+            HIPCHK(launch_err);
         } else if (canny_tiled_radius(R)) {
             const stp_fastdiv fd = make_fastdiv(ctx, prm->gauss_w, R);
             switch (R) {

@@ -157,13 +157,18 @@ class _Object:
 
     def _v1_block(self, addr, size, nmsg):
         rd = self.rd
-        blocks = [(addr, size)]
+        blocks, seen = [(addr, size)], set()
         while blocks and len(self.msgs) < nmsg:
             a, n = blocks.pop(0)
+            if a in seen:
+                raise H5LiteError('object header continuation blocks form a cycle at %d' % a)
+            seen.add(a)
             buf = rd.read(a, n)
             p = 0
             while p + 8 <= n and len(self.msgs) < nmsg:
-                mtype, msize, _mflags = struct.unpack_from('<HHB', buf, p)
+                mtype, msize, mflags = struct.unpack_from('<HHB', buf, p)
+                if mflags & 0x02 and mtype in (0x03, 0x0B, 0x0C):
+                    raise H5LiteUnsupported('shared (committed) datatype / filter / attribute message in the object header at %d' % self.addr)
                 body = buf[p + 8:p + 8 + msize]
                 p += 8 + msize
                 if mtype == 0x10:                               # continuation
@@ -172,7 +177,7 @@ class _Object:
 
     def _v2(self, addr):
         rd = self.rd
-        head = rd.read(addr, 64)
+        head = rd.read(addr, min(64, rd.size - addr))          # (a header within 64 bytes of the end of the file)
         flags = head[5]
         p = 6
         if flags & 0x20:
@@ -183,9 +188,12 @@ class _Object:
         size0 = rd.uint(head, p, w)
         p += w
         track = bool(flags & 0x04)
-        blocks = [(addr + p, size0)]
+        blocks, seen = [(addr + p, size0)], set()
         while blocks:
             a, n = blocks.pop(0)
+            if a in seen:
+                raise H5LiteError('object header continuation blocks form a cycle at %d' % a)
+            seen.add(a)
             buf = rd.read(a, n)
             q = 0
             while q + 4 <= n:
@@ -303,8 +311,10 @@ class Group:
                 raise H5LiteUnsupported('group %r keeps its links in a fractal heap (file written with libver="latest")' % self.name)
         self._links = links
 
-    def _walk_group_tree(self, addr, heap, links):
+    def _walk_group_tree(self, addr, heap, links, depth=0):
         rd = self.rd
+        if depth > 32:                                          # (a B-tree this deep does not exist; a cyclic file does)
+            raise H5LiteError('group B-tree deeper than 32 levels at %d (corrupt or cyclic file)' % addr)
         head = rd.read(addr, 8 + 2 * rd.O)
         if head[:4] != b'TREE' or head[4] != 0:
             raise H5LiteError('no group B-tree node at %d' % addr)
@@ -315,7 +325,7 @@ class Group:
             child = rd.uint(body, p, rd.O) + rd.base
             p += rd.O + rd.L
             if level:
-                self._walk_group_tree(child, heap, links)
+                self._walk_group_tree(child, heap, links, depth + 1)
                 continue
             s = rd.read(child, 8)
             if s[:4] != b'SNOD':
@@ -425,8 +435,10 @@ class Dataset:
             self._index = idx
         return self._index
 
-    def _walk_chunk_tree(self, addr, idx):
+    def _walk_chunk_tree(self, addr, idx, depth=0):
         rd = self.rd
+        if depth > 32:
+            raise H5LiteError('chunk B-tree deeper than 32 levels at %d (corrupt or cyclic file)' % addr)
         head = rd.read(addr, 8 + 2 * rd.O)
         if head[:4] != b'TREE' or head[4] != 1:
             raise H5LiteError('no chunk B-tree node at %d' % addr)
@@ -439,7 +451,7 @@ class Dataset:
             offs = struct.unpack_from('<%dQ' % self.ndim, body, p + 8)
             child = rd.uint(body, p + ksz, rd.O) + rd.base
             if level:
-                self._walk_chunk_tree(child, idx)
+                self._walk_chunk_tree(child, idx, depth + 1)
             else:
                 idx[offs] = (child, csize, mask)
 

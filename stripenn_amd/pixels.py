@@ -257,8 +257,10 @@ class CoolTable:
         self.chunk = int(chunk)
         self.max_read = 0            # largest single read of a pixel column, in pixels (tests)
         self.threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)))
-        self._pool = None            # inflate workers (created with the first piece read)
-        self._readers = None
+        self._pool = None            # inflate workers (created with the first piece read, under _lazy_lock: the read-ahead
+        self._readers = None         #  thread and the caller's thread may both arrive here first)
+        import threading
+        self._lazy_lock = threading.Lock()
         self.direct_reads = 0        # HDF5 chunks decoded by _ChunkReader rather than by HDF5's own filter pipeline (tests)
         self._ahead = {}             # chrom -> (thread, result box)
         self._nonneg = None
@@ -323,21 +325,23 @@ class CoolTable:
         releases the GIL).  Any other filter pipeline, or a chunk the writer stored unfiltered, goes through h5py's
         ordinary read."""
         cols = (self.bin1_id, self.bin2_id, self.count)
-        if self._readers is None:
-            self._readers = [_ChunkReader.of(d) for d in cols]
-        readers = self._readers
+        with self._lazy_lock:
+            if self._readers is None:
+                self._readers = [_ChunkReader.of(d) for d in cols]
+            readers = self._readers
+            if self.threads >= 2 and self._pool is None and not any(r is None for r in readers):
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(self.threads)
         if self.threads < 2 or any(r is None for r in readers):
             return tuple(np.asarray(d[x:y]) for d in cols)
-        if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(self.threads)
         outs = [np.empty(y - x, d.dtype) for d in cols]
         jobs = []
         for r, o in zip(readers, outs):
             for c0 in range(x - x % r.clen, y, r.clen):
                 jobs.append(self._pool.submit(r.into, c0, x, y, o))
-        for j in jobs:
-            self.direct_reads += j.result()
+        n = sum(j.result() for j in jobs)
+        with self._lazy_lock:
+            self.direct_reads += n
         return tuple(outs)
 
     def prefetch(self, chrom):

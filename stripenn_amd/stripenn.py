@@ -3,7 +3,6 @@ as the reference's stripenn.compute (src/stripenn/stripenn.py:64-163); the five 
 the MI355X stripe engine (stripenn_amd/getStripe.py).  Extra keywords (not in the reference):
 `force` (non-interactive overwrite of the output directory), `device`, and `gpus` > 1 to shard the
 chromosome x maxpixel grid over several GPUs (stripenn_amd/shard.py)."""
-import errno
 import os
 import shutil
 import sys
@@ -21,39 +20,37 @@ RESULT_COLUMNS = ['chr', 'pos1', 'pos2', 'chr2', 'pos3', 'pos4', 'length', 'widt
 HELPER_COLUMNS = ['total', 'num', 'start', 'end', 'x', 'y', 'h', 'w', 'medpixel']
 
 
+def _empty_directory(path):
+    """Remove every entry of `path` (not the directory itself); an entry that cannot be removed is reported and skipped."""
+    with os.scandir(path) as entries:
+        for entry in entries:
+            try:
+                if entry.is_dir(follow_symlinks=False):
+                    shutil.rmtree(entry.path)
+                else:
+                    os.unlink(entry.path)
+            except OSError as e:
+                print('Failed to delete %s with the reason: %s' % (entry.path, e))
+
+
 def makeOutDir(outdir, force=False):
-    """stripenn.py:12-42 (the interactive prompt is kept; force=True answers Y)."""
-    if outdir[-1] != '/':
-        outdir += '/'
-    if os.path.exists(outdir):
-        if force:
-            userinput = 'Y'
-        else:
-            print('\n%s exists. Do you want to remove all files and save new results in this folder? [Y/n]' % outdir)
-            userinput = input()
-        if userinput in ('Y', 'y'):
-            print('All directories and files in %s will be deleted.' % outdir)
-            for filename in os.listdir(outdir):
-                file_path = os.path.join(outdir, filename)
-                try:
-                    if os.path.isfile(file_path) or os.path.islink(file_path):
-                        os.unlink(file_path)
-                    elif os.path.isdir(file_path):
-                        shutil.rmtree(file_path)
-                except Exception as e:
-                    print('Failed to delete %s with the reason: %s' % (file_path, e))
-        elif userinput in ('n', 'N'):
-            print('Input another output directory. Exit.')
-            sys.exit()
-        else:
-            print('Type Y or n.\nExit.')
-            sys.exit()
-    else:
-        try:
-            os.makedirs(outdir)
-        except OSError as e:
-            if e.errno != errno.EEXIST:
-                raise
+    """Prepare the output directory with the behaviour of the reference's helper (stripenn.py:12-42): a missing directory is
+    created; an existing one is emptied after the user answers Y to the same prompt (force=True answers for them), kept and
+    the run ended on n, and the run ended on anything else."""
+    outdir = os.path.join(outdir, '')                      # trailing separator, as the messages print it
+    if not os.path.exists(outdir):
+        os.makedirs(outdir, exist_ok=True)
+        return
+    answer = 'y'
+    if not force:
+        print('\n%s exists. Do you want to remove all files and save new results in this folder? [Y/n]' % outdir)
+        answer = input()
+    if answer in ('Y', 'y'):
+        print('All directories and files in %s will be deleted.' % outdir)
+        _empty_directory(outdir)
+        return
+    print('Input another output directory. Exit.' if answer in ('n', 'N') else 'Type Y or n.\nExit.')
+    sys.exit()
 
 
 def addlog(cool, out, norm, chrom, canny, minL, maxW, maxpixel, numcores, pvalue, mask, bfilter):

@@ -104,12 +104,16 @@ def test_mm10_genome_compute_determinism_invariants_and_sampled_frames(tmp_path)
     a = _run_compute(table, str(tmp_path / 'a'), '0.95,0.96,0.97,0.98,0.99')
     b = _run_compute(table, str(tmp_path / 'b'), '0.95,0.96,0.97,0.98,0.99')
     assert a == b, 'two runs of the same genome differ'
-    os.environ['STP_CANNY'] = 'exact'             # the all-f64 Canny kernel instead of k_canny_f32 (79 350 images): same TSVs
+    # every intermediate in the reference's f64 operations -- k_canny_pipe instead of k_canny_f32 AND k_gray<1> instead of the
+    # certified k_gray_c3 -- on all 79 350 images: same TSVs
+    os.environ['STP_CANNY'] = 'exact'
+    os.environ['STP_GRAY'] = 'exact'
     try:
         c = _run_compute(table, str(tmp_path / 'c'), '0.95,0.96,0.97,0.98,0.99')
     finally:
         os.environ.pop('STP_CANNY', None)
-    assert a == c, 'k_canny_f32 and k_canny_pipe give different tables'
+        os.environ.pop('STP_GRAY', None)
+    assert a == c, 'the certified kernels (k_canny_f32, k_gray_c3) and the exact ones (k_canny_pipe, k_gray<1>) give different tables'
     u, f = _check_tables(a[0], a[1], names, MM10, levels, 0.1)
     assert len(u) > 30000 and len(f) > 2000 and set(u['chr']) == set(names)
     # >= 40 frames across all chromosomes against the oracle: the facade's own quantiles and searches

@@ -5,7 +5,7 @@ K=${1:-k_canny_f32}; shift
 LIBS=${@:-libstripenn_hip.so}
 R=$(pwd); cd /tmp; export TMPDIR=/tmp
 for l in $LIBS; do
-  out=$R/gpurun_out/pmc_diag_${K}_$(basename $l .so).txt; : > $out
+  mkdir -p $R/gpurun_out; out=$R/gpurun_out/pmc_diag_${K}_$(basename $l .so).txt; : > $out
   PYTHONPATH=$R STP_LIB=$R/stripenn_amd/$l timeout 200 python3 $R/tools/probe_chain.py | tail -1 >> $out
   n=0
   for set in \
