@@ -46,7 +46,7 @@ CHR16_BINS = 19642     # mm10 chr16 (98,207,768 bp) at 5 kb
 RESOL = 5000
 MAXPIXEL = [0.95, 0.96, 0.97, 0.98, 0.99]
 BYTES_PER_IMAGE_PX = {'gray': 12.0, 'canny': 5.0, 'lines': 9.0}  # SURVEY.md 8(d) stages A, B, C-F
-SCORE_KERNELS = ('pvalue', 'stripiness')
+SCORE_KERNELS = ('pvalue', 'stripiness', 'score')
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_current.json')    # written by tools/summarize_profile.py
 
 
@@ -566,8 +566,7 @@ class _Workload:
                 ci, recs, nz, st = job
                 pv, sc = self.BK.score_inputs(recs, nz, st, self.nbins[ci], self.bs)
                 sband = self.bands2[self.names[ci]]
-                self.hb2.pvalue(sband, self.bs, pv)
-                self.hb2.stripiness(sband, self.EV[ci], sc)
+                self.hb2.score(sband, self.bs, self.EV[ci], pv, sc)
             except BaseException as e:      # noqa: BLE001 -- reported by step()
                 self._err.append(e)
             finally:
@@ -642,9 +641,12 @@ class _Workload:
                 sband = self.bands[self.names[ci]]
                 pv, sc = self.BK.score_inputs(recs, fr.nz, st[f0:f1], self.nbins[ci], self.bs)
                 tw = time.perf_counter()
-                self.hb.pvalue(sband, self.bs, pv)
-                self.hb.stripiness(sband, self.EV[ci], sc)
-                self.host_call_s += time.perf_counter() - tw       # two blocking calls: copy in, kernel, copy out
+                if os.environ.get('STP_BENCH_SCORE_CALLS') == '2':  # (A/B hook: the two separate calls of rounds 1-4)
+                    self.hb.pvalue(sband, self.bs, pv)
+                    self.hb.stripiness(sband, self.EV[ci], sc)
+                else:
+                    self.hb.score(sband, self.bs, self.EV[ci], pv, sc)     # p-value and Stripiness: one upload, one launch, one download
+                self.host_call_s += time.perf_counter() - tw       # one blocking call: copy in, kernel, copy out
             if digest is not None:
                 digest.update(np.ascontiguousarray(recs[:len(recs)]).tobytes())
             nrec += len(recs)

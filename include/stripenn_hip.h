@@ -246,6 +246,13 @@ typedef struct {
 int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, const stp_score_stripe* stripes,
                    int64_t n, double* out_g, double* out_oe_mean, double* out_oe_total, int32_t* out_status);
 
+/* ---- p-value AND Stripiness of the same stripes in one call (one upload, one launch, one download): what
+ * score.getScore (score.py:52-55) and a driver that scores candidates straight from the search do back to back.
+ * pv_stripes[i] / sc_stripes[i] describe stripe i as stp_pvalue / stp_stripiness take it; outputs as theirs. */
+int stp_score(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int32_t bs, const double* exval400,
+              const stp_pv_stripe* pv_stripes, const stp_score_stripe* sc_stripes, int64_t n, double* out_p, double* out_g,
+              double* out_oe_mean, double* out_oe_total, int32_t* out_status);
+
 /* ---- observed mean / sum: getStripe.getMean (getStripe.py:501-534) -------------------------- */
 typedef struct {
     int32_t row0, row1, col0, col1;

@@ -68,6 +68,7 @@ class HipBackend:
         L.stp_background_free.restype = None
         L.stp_pvalue.argtypes = [vp, vp, vp, C.c_int32, vp, C.c_int64, vp]
         L.stp_stripiness.argtypes = [vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp]
+        L.stp_score.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp]
         L.stp_stripe_mean.argtypes = [vp, vp, vp, C.c_int64, vp, vp]
         L.stp_window_plane.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_double, vp]
         L.stp_remove_redundant.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
@@ -171,6 +172,24 @@ class HipBackend:
             raise IndexError('index out of bounds for axis 0: an all-NaN flank column maps to a row outside stripe %d'
                              % int(np.nonzero(status)[0][0]))
         return g, m, t
+
+    def score(self, band, bs, exval, pv_stripes, sc_stripes):
+        """p-value and Stripiness of the same stripes in ONE device call (stp_score): (p, g, O/E mean, O/E total)."""
+        pv = np.ascontiguousarray(pv_stripes, dtype=PV_STRIPE_DTYPE)
+        sc = np.ascontiguousarray(sc_stripes, dtype=SCORE_STRIPE_DTYPE)
+        if len(pv) != len(sc):
+            raise ValueError('score: %d p-value stripes but %d Stripiness stripes' % (len(pv), len(sc)))
+        exval = np.ascontiguousarray(exval, dtype=np.float64)
+        n = len(pv)
+        p, g, m, t = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
+        status = np.zeros(n, np.int32)
+        if n:
+            self.ctx._chk(self.ctx.L.stp_score(self.ctx.h, band.h, self._bg, int(bs), _p(exval), _p(pv), _p(sc), n, _p(p), _p(g), _p(m),
+                                               _p(t), _p(status)))
+        if status.any():
+            raise IndexError('index out of bounds for axis 0: an all-NaN flank column maps to a row outside stripe %d'
+                             % int(np.nonzero(status)[0][0]))
+        return p, g, m, t
 
     def stripe_mean(self, band, rects):
         rects = np.ascontiguousarray(rects, dtype=RECT_DTYPE)

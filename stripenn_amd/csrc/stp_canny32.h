@@ -62,7 +62,36 @@ struct stp_w32 {
     // row (stp_bleed_v / stp_bleed_h: the same for every such row), with their f32 reciprocals (c32_rb_tables): tiles that the
     // border does not cut vertically fill their tables from these instead of running the 2R+1-step f64 loops per row
     double vfull, bifull; float rbfull, rvfull;
+    // flat-window threshold for tiles whose every window lies inside the image (c32_flat_interior below)
+    float flat_int;
 };
+
+// Flat-window rule for INTERIOR tiles (round 5).  STP_FLAT_RANGE (stp_phases.h) rests on "every smoothed value lies between
+// the extremes of its window": |S(x+1) - S(x-1)| <= range, |sobel| <= 4 range, magnitude <= 5.657 range.  Where every
+// window of the tile (its two halo rows / columns included) lies inside the image the weights are the same for
+// neighbouring pixels -- the bleed-over is one constant -- and the difference is itself ONE weighted sum of the grey values:
+//   S(y, x+1) - S(y, x-1) = sum_ky v_ky sum_k (v_{k-1} - v_{k+1}) g(y + ky, x + k),   v = w / sum(w)  (v = 0 beyond +-R).
+// The coefficients d_k = v_{k-1} - v_{k+1} add up to 0, so any constant c may be subtracted from g; with c the middle of the
+// window's range, |sum_k d_k (g - c)| <= (sum_k |d_k|) range / 2.  The weights fall away from the centre on both sides, so
+// sum_k |d_k| telescopes to 2 (v_0 + v_1) (centre tap and its neighbour), and the outer sum is convex:
+//   |S(x+1) - S(x-1)| <= (v_0 + v_1) range,   |jsobel|, |isobel| <= 4 (v_0 + v_1) range  (the rows' / columns' (1, 2, 1)),
+//   magnitude <= 5.657 (v_0 + v_1) (range + 6e-7)        [the same two float roundings as in STP_FLAT_RANGE's derivation].
+// v_0 + v_1 = 0.3755 at sigma 2 (0.307 at 2.5): magnitudes stay below 0.085 for range < 0.040 instead of 0.015.
+// Border tiles keep STP_FLAT_RANGE (their windows are renormalised pixel by pixel).  Monotone weights are checked; weights that
+// are not (no Gaussian is) fall back to STP_FLAT_RANGE.
+STP_HD float c32_flat_interior(const double* w /* w[R] = centre */, int R)
+{
+    double W = w[R];
+    for (int k = 1; k <= R; k++) {
+        if (!(w[R - k] <= w[R - k + 1]) || !(w[R - k] >= 0.0)) return STP_FLAT_RANGE;
+        W += 2.0 * w[R - k];
+    }
+    if (R < 1 || !(W > 0.0)) return STP_FLAT_RANGE;
+    const double v01 = (w[R] + w[R - 1]) / W;
+    const double thr = 0.0849 / (5.65686 * v01) - 1e-5;                  // 5.65686 > 4 sqrt 2; slack for the roundings
+    const float f = (float)(thr * 0.9999);
+    return f > STP_FLAT_RANGE ? (f < 1.0f ? f : 1.0f) : STP_FLAT_RANGE;
+}
 
 // rho = 3 + sum_k P_k / W of one pass for the window cut to taps lo .. hi (-R <= lo <= 0 <= hi <= R), see above
 STP_HD double c32_rho(const double* w /* w[R] = centre */, int R, int lo, int hi)
@@ -95,6 +124,7 @@ STP_HD void c32_budget(const double* w, int R, stp_w32* out)
     out->bifull = stp_bleed_h(out->vfull, 2 * R + 2, Sbig, R, w);
     out->rbfull = (float)(1.0 / (out->bifull + DBL_EPSILON));
     out->rvfull = (float)(1.0 / out->vfull);
+    out->flat_int = c32_flat_interior(w, R);
 }
 // which of the three a tile uses
 STP_HD int c32_budget_of(bool interior, int S, int R) { return interior ? 0 : (S >= 2 * R + 1 ? 1 : 2); }

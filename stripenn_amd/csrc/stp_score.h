@@ -18,7 +18,28 @@ struct stp_bandref {
     const double* d;
     int64_t nrows;
     int W, hw;
+    int sym;      // 1: the band has been verified bit for bit symmetric (k_band_symcheck) -- M[r][c] may be read as M[c][r]
 };
+
+// Is the band symmetric, M[i][i + d] == M[i + d][i] bit for bit for 0 < d < hw?  Every band of a contact map is (cooler stores
+// the upper triangle; the packer writes one value into both cells), but the ABI takes any band, so it is checked -- once per
+// band -- before a kernel relies on it.  Why it matters: a stripe is a tall, narrow rectangle.  Its rows lie W - 1 doubles
+// apart in the band (lane = row: 64 cache lines per wave load), but by symmetry column c of the matrix IS row c of the band:
+// M[r][c] = band[c][r - c + hw], consecutive rows at consecutive addresses (lane = row: one 512-byte run per wave load).
+__global__ __launch_bounds__(256) void k_band_symcheck(const double* __restrict__ band, int64_t nrows, int W, int hw, int* __restrict__ asym)
+{
+    const int64_t n = nrows * (int64_t)(hw - 1);
+    int bad = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n && !bad; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = p / (hw - 1);
+        const int d = (int)(p - i * (hw - 1)) + 1;
+        if (i + d >= nrows) continue;
+        const unsigned long long a = (unsigned long long)__double_as_longlong(band[i * (int64_t)W + hw + d]);
+        const unsigned long long b = (unsigned long long)__double_as_longlong(band[(i + d) * (int64_t)W + hw - d]);
+        if (a != b) bad = 1;
+    }
+    if (bad) atomicOr(asym, 1);
+}
 
 // M[r][c] with NaN kept; 0 outside the band / chromosome
 __device__ __forceinline__ double band_at(const stp_bandref& B, int64_t r, int64_t c)
@@ -248,14 +269,16 @@ __device__ __forceinline__ int bg_count_ge(const double* __restrict__ srt, int n
 template <bool BIG>
 __global__ __launch_bounds__(256) void k_pvalue(stp_bandref B, const double* __restrict__ srt /* sorted lu,ru,ld,rd */,
                                                  const int* __restrict__ nvalid, int ncolbg, int bs,
-                                                 const stp_pv_stripe* __restrict__ st, double* __restrict__ out, int HR)
+                                                 const stp_pv_stripe* __restrict__ st, double* __restrict__ out, int HR,
+                                                 const int* __restrict__ idx = nullptr /* stripes of this launch (null: all, in order) */)
 {
     // LDS sized by the host for the tallest stripe of the batch: pv[HR] | part[3][HR]
     extern __shared__ double s_dyn[];
     double* const pv = s_dyn;
     double* const part[3] = {s_dyn + HR, s_dyn + 2 * HR, s_dyn + 3 * HR};
     __shared__ double s_res[2];
-    const stp_pv_stripe s = st[blockIdx.x];
+    const int si = idx ? idx[blockIdx.x] : (int)blockIdx.x;
+    const stp_pv_stripe s = st[si];
     const int h = s.row1 - s.row0;
     const int ncol = s.col1 - s.col0;
     int64_t lo[3], hi[3];
@@ -289,7 +312,7 @@ __global__ __launch_bounds__(256) void k_pvalue(stp_bandref B, const double* __r
     }
     __syncthreads();
     double med = block_median(pv, h, s_res);
-    if (threadIdx.x == 0) out[blockIdx.x] = med;
+    if (threadIdx.x == 0) out[si] = med;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -299,7 +322,8 @@ template <bool BIG>
 __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double* __restrict__ exval,
                                                      const stp_score_stripe* __restrict__ st, double* __restrict__ out_g,
                                                      double* __restrict__ out_mean, double* __restrict__ out_total,
-                                                     int* __restrict__ out_status, int HR, int CW)
+                                                     int* __restrict__ out_status, int HR, int CW,
+                                                     const int* __restrict__ idx = nullptr)
 {
     // LDS sized by the host for the tallest / widest stripe of the batch (HR rows, CW columns per block):
     // ex[400] | rowm[3][HR] | diff[max(HR, 256)] | keepr[HR] | keepc[3][CW] | rowdel[HR]
@@ -318,7 +342,8 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
     __shared__ stp_score_stripe s_stripe;            // indexed with run-time block numbers: keep it out of scratch
     __shared__ stp_pw_frame s_stk[16];
     const int tid = threadIdx.x, nt = blockDim.x;
-    if (tid == 0) s_stripe = st[blockIdx.x];
+    const int si = idx ? idx[blockIdx.x] : (int)blockIdx.x;
+    if (tid == 0) s_stripe = st[si];
     __syncthreads();
     const stp_score_stripe& s = s_stripe;
     const int h = s.row1 - s.row0;
@@ -394,7 +419,7 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
         }
     }
     __syncthreads();
-    if (tid == 0) out_status[blockIdx.x] = s_status;
+    if (tid == 0 && out_status) out_status[si] = s_status;
     if (s_anydel) {
         if (tid < 64) {
             const int lane = tid;
@@ -503,12 +528,429 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
             sum = stp_pw<true>([&](int64_t k) { return dk[k]; }, 0, n, s_stk);
         }
         const double avg = sum / (double)n;
-        out_g[blockIdx.x] = med * avg;
+        out_g[si] = med * avg;
         const int nc = nkc[0];
         // every centre column deleted (a mask covering the whole stripe width): np.sum over the empty block is 0.0,
         // np.mean is NaN (getStripe.py:747-748)
-        out_total[blockIdx.x] = (nc == 0) ? 0.0 : s_tot * (double)nc;
-        out_mean[blockIdx.x] = (nc == 0) ? NAN : (s_tot * (double)nc) / ((double)hk * nc * nc);
+        out_total[si] = (nc == 0) ? 0.0 : s_tot * (double)nc;
+        out_mean[si] = (nc == 0) ? NAN : (s_tot * (double)nc) / ((double)hk * nc * nc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_score_wave (round 5): p-value and / or Stripiness of one stripe per WAVE -- four stripes per workgroup, no workgroup
+// barrier after the expected-value table is in LDS.  k_pvalue / k_stripiness give a stripe a whole workgroup and walk it in
+// ~8 / ~20 barrier-separated phases; a candidate stripe is ~60 rows x ~28 columns, so most of their time is barriers, index
+// divisions, bounds tests per element and a quadratic median spread over idle lanes.  Here lane = row (up to SW_KR rows per
+// lane), every loop over columns is wave-uniform, and
+//   * the host has checked the rectangles against the band (check_rect), so pixels are read without bounds tests;
+//   * column occupancy (the all-NaN-column rule, getStripe.py:709-711) is one ballot per column, kept as a 64-bit mask;
+//   * the medians are rank selections whose counts are ballots (scalar popcounts), ending as soon as both middle order
+//     statistics are known;
+//   * np.mean(diff) keeps numpy's pairwise order (eight stride-8 partial sums per leaf, two leaves beyond 128 values).
+// Same operations in the same order per output as k_pvalue / k_stripiness (p-value, Stripiness: bit-identical; the centre
+// sum is a tolerance statistic in both and is reduced in another order here).  Stripes the wave form does not take --
+// more than SW_MAXH rows, a block wider than SW_MAXW columns, row sums of more than 128 terms -- go to the block kernels
+// through an index list; STP_SCORE=block sends everything there (tests compare the two).
+#define SW_KR_SHORT 2      /* rows per lane of the two instances: stripes of up to 128 rows (95 % of the candidates; 28 waves per CU) ... */
+#define SW_KR_TALL 4       /* ... and of up to 256 rows (the rest of what a 400-bin frame yields; 16 waves per CU) */
+#define SW_MAXH (64 * SW_KR_TALL)
+#define SW_MAXW 64
+#define SW_WAVES 4
+
+// stp_pw_leaf with its loads in batches of eight (the values of a batch are requested before the first is added: one memory
+// round trip per batch instead of one per element); same additions in the same order.
+template <class F>
+__device__ __forceinline__ double sw_pw_leaf(F get, int64_t o, int n)
+{
+    if (n < 8) {
+        double v[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) v[i] = (i < n) ? get(o + i) : 0.0;
+        double res = 0.;
+#pragma unroll
+        for (int i = 0; i < 7; i++)
+            if (i < n) res += v[i];
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) r[t] = get(o + t);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        double v[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) v[t] = get(o + i + t);
+#pragma unroll
+        for (int t = 0; t < 8; t++) r[t] += v[t];
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    {
+        const int m = n - i;                                    // 0 .. 7 tail values, in order
+        double v[7];
+#pragma unroll
+        for (int t = 0; t < 7; t++) v[t] = (t < m) ? get(o + i + t) : 0.0;
+#pragma unroll
+        for (int t = 0; t < 7; t++)
+            if (t < m) res += v[t];
+    }
+    return res;
+}
+
+__device__ __forceinline__ void sw_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// Order statistics k0 <= k1 of arr[0..n) (this wave's LDS array): *r0 / *r1 = a value v with #(< v) <= k < #(<= v), 0.0 when
+// there is none -- block_median's rule; NaN entries are never counted and never chosen.  All lanes must call.
+template <int SW_KR>
+__device__ __forceinline__ void sw_select(const double* arr, int n, int k0, int k1, int lane, double* r0, double* r1)
+{
+    double m[SW_KR];
+    const int nq = (n + 63) >> 6;
+#pragma unroll
+    for (int q = 0; q < SW_KR; q++) { const int j = lane + 64 * q; m[q] = (q < nq && j < n) ? arr[j] : NAN; }
+    double a = 0.0, b = 0.0;
+    bool fa = false, fb = false;
+    for (int k = 0; k < n && !(fa && fb); k++) {               // wave-uniform
+        const double v = arr[k];
+        int less = 0, leq = 0;
+#pragma unroll
+        for (int q = 0; q < SW_KR; q++)
+            if (q < nq) { less += __popcll(__ballot(m[q] < v)); leq += __popcll(__ballot(m[q] <= v)); }
+        if (less <= k0 && k0 < leq) { a = v; fa = true; }
+        if (less <= k1 && k1 < leq) { b = v; fb = true; }
+    }
+    *r0 = a; *r1 = b;
+}
+// numpy's pairwise sum of v[0..n), n <= 256: stp_pw's recursion pw(o, n) = pw(o, n2) + pw(o + n2, n - n2), n2 = n / 2 - (n / 2) % 8,
+// ends in at most three leaves of <= 128 values here -- [0, nA), and [nA, n) either whole or split once more -- whose eight
+// stride-8 partial sums run on lanes 0..7 / 8..15 / 16..23; `scr`: 24 doubles of this wave's LDS.  All lanes must call;
+// the result is wave-uniform.
+__device__ __forceinline__ double sw_pw_sum(const double* v, int n, int lane, double* scr)
+{
+    int off[3] = {0, 0, 0}, len[3] = {n, 0, 0};
+    int nl = 1;
+    if (n > 128) {
+        int n2 = n / 2; n2 -= n2 % 8;
+        len[0] = n2; off[1] = n2; len[1] = n - n2; nl = 2;
+        if (len[1] > 128) {
+            int m2 = len[1] / 2; m2 -= m2 % 8;
+            off[2] = off[1] + m2; len[2] = len[1] - m2; len[1] = m2; nl = 3;
+        }
+    }
+    const int lf = lane >> 3, t = lane & 7;
+    if (lf < nl) {
+        const int o = lf == 0 ? off[0] : (lf == 1 ? off[1] : off[2]), m = lf == 0 ? len[0] : (lf == 1 ? len[1] : len[2]);
+        if (m >= 8) {
+            double r = v[o + t];
+            for (int i = 8; i < m - (m % 8); i += 8) r += v[o + i + t];
+            scr[lf * 8 + t] = r;
+        }
+    }
+    sw_sync();
+    double res[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        if (l >= nl) break;
+        const int o = off[l], m = len[l];
+        double r;
+        int i;
+        if (m < 8) { r = 0.; i = 0; }
+        else {
+            const double* a = scr + l * 8;
+            r = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+            i = m - (m % 8);
+        }
+        for (; i < m; i++) r += v[o + i];
+        res[l] = r;
+    }
+    const double tot = nl == 1 ? res[0] : (nl == 2 ? res[0] + res[1] : res[0] + (res[1] + res[2]));
+    sw_sync();
+    return tot;
+}
+
+template <bool DO_PV, bool DO_SC, int SW_KR>
+__global__ __launch_bounds__(64 * SW_WAVES) void k_score_wave(stp_bandref B, const int* __restrict__ idx, int nidx, int bs,
+                                                              const double* __restrict__ srt, const int* __restrict__ nvalid, int ncolbg,
+                                                              const stp_pv_stripe* __restrict__ pst, double* __restrict__ out_p,
+                                                              const double* __restrict__ exval, const stp_score_stripe* __restrict__ sst,
+                                                              double* __restrict__ out_g, double* __restrict__ out_mean,
+                                                              double* __restrict__ out_total, int* __restrict__ out_status)
+{
+    __shared__ double exl[STP_NDIAG];                            // expected value + 1e-8 (getStripe.py:655-659)
+    __shared__ double s_arr[SW_WAVES][3][64 * SW_KR];
+    __shared__ double s_scr[SW_WAVES][24];
+    __shared__ int16_t s_keepc[SW_WAVES][3][SW_MAXW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (DO_SC) {
+        for (int i = tid; i < STP_NDIAG; i += 64 * SW_WAVES) exl[i] = exval[i] + .00000001;
+        __syncthreads();
+    }
+    const int slot = blockIdx.x * SW_WAVES + wv;
+    if (slot >= nidx) return;                                    // (no workgroup barrier below)
+    const int si = __builtin_amdgcn_readfirstlane(idx ? idx[slot] : slot);
+    double* const A = s_arr[wv][0];
+    double* const Bv = s_arr[wv][1];
+    double* const Cv = s_arr[wv][2];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (DO_PV) {
+        // ---- getStripe.pvalue (getStripe.py:552-605), as k_pvalue
+        const stp_pv_stripe s = pst[si];
+        const int h = s.row1 - s.row0, ncol = s.col1 - s.col0, nq = (h + 63) >> 6;
+        const bool tr = B.sym && (s.row1 - 1 - s.col0 < B.hw);          // every mirrored pixel lies inside its band row (wave-uniform)
+        int64_t lo[3], hi[3];
+        stp_pyslice(bs, -bs, ncol, &lo[0], &hi[0]);
+        stp_pyslice(0, bs, ncol, &lo[1], &hi[1]);
+        stp_pyslice(-bs, ncol, ncol, &lo[2], &hi[2]);
+        double dv[2 * SW_KR];                                    // centre - left, centre - right of row lane + 64 q
+        int nv[2 * SW_KR];
+        const double* sp[2 * SW_KR];
+#pragma unroll
+        for (int t = 0; t < 2 * SW_KR; t++) { dv[t] = 0.0; nv[t] = 0; sp[t] = srt; }
+#pragma unroll
+        for (int q = 0; q < SW_KR; q++) {
+            if (q >= nq) break;                                  // wave-uniform
+            const int j = lane + 64 * q;
+            const bool on = j < h;
+            const int jj = on ? j : 0;                           // idle lanes repeat row 0 (loads stay inside the rectangle)
+            const int64_t gr = (int64_t)s.row0 + jj;
+            // mat[jj][k] = M[gr][col0 + k]: read from band row gr (rowp[k]) or, in a symmetric band, as M[col0 + k][gr] from
+            // band row col0 + k (colp[k * (W - 1)]: consecutive lanes = consecutive rows = consecutive addresses)
+            const double* rowp = B.d + gr * (int64_t)B.W + ((int64_t)s.col0 - gr + B.hw);
+            const double* colp = B.d + (int64_t)s.col0 * B.W + (gr - (int64_t)s.col0 + B.hw);
+            const int64_t cstep = B.W - 1;
+            double part[3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const int n = (int)(hi[p] - lo[p]);
+                if (tr) part[p] = sw_pw_leaf([&](int64_t k) { const double v = colp[k * cstep]; return (v != v) ? 0.0 : v; }, lo[p], n) / (double)n;
+                else part[p] = sw_pw_leaf([&](int64_t k) { const double v = rowp[k]; return (v != v) ? 0.0 : v; }, lo[p], n) / (double)n;
+            }
+            dv[2 * q] = part[0] - part[1]; dv[2 * q + 1] = part[0] - part[2];
+            int d, tab;
+            if (s.mode == 0) { d = jj; tab = 1; }
+            else if (s.mode == 1) { d = s.upbase - jj - 1; tab = 0; }
+            else { d = s.fixed_row; tab = s.fixed_tab; }
+            if (s.mode != 2 && d >= 400) d = 399;
+            if (d < 0) d += STP_NDIAG;
+            const size_t rl = (size_t)(tab ? 2 : 0) * STP_NDIAG + d, rr = (size_t)(tab ? 3 : 1) * STP_NDIAG + d;
+            nv[2 * q] = nvalid[rl]; nv[2 * q + 1] = nvalid[rr];
+            sp[2 * q] = srt + rl * ncolbg; sp[2 * q + 1] = srt + rr * ncolbg;
+        }
+        // the lower bounds of all (row, side) pairs of a lane in lock step: 2 nq dependent load chains in flight
+        int slo[2 * SW_KR], shi[2 * SW_KR];
+#pragma unroll
+        for (int t = 0; t < 2 * SW_KR; t++) { slo[t] = 0; shi[t] = (t < 2 * nq) ? nv[t] : 0; }
+        for (;;) {
+            bool any = false;
+            double xv[2 * SW_KR];
+            int mid[2 * SW_KR];
+#pragma unroll
+            for (int t = 0; t < 2 * SW_KR; t++) {
+                const bool a = slo[t] < shi[t];
+                any = any || a;
+                mid[t] = (slo[t] + shi[t]) >> 1;
+                xv[t] = a ? sp[t][mid[t]] : 0.0;
+            }
+            if (!any) break;
+#pragma unroll
+            for (int t = 0; t < 2 * SW_KR; t++)
+                if (slo[t] < shi[t]) { if (xv[t] < dv[t]) slo[t] = mid[t] + 1; else shi[t] = mid[t]; }
+        }
+#pragma unroll
+        for (int q = 0; q < SW_KR; q++) {
+            if (q >= nq) break;
+            const int j = lane + 64 * q;
+            const int vL = nv[2 * q], vR = nv[2 * q + 1];
+            const int cL = (dv[2 * q] != dv[2 * q]) ? 0 : vL - slo[2 * q], cR = (dv[2 * q + 1] != dv[2 * q + 1]) ? 0 : vR - slo[2 * q + 1];   // bg_count_ge
+            const double p1 = (double)cL / (double)vL, p2 = (double)cR / (double)vR;
+            double p = (p2 > p1) ? p2 : p1;
+            if (p == 0.0) p = 1.0 / (double)ncolbg;
+            if (j < h) A[j] = p;
+        }
+        sw_sync();
+        double r0, r1;
+        const int k0 = (h - 1) / 2, k1 = h / 2;
+        sw_select<SW_KR>(A, h, k0, k1, lane, &r0, &r1);
+        if (lane == 0) out_p[si] = (k0 == k1) ? r0 : (r0 + r1) / 2.0;
+        sw_sync();                                               // A is reused below
+    }
+    if (DO_SC) {
+        // ---- getStripe.scoringstripes.iterate_idx (getStripe.py:661-759), as k_stripiness
+        const stp_score_stripe s = sst[si];
+        const int h = s.row1 - s.row0, nq = (h + 63) >> 6;
+        int16_t (*keepc)[SW_MAXW] = s_keepc[wv];
+        // one pixel of block b: observed / (expected + 1e-8); a masked pixel is NaN (:701-707)
+        const int cmin = min(s.col0[0], min(s.col0[1], s.col0[2]));
+        const bool tr = B.sym && (s.row1 - 1 - cmin < B.hw);            // as above, for the three blocks
+        auto obs = [&](int b, int r, int c) -> double {
+            const int64_t gr = (int64_t)s.row0 + r, gc = (int64_t)s.col0[b] + c;
+            return tr ? B.d[gc * (int64_t)B.W + (gr - gc + B.hw)] : B.d[gr * (int64_t)B.W + (gc - gr + B.hw)];
+        };
+        auto exv = [&](int b, int r, int c) -> double {
+            int ix = (s.ex0[b] + c) - (s.ey0 + r);
+            if (ix < 0) ix = -ix;
+            if (ix >= 400) ix = 399;
+            return exl[ix];
+        };
+        // columns that hold a pixel that is not NaN (:709-711)
+        unsigned long long alive[3];
+        int wb[3];
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const int w = s.col1[b] - s.col0[b];
+            wb[b] = w;
+            unsigned long long m = 0ull;
+            for (int c0 = 0; c0 < w; c0 += 4) {                  // wave-uniform; four columns' pixels requested together
+                unsigned found = 0u;
+                for (int q = 0; q < nq && found != 15u; q++) {
+                    const int r = lane + 64 * q;
+                    const bool ron = r < h && !(r >= s.mrow0 && r <= s.mrow1);
+                    double o[4], e[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int c = c0 + u;
+                        const bool con = ron && c < w && !(c >= s.mcol0[b] && c <= s.mcol1[b]);
+                        o[u] = con ? obs(b, r, c) : NAN;
+                        e[u] = con ? exv(b, r, c) : 1.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        bool al;
+                        if (e[u] > 0.0 && e[u] < INFINITY) al = (o[u] == o[u]);      // o / e is NaN exactly when o is
+                        else { const double v = o[u] / e[u]; al = (v == v); }
+                        if (__ballot(al) != 0ull) found |= 1u << u;
+                    }
+                }
+                m |= (unsigned long long)found << c0;
+            }
+            alive[b] = m;
+        }
+        // the rows dead columns delete (:713-733)
+        int status = 0;
+        bool del[SW_KR];
+#pragma unroll
+        for (int q = 0; q < SW_KR; q++) del[q] = false;
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const int w = wb[b];
+            unsigned long long dead = ~alive[b] & (w >= 64 ? ~0ull : ((1ull << w) - 1ull));
+            while (dead) {                                       // wave-uniform, rare
+                const int c = __ffsll((long long)dead) - 1;
+                dead &= dead - 1ull;
+                int rd = s.mirror ? (h - 1 - c) : c;
+                if (rd < -h || rd >= h) status = 1;              // np.delete: index out of bounds
+                if (rd < 0) rd += h;
+                if (rd >= 0 && rd < h) {
+#pragma unroll
+                    for (int q = 0; q < SW_KR; q++) del[q] = del[q] || (lane + 64 * q == rd);
+                }
+            }
+            if (lane < w && ((alive[b] >> lane) & 1ull)) keepc[b][__popcll(alive[b] & lt)] = (int16_t)lane;
+        }
+        int nkc[3];
+#pragma unroll
+        for (int b = 0; b < 3; b++) nkc[b] = __popcll(alive[b]);
+        // kept rows in order
+        int pos[SW_KR], hk = 0;
+        bool keep[SW_KR];
+#pragma unroll
+        for (int q = 0; q < SW_KR; q++) {
+            const int r = lane + 64 * q;
+            keep[q] = q < nq && r < h && !del[q];
+            const unsigned long long bal = __ballot(keep[q]);
+            pos[q] = hk + __popcll(bal & lt);
+            hk += __popcll(bal);
+        }
+        sw_sync();                                               // keepc is written
+        // row means after nantozero (:739-745), numpy's pairwise order over the kept columns
+        double loc = 0.0;
+#pragma unroll
+        for (int q = 0; q < SW_KR; q++) {
+            if (q >= nq) break;
+            if (keep[q]) {
+                const int r = lane + 64 * q;
+                const bool rmask = r >= s.mrow0 && r <= s.mrow1;
+#pragma unroll
+                for (int b = 0; b < 3; b++) {
+                    const int n = nkc[b];
+                    const bool full = n == wb[b];                // no column deleted: kept column k is column k
+                    const double sum = sw_pw_leaf([&](int64_t k) {
+                        const int c = full ? (int)k : (int)keepc[b][k];
+                        if (rmask || (c >= s.mcol0[b] && c <= s.mcol1[b])) return 0.0;
+                        const double v = obs(b, r, c) / exv(b, r, c);
+                        return (v != v) ? 0.0 : v;
+                    }, 0, n);
+                    const double mean = sum / (double)n;
+                    s_arr[wv][b][pos[q]] = mean;
+                    if (b == 0) loc += mean * (double)n;         // centerTotal (:747), a tolerance statistic
+                }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) loc += __shfl_xor(loc, o);
+        const double s_tot = loc;
+        sw_sync();
+        // Sobel-like scores (:750-756, stats.py:184-199) of rows 1 .. hk-2
+        const int nd = hk - 2 > 0 ? hk - 2 : 0;
+        double dq[SW_KR];
+#pragma unroll
+        for (int q = 0; q < SW_KR; q++) {
+            const int i = 1 + lane + 64 * q;
+            dq[q] = NAN;
+            if (q < nq && i < hk - 1) {
+                const double* cm = A; const double* lm = Bv; const double* rm = Cv;
+                double gxl = 0.0, gxr = 0.0, gy = 0.0;
+                gxl += (-1.0 * lm[i - 1] + -2.0 * lm[i]) + -1.0 * lm[i + 1];
+                gxl += (1.0 * cm[i - 1] + 2.0 * cm[i]) + 1.0 * cm[i + 1];
+                gxr += (1.0 * cm[i - 1] + 2.0 * cm[i]) + 1.0 * cm[i + 1];
+                gxr += (-1.0 * rm[i - 1] + -2.0 * rm[i]) + -1.0 * rm[i + 1];
+                gy += (1.0 * lm[i - 1] + 0.0 * lm[i]) + -1.0 * lm[i + 1];
+                gy += (2.0 * cm[i - 1] + 0.0 * cm[i]) + -2.0 * cm[i + 1];
+                gy += (1.0 * rm[i - 1] + 0.0 * rm[i]) + -1.0 * rm[i + 1];
+                if (gy < 0) gy *= -1;
+                double gx = (gxl < gxr || gxl != gxl) ? gxl : gxr;           // np.minimum (NaN propagates)
+                if (gxr != gxr) gx = gxr;
+                dq[q] = gx - gy;
+            }
+        }
+        sw_sync();                                               // everybody has read the flank means: Bv takes the differences
+        // diff = [x for x in diff if x >= 0 or x < 0], in order (:757)
+        int ndk = 0;
+#pragma unroll
+        for (int q = 0; q < SW_KR; q++) {
+            const int t = lane + 64 * q;
+            const bool kp = q < nq && t < nd && dq[q] == dq[q];
+            const unsigned long long bal = __ballot(kp);
+            if (kp) Bv[ndk + __popcll(bal & lt)] = dq[q];
+            ndk += __popcll(bal);
+        }
+        // np.nanmedian(centerm): the order statistics of the values that are not NaN
+        int nm = 0;
+#pragma unroll
+        for (int q = 0; q < SW_KR; q++) {
+            const int j = lane + 64 * q;
+            const double v = (q < nq && j < hk) ? A[j] : NAN;
+            nm += __popcll(__ballot(v == v));
+        }
+        sw_sync();
+        double med = NAN;
+        if (nm > 0) {
+            double r0, r1;
+            const int k0 = (nm - 1) / 2, k1 = nm / 2;
+            sw_select<SW_KR>(A, hk, k0, k1, lane, &r0, &r1);
+            med = (k0 == k1) ? r0 : (r0 + r1) / 2.0;
+        }
+        const double sum = sw_pw_sum(Bv, ndk, lane, s_scr[wv]);
+        if (lane == 0) {
+            const double avg = sum / (double)ndk;
+            out_g[si] = med * avg;
+            const int nc = nkc[0];
+            out_total[si] = (nc == 0) ? 0.0 : s_tot * (double)nc;
+            out_mean[si] = (nc == 0) ? NAN : (s_tot * (double)nc) / ((double)hk * nc * nc);
+            if (out_status) out_status[si] = status;
+        }
     }
 }
 

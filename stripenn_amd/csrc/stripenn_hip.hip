@@ -856,6 +856,9 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     // reduces the cells of images w and w + 4 (both cell loads of a lane in flight together), the verdicts meet in LDS
     int* sFlat = (int*)(sG + C32_NBMAX);
     {
+        // (interior tiles -- every window inside the image -- may call a wider range flat: c32_flat_interior)
+        const float flat_thr = ((T.ty0 - R - 2 >= 0) && (T.ty0 + CT_Y + R + 1 < S) && (T.tx0 - 2 - R >= 0) && (T.tx0 + CT_X + 1 + R < S))
+                                   ? W32.flat_int : STP_FLAT_RANGE;
         const int wy0 = max(T.ty0 - R - 2, 0), wy1 = min(T.ty0 + CT_Y + R + 2, S);
         const int wx0 = max(T.tx0 - R - 2, 0), wx1 = min(T.tx0 + CT_X + R + 2, S);
         const int r0 = wy0 / GC_CY, nr = (wy1 - 1) / GC_CY - r0 + 1, c0 = wx0 / GC_CX, nc = (wx1 - 1) / GC_CX - c0 + 1;
@@ -878,7 +881,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
                 for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
                 if (lane == 0 && bi < C32_NBMAX) {
                     sG[bi] = mx;
-                    sFlat[bi] = (bi < nb && mx - mn < STP_FLAT_RANGE) ? 1 : 0;   // flat window: no pixel of this tile can reach the
+                    sFlat[bi] = (bi < nb && mx - mn < flat_thr) ? 1 : 0;          // flat window: no pixel of this tile can reach the
                                                                                 // low threshold (its class words stay 0)
                 }
             }
@@ -1043,20 +1046,63 @@ struct stp_drec {
 // 64 x 64 bit-block transpose across a wave: lane L holds row L (bit c = column c); afterwards lane L
 // holds column L (bit r = row r).  Recursive block swap: at block size j the off-diagonal j x j
 // sub-blocks of every 2j x 2j block are exchanged between lanes L and L ^ j.
+// Round 5: no LDS traffic (rounds 1-4 fetched the partner's words with ds_bpermute: 12 per transpose, 252 sites in
+// k_lines).  The exchange of stage 32 IS v_permlane32_swap on the (low word, high word) pair -- lanes 0..31 hand their
+// high word to lanes 32..63 and take those lanes' low word; stage 16 takes the partner row's word by v_permlane16_swap and
+// merges half-words with one v_perm_b32 whose selector depends on the lane's side; stages 8 .. 1 stay inside a row of 16
+// lanes: the partner's word arrives by a DPP move (row_ror:8, row_shl:4 / row_shr:4 by bank, quad_perm), stage 8 merges bytes by
+// v_perm_b32, stages 4 .. 1 rotate the partner's word into place (v_alignbit_b32) and insert it under a mask (v_bfi_b32).
+__device__ __forceinline__ unsigned wt_dpp_xor8(unsigned w) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x128, 0xF, 0xF, false); }   // row_ror:8
+__device__ __forceinline__ unsigned wt_dpp_xor4(unsigned w)
+{
+    int p = __builtin_amdgcn_update_dpp(0, (int)w, 0x104, 0xF, 0x5, false);         // row_shl:4 -> banks 0, 2 (lane bit 2 clear) read lane + 4
+    return (unsigned)__builtin_amdgcn_update_dpp(p, (int)w, 0x114, 0xF, 0xA, false);  // row_shr:4 -> banks 1, 3 read lane - 4
+}
+__device__ __forceinline__ unsigned wt_dpp_xor2(unsigned w) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xF, 0xF, false); }    // quad_perm:[2,3,0,1]
+__device__ __forceinline__ unsigned wt_dpp_xor1(unsigned w) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, false); }    // quad_perm:[1,0,3,2]
+// one word of a stage j <= 4: lanes with bit j clear keep their bits under m and take the partner's bits under m, moved up
+// by j; lanes with the bit set keep their bits under m << j (= ~m) and take the partner's bits under ~m, moved down by j
+__device__ __forceinline__ unsigned wt_bits(unsigned w, unsigned p, unsigned rot /* 32 - j | j */, unsigned ins /* ~m | m */)
+{
+    const unsigned r = __builtin_amdgcn_alignbit(p, p, rot);                         // rotate right by rot
+    return (ins & r) | (~ins & w);                                                    // v_bfi_b32
+}
 __device__ __forceinline__ stp_u64 wave_transpose64(stp_u64 x, int lane)
 {
-    const stp_u64 masks[6] = {0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
-                              0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
-#pragma unroll
-    for (int s = 0; s < 6; s++) {
-        const int j = 32 >> s;
-        const stp_u64 m = masks[s];
-        const unsigned lo = __shfl_xor((unsigned)x, j), hi = __shfl_xor((unsigned)(x >> 32), j);
-        const stp_u64 p = ((stp_u64)hi << 32) | lo;
-        if ((lane & j) == 0) { const stp_u64 t = ((x >> j) ^ p) & m; x ^= (t << j); }
-        else { const stp_u64 t = ((p >> j) ^ x) & m; x ^= t; }
+    unsigned lo = (unsigned)x, hi = (unsigned)(x >> 32);
+    {   // j = 32: lanes 0..31: (lo, partner lo); lanes 32..63: (partner hi, hi)
+        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);        // lo's lanes 32..63 <-> hi's lanes 0..31
+        lo = r[0]; hi = r[1];
     }
-    return x;
+    {   // j = 16: even rows: low half-word own, high half-word = partner's low; odd rows: low = partner's high, high own
+        const bool odd = (lane & 16) != 0;
+        const unsigned sel = odd ? 0x07060302u : 0x05040100u;
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);        // even rows: (own, partner); odd rows: (partner, own)
+        lo = __builtin_amdgcn_perm(a[1], a[0], sel);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        hi = __builtin_amdgcn_perm(b[1], b[0], sel);
+    }
+    {   // j = 8: bytes.  clear: (own b0, partner b0, own b2, partner b2); set: (partner b1, own b1, partner b3, own b3)
+        const unsigned sel = (lane & 8) ? 0x03070105u : 0x06020400u;                  // v_perm_b32(S0 = partner: bytes 4..7, S1 = own: 0..3)
+        lo = __builtin_amdgcn_perm(wt_dpp_xor8(lo), lo, sel);
+        hi = __builtin_amdgcn_perm(wt_dpp_xor8(hi), hi, sel);
+    }
+    {
+        const bool set = (lane & 4) != 0;
+        const unsigned rot = set ? 4u : 28u, ins = set ? 0x0F0F0F0Fu : 0xF0F0F0F0u;
+        lo = wt_bits(lo, wt_dpp_xor4(lo), rot, ins); hi = wt_bits(hi, wt_dpp_xor4(hi), rot, ins);
+    }
+    {
+        const bool set = (lane & 2) != 0;
+        const unsigned rot = set ? 2u : 30u, ins = set ? 0x33333333u : 0xCCCCCCCCu;
+        lo = wt_bits(lo, wt_dpp_xor2(lo), rot, ins); hi = wt_bits(hi, wt_dpp_xor2(hi), rot, ins);
+    }
+    {
+        const bool set = (lane & 1) != 0;
+        const unsigned rot = set ? 1u : 31u, ins = set ? 0x55555555u : 0xAAAAAAAAu;
+        lo = wt_bits(lo, wt_dpp_xor1(lo), rot, ins); hi = wt_bits(hi, wt_dpp_xor1(hi), rot, ins);
+    }
+    return ((stp_u64)hi << 32) | lo;
 }
 // column (64 * cg + lane) of a row-major bit matrix as 7 words, all 64 lanes of the wave cooperating
 __device__ __forceinline__ void wave_load_cols(const stp_u64* m, int S, int cg, int lane, stp_u64* col)
@@ -1582,6 +1628,8 @@ struct stp_band {
     int hw = 0, W = 0;
     bool owned = false;
     int32_t* near = nullptr;   // 2 x nrows nearest-positive-pixel distances (bands built by stp_band_pack only)
+    mutable int sym = -1;      // -1 not checked yet, 0 / 1: k_band_symcheck's verdict (the score kernels' coalesced reads).  A band
+                               // wrapped around the caller's device memory must not be modified while its handle lives.
 };
 
 struct stp_frames {
@@ -2834,7 +2882,25 @@ int stp_dbg_canny_f32(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
     return STP_OK;
 }
 
-static stp_bandref bref(const stp_band* b) { return stp_bandref{b->d, b->nrows, b->W, b->hw}; }
+static stp_bandref bref(const stp_band* b) { return stp_bandref{b->d, b->nrows, b->W, b->hw, 0}; }
+// the band's symmetry verdict, established on first use (one pass over the band on the auxiliary stream, one word back)
+static int band_symmetric(stp_ctx* ctx, const stp_band* b, int* out)
+{
+    if (b->sym < 0) {
+        dev_buf f;
+        HIPCHK(f.alloc(ctx, sizeof(int)));
+        HIPCHK(hipMemsetAsync(f.p, 0, sizeof(int), ctx->aux));
+        if (b->hw > 1)
+            hipLaunchKernelGGL(k_band_symcheck, dim3(256 * 16), dim3(256), 0, ctx->aux, b->d, b->nrows, b->W, b->hw, (int*)f.p);
+        HIPCHK(hipGetLastError());
+        int asym = 1;
+        HIPCHK(hipMemcpyAsync(&asym, f.p, sizeof(int), hipMemcpyDeviceToHost, ctx->aux));
+        HIPCHK(hipStreamSynchronize(ctx->aux));
+        b->sym = asym ? 0 : 1;
+    }
+    *out = b->sym;
+    return STP_OK;
+}
 
 int stp_diag_sums(stp_ctx* ctx, const stp_band* band, double* part_sum, int64_t* part_cnt, int32_t n400)
 {
@@ -2962,106 +3028,181 @@ static int check_rect(stp_ctx* ctx, const stp_band* band, int64_t i, int r0, int
     return STP_OK;
 }
 
+// p-value and / or Stripiness of n stripes: ONE upload, one launch of k_score_wave over the stripes its wave form takes
+// (plus the block kernels over the rest, through index lists), one download.  pst / sst: either may be null.
+static int run_score(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int32_t bs, const double* exval400,
+                     const stp_pv_stripe* pst, const stp_score_stripe* sst, int64_t n, double* out_p, double* out_g, double* out_mean,
+                     double* out_total, int32_t* out_status)
+{
+    if (n == 0) return STP_OK;
+    if (n > 0x7FFFFFF0ll) return set_err(ctx, STP_E_UNSUPPORTED, "more than 2^31 stripes in one call");
+    for (int64_t i = 0; i < n; i++) {
+        if (pst) {
+            int rc = check_rect(ctx, band, i, pst[i].row0, pst[i].row1, pst[i].col0, pst[i].col1, STP_SCORE_MAXROWS, 1 << 20);
+            if (rc) return rc;
+            if (pst[i].mode < 0 || pst[i].mode > 2 || (pst[i].mode == 2 && (pst[i].fixed_row < 0 || pst[i].fixed_row >= STP_NDIAG)))
+                return set_err(ctx, STP_E_ARG, "stripe " + std::to_string(i) + ": bad direction mode");
+        }
+        if (sst)
+            for (int b = 0; b < 3; b++) {
+                int rc = check_rect(ctx, band, i, sst[i].row0, sst[i].row1, sst[i].col0[b], sst[i].col1[b], STP_SCORE_MAXROWS,
+                                    STP_SCORE_MAXCOLS);
+                if (rc) return rc;
+            }
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    // which stripes the wave form takes (STP_SCORE=block: none -- the tests compare the two forms)
+    const char* env = getenv("STP_SCORE");
+    const bool all_block = env && strcmp(env, "block") == 0;
+    std::vector<int> small, tall, big;                                    // wave form (<= 128 rows), wave form (<= 256 rows), block kernels
+    double bytes_pv = 0, bytes_sc = 0;
+    for (int64_t i = 0; i < n; i++) {
+        bool ok = !all_block;
+        int h = 0;
+        if (pst) {
+            const int w = pst[i].col1 - pst[i].col0;
+            h = pst[i].row1 - pst[i].row0;
+            ok = ok && w <= 128 && bs <= 128;                            // every row sum is one pairwise leaf
+            bytes_pv += (8.0 * w + 16000.0) * h;
+        }
+        if (sst) {
+            h = std::max(h, (int)(sst[i].row1 - sst[i].row0));
+            for (int b = 0; b < 3; b++) {
+                ok = ok && (sst[i].col1[b] - sst[i].col0[b]) <= SW_MAXW;
+                bytes_sc += 8.0 * (sst[i].col1[b] - sst[i].col0[b]) * (sst[i].row1 - sst[i].row0);
+            }
+        }
+        (!ok || h > SW_MAXH ? big : (h > 64 * SW_KR_SHORT ? tall : small)).push_back((int)i);
+    }
+    dev_buf bP, bS, bE, bO, bI;
+    if (pst) HIPCHK(bP.alloc(ctx, (size_t)n * sizeof(stp_pv_stripe)));
+    if (sst) HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_score_stripe)));
+    if (sst) HIPCHK(bE.alloc(ctx, STP_NDIAG * sizeof(double)));
+    HIPCHK(bO.alloc(ctx, (size_t)n * 4 * sizeof(double) + (size_t)n * sizeof(int)));
+    const bool need_idx = small.size() != (size_t)n;                     // (everything in one wave launch: no list, stripes in order)
+    if (need_idx) HIPCHK(bI.alloc(ctx, (size_t)n * sizeof(int)));
+    stp_xfer x(ctx, ctx->aux);
+    if (pst) HIPCHK(x.h2d(bP.p, pst, (size_t)n * sizeof(stp_pv_stripe)));
+    if (sst) HIPCHK(x.h2d(bS.p, sst, (size_t)n * sizeof(stp_score_stripe)));
+    if (sst) HIPCHK(x.h2d(bE.p, exval400, STP_NDIAG * sizeof(double)));
+    int *d_small = nullptr, *d_tall = nullptr, *d_big = nullptr;
+    if (need_idx) {
+        std::vector<int> all(small);
+        all.insert(all.end(), tall.begin(), tall.end());
+        all.insert(all.end(), big.begin(), big.end());
+        d_small = (int*)bI.p; d_tall = d_small + small.size(); d_big = d_tall + tall.size();
+        HIPCHK(x.h2d(d_small, all.data(), all.size() * sizeof(int)));     // (staged: `all` may go out of scope)
+    }
+    double* o = (double*)bO.p;                                           // p | g | mean | total | status
+    double* o_p = o; double* o_g = o + n; double* o_m = o + 2 * n; double* o_t = o + 3 * n;
+    int* o_s = (int*)(o + 4 * n);
+    stp_bandref br = bref(band);
+    {
+        const char* e2 = getenv("STP_SCORE_NOSYM");                      // (measurement hook: row-strided reads even in a symmetric band)
+        if (!(e2 && e2[0] == '1')) { int rcs = band_symmetric(ctx, band, &br.sym); if (rcs) return rcs; }
+    }
+    const double* d_srt = bg ? (const double*)bg->sorted : nullptr;
+    const int* d_nv = bg ? (const int*)bg->nvalid : nullptr;
+    const int ncolbg = bg ? bg->ncol : 0;
+    const char* scope = (pst && sst) ? "score" : (pst ? "pvalue" : "stripiness");
+    for (int cls = 0; cls < 2; cls++) {
+        const std::vector<int>& L = cls ? tall : small;
+        if (L.empty()) continue;
+        const int* d_idx = need_idx ? (cls ? d_tall : d_small) : nullptr;
+        const unsigned grid = (unsigned)((L.size() + SW_WAVES - 1) / SW_WAVES);
+        const double frac = (double)L.size() / (double)n;
+        prof_scope ps(ctx, scope, ((pst ? bytes_pv : 0.0) + (sst ? bytes_sc : 0.0)) * frac, ctx->aux);
+#define STP_SW_LAUNCH(PV, SC, KR)                                                                                                      \
+        hipLaunchKernelGGL((k_score_wave<PV, SC, KR>), dim3(grid), dim3(64 * SW_WAVES), 0, ctx->aux, br, d_idx, (int)L.size(), bs, d_srt, d_nv, ncolbg, \
+                           (const stp_pv_stripe*)bP.p, o_p, (const double*)bE.p, (const stp_score_stripe*)bS.p, o_g, o_m, o_t, o_s)
+        if (pst && sst) { if (cls) STP_SW_LAUNCH(true, true, SW_KR_TALL); else STP_SW_LAUNCH(true, true, SW_KR_SHORT); }
+        else if (pst) { if (cls) STP_SW_LAUNCH(true, false, SW_KR_TALL); else STP_SW_LAUNCH(true, false, SW_KR_SHORT); }
+        else { if (cls) STP_SW_LAUNCH(false, true, SW_KR_TALL); else STP_SW_LAUNCH(false, true, SW_KR_SHORT); }
+#undef STP_SW_LAUNCH
+        HIPCHK(hipGetLastError());
+    }
+    if (!big.empty()) {
+        const double frac = (double)big.size() / (double)n;
+        if (pst) {
+            prof_scope ps(ctx, (small.empty() && tall.empty()) ? "pvalue" : "pvalue_block", bytes_pv * frac, ctx->aux);
+            bool bigsum = bs > 128;
+            int hmax = 1;
+            for (int i : big) {
+                bigsum = bigsum || (pst[i].col1 - pst[i].col0) > 128;
+                hmax = std::max(hmax, (int)(pst[i].row1 - pst[i].row0));
+            }
+            const size_t lds = 4 * sizeof(double) * (size_t)hmax;
+            if (lds > 48 * 1024) {      // stripes beyond ~1500 rows: more dynamic LDS than the default launch limit
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pvalue<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pvalue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+            if (!bigsum)
+                hipLaunchKernelGGL(k_pvalue<false>, dim3((unsigned)big.size()), dim3(STP_PV_NT), lds, ctx->aux, bref(band), d_srt, d_nv, ncolbg, bs,
+                                   (const stp_pv_stripe*)bP.p, o_p, hmax, (const int*)d_big);
+            else
+                hipLaunchKernelGGL(k_pvalue<true>, dim3((unsigned)big.size()), dim3(STP_PV_NT), lds, ctx->aux, bref(band), d_srt, d_nv, ncolbg, bs,
+                                   (const stp_pv_stripe*)bP.p, o_p, hmax, (const int*)d_big);
+            HIPCHK(hipGetLastError());
+        }
+        if (sst) {
+            prof_scope ps(ctx, (small.empty() && tall.empty()) ? "stripiness" : "stripiness_block", bytes_sc * frac, ctx->aux);
+            bool bigsum = false;
+            int hmax = 1, wmax = 1;
+            for (int i : big) {
+                hmax = std::max(hmax, (int)(sst[i].row1 - sst[i].row0));
+                for (int b = 0; b < 3; b++) {
+                    wmax = std::max(wmax, (int)(sst[i].col1[b] - sst[i].col0[b]));
+                    bigsum = bigsum || (sst[i].col1[b] - sst[i].col0[b]) > 128;
+                }
+            }
+            const int HR = (hmax + 3) & ~3, CW = (wmax + 3) & ~3;     // keeps every sub-array 8-byte aligned
+            const size_t lds = sizeof(double) * (STP_NDIAG + 3 * (size_t)HR + std::max(HR, 256)) +
+                               sizeof(int16_t) * ((size_t)HR + 3 * (size_t)CW) + (size_t)HR;
+            if (lds > 48 * 1024) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stripiness<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stripiness<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+            if (!bigsum)
+                hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)big.size()), dim3(STP_SC_NT), lds, ctx->aux, bref(band), (const double*)bE.p,
+                                   (const stp_score_stripe*)bS.p, o_g, o_m, o_t, o_s, HR, CW, (const int*)d_big);
+            else
+                hipLaunchKernelGGL(k_stripiness<true>, dim3((unsigned)big.size()), dim3(STP_SC_NT), lds, ctx->aux, bref(band), (const double*)bE.p,
+                                   (const stp_score_stripe*)bS.p, o_g, o_m, o_t, o_s, HR, CW, (const int*)d_big);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    if (pst) HIPCHK(x.d2h(out_p, o_p, (size_t)n * sizeof(double)));
+    if (sst) {
+        HIPCHK(x.d2h(out_g, o_g, (size_t)n * sizeof(double)));
+        HIPCHK(x.d2h(out_mean, o_m, (size_t)n * sizeof(double)));
+        HIPCHK(x.d2h(out_total, o_t, (size_t)n * sizeof(double)));
+        if (out_status) HIPCHK(x.d2h(out_status, o_s, (size_t)n * sizeof(int)));
+    }
+    HIPCHK(x.finish());
+    return STP_OK;
+}
+
 int stp_pvalue(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int32_t bs, const stp_pv_stripe* st, int64_t n,
                double* out_p)
 {
     if (!ctx || !band || !bg || !st || !out_p || n < 0 || bs < 1) return STP_E_ARG;
-    if (n == 0) return STP_OK;
-    for (int64_t i = 0; i < n; i++) {
-        int rc = check_rect(ctx, band, i, st[i].row0, st[i].row1, st[i].col0, st[i].col1, STP_SCORE_MAXROWS, 1 << 20);
-        if (rc) return rc;
-        if (st[i].mode < 0 || st[i].mode > 2 || (st[i].mode == 2 && (st[i].fixed_row < 0 || st[i].fixed_row >= STP_NDIAG)))
-            return set_err(ctx, STP_E_ARG, "stripe " + std::to_string(i) + ": bad direction mode");
-    }
-    HIPCHK(hipSetDevice(ctx->device));
-    dev_buf bS, bO;
-    HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_pv_stripe)));
-    HIPCHK(bO.alloc(ctx, (size_t)n * sizeof(double)));
-    stp_xfer x(ctx, ctx->aux);
-    HIPCHK(x.h2d(bS.p, st, (size_t)n * sizeof(stp_pv_stripe)));
-    {
-        double bytes = 0;
-        for (int64_t i = 0; i < n; i++) bytes += (8.0 * (st[i].col1 - st[i].col0) + 16000.0) * (st[i].row1 - st[i].row0);
-        prof_scope ps(ctx, "pvalue", bytes, ctx->aux);
-        bool big = bs > 128;
-        int hmax = 1;
-        for (int64_t i = 0; i < n; i++) {
-            big = big || (st[i].col1 - st[i].col0) > 128;
-            hmax = std::max(hmax, (int)(st[i].row1 - st[i].row0));
-        }
-        const size_t lds = 4 * sizeof(double) * (size_t)hmax;
-        if (lds > 48 * 1024) {      // stripes beyond ~1500 rows: more dynamic LDS than the default launch limit
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pvalue<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pvalue<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
-        if (!big)
-            hipLaunchKernelGGL(k_pvalue<false>, dim3((unsigned)n), dim3(STP_PV_NT), lds, ctx->aux, bref(band), (const double*)bg->sorted,
-                               (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p, hmax);
-        else
-            hipLaunchKernelGGL(k_pvalue<true>, dim3((unsigned)n), dim3(STP_PV_NT), lds, ctx->aux, bref(band), (const double*)bg->sorted,
-                               (const int*)bg->nvalid, bg->ncol, bs, (const stp_pv_stripe*)bS.p, (double*)bO.p, hmax);
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(x.d2h(out_p, bO.p, (size_t)n * sizeof(double)));
-    HIPCHK(x.finish());
-    return STP_OK;
+    return run_score(ctx, band, bg, bs, nullptr, st, nullptr, n, out_p, nullptr, nullptr, nullptr, nullptr);
 }
 
 int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, const stp_score_stripe* st, int64_t n,
                    double* out_g, double* out_mean, double* out_total, int32_t* out_status)
 {
     if (!ctx || !band || !exval400 || !st || !out_g || !out_mean || !out_total || n < 0) return STP_E_ARG;
-    if (n == 0) return STP_OK;
-    for (int64_t i = 0; i < n; i++)
-        for (int b = 0; b < 3; b++) {
-            int rc = check_rect(ctx, band, i, st[i].row0, st[i].row1, st[i].col0[b], st[i].col1[b], STP_SCORE_MAXROWS,
-                                STP_SCORE_MAXCOLS);
-            if (rc) return rc;
-        }
-    HIPCHK(hipSetDevice(ctx->device));
-    dev_buf bS, bE, bO;
-    HIPCHK(bS.alloc(ctx, (size_t)n * sizeof(stp_score_stripe)));
-    HIPCHK(bE.alloc(ctx, STP_NDIAG * sizeof(double)));
-    HIPCHK(bO.alloc(ctx, (size_t)n * 3 * sizeof(double) + (size_t)n * sizeof(int)));
-    stp_xfer x(ctx, ctx->aux);
-    HIPCHK(x.h2d(bS.p, st, (size_t)n * sizeof(stp_score_stripe)));
-    HIPCHK(x.h2d(bE.p, exval400, STP_NDIAG * sizeof(double)));
-    double* o = (double*)bO.p;
-    {
-        double bytes = 0;
-        for (int64_t i = 0; i < n; i++)
-            for (int b = 0; b < 3; b++) bytes += 8.0 * (st[i].col1[b] - st[i].col0[b]) * (st[i].row1 - st[i].row0);
-        prof_scope ps(ctx, "stripiness", bytes, ctx->aux);
-        bool big = false;
-        int hmax = 1, wmax = 1;
-        for (int64_t i = 0; i < n; i++) {
-            hmax = std::max(hmax, (int)(st[i].row1 - st[i].row0));
-            for (int b = 0; b < 3; b++) {
-                wmax = std::max(wmax, (int)(st[i].col1[b] - st[i].col0[b]));
-                big = big || (st[i].col1[b] - st[i].col0[b]) > 128;
-            }
-        }
-        const int HR = (hmax + 3) & ~3, CW = (wmax + 3) & ~3;     // keeps every sub-array 8-byte aligned
-        const size_t lds = sizeof(double) * (STP_NDIAG + 3 * (size_t)HR + std::max(HR, 256)) +
-                           sizeof(int16_t) * ((size_t)HR + 3 * (size_t)CW) + (size_t)HR;
-        if (lds > 48 * 1024) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stripiness<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_stripiness<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        }
-        if (!big)
-            hipLaunchKernelGGL(k_stripiness<false>, dim3((unsigned)n), dim3(STP_SC_NT), lds, ctx->aux, bref(band), (const double*)bE.p,
-                               (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n), HR, CW);
-        else
-            hipLaunchKernelGGL(k_stripiness<true>, dim3((unsigned)n), dim3(STP_SC_NT), lds, ctx->aux, bref(band), (const double*)bE.p,
-                               (const stp_score_stripe*)bS.p, o, o + n, o + 2 * n, (int*)(o + 3 * n), HR, CW);
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(x.d2h(out_g, o, (size_t)n * sizeof(double)));
-    HIPCHK(x.d2h(out_mean, o + n, (size_t)n * sizeof(double)));
-    HIPCHK(x.d2h(out_total, o + 2 * n, (size_t)n * sizeof(double)));
-    if (out_status) HIPCHK(x.d2h(out_status, o + 3 * n, (size_t)n * sizeof(int)));
-    HIPCHK(x.finish());
-    return STP_OK;
+    return run_score(ctx, band, nullptr, 1, exval400, nullptr, st, n, nullptr, out_g, out_mean, out_total, out_status);
+}
+
+int stp_score(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int32_t bs, const double* exval400,
+              const stp_pv_stripe* pv_stripes, const stp_score_stripe* sc_stripes, int64_t n, double* out_p, double* out_g,
+              double* out_mean, double* out_total, int32_t* out_status)
+{
+    if (!ctx || !band || !bg || !exval400 || !pv_stripes || !sc_stripes || !out_p || !out_g || !out_mean || !out_total || n < 0 || bs < 1)
+        return STP_E_ARG;
+    return run_score(ctx, band, bg, bs, exval400, pv_stripes, sc_stripes, n, out_p, out_g, out_mean, out_total, out_status);
 }
 
 int stp_stripe_mean(stp_ctx* ctx, const stp_band* band, const stp_rect* rc, int64_t n, double* out_mean, double* out_sum)

@@ -254,7 +254,9 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
                 float mn = INFINITY, mx = -INFINITY;
                 for (int y = Y0; y < Y1; y++)
                     for (int x = X0; x < X1; x++) { const float v = gray[y * STP_PITCH + x]; mn = std::min(mn, v); mx = std::max(mx, v); }
-                if (mx - mn < STP_FLAT_RANGE) continue;
+                // (k_canny_f32 calls a wider range flat in tiles whose every window lies inside the image: c32_flat_interior)
+                const bool interior = (ty0 - R - 2 >= 0) && (ty0 + CT_Y + R + 1 < S) && (tx0 - 2 - R >= 0) && (tx0 + CT_X + 1 + R < S);
+                if (mx - mn < ((blocked == 2 && interior) ? c32_flat_interior(w, R) : STP_FLAT_RANGE)) continue;
                 gmax = mx;
             }
             canny_p0(0, 1, gray, T, R, sG.data());

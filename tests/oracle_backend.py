@@ -114,6 +114,9 @@ class OracleBackend:
                                       int(s['mode']), int(s['upbase']), int(s['fixed_row']), int(s['fixed_tab']), self.bg)
                          for s in stripes])
 
+    def score(self, band, bs, exval, pv_stripes, sc_stripes):
+        return (self.pvalue(band, bs, pv_stripes),) + tuple(self.stripiness(band, exval, sc_stripes))
+
     def stripiness(self, band, exval, stripes):
         g, m, t = [], [], []
         for s in stripes:

@@ -367,3 +367,33 @@ def test_tile_wide_budget_constants(emu, sigma):
         assert eg <= out[3 * t] <= eg * 1.001
         assert out[3 * t + 1] >= 1.41421 * out[3 * t] + 17.6 and out[3 * t + 2] >= 2 * out[3 * t + 1] + 17.0
     assert out[0] < out[3] <= out[6] and out[3] < 234.0
+
+
+@pytest.mark.parametrize('sigma,key', [(2.0, 'gw_2p0'), (2.5, 'gw_2p5')])
+def test_interior_flat_window_threshold(emu, golden_stages, sigma, key):
+    """c32_flat_interior (stp_canny32.h): in tiles whose every window lies inside the image a grey range below
+    0.0849 / (5.657 (v_0 + v_1)) keeps every magnitude below 0.085.  Worst cases for the bound -- two-level images whose
+    amplitude is just under the threshold: steps, corners, checkers of every period, random two-level noise -- must give
+    NO class in the oracle (the magnitudes themselves are checked against 0.085), and the replay must equal the oracle on
+    them and on the same patterns just above the threshold (where the tile is not skipped)."""
+    gw = np.ascontiguousarray(golden_stages[key], dtype=np.float64)
+    R = (len(gw) - 1) // 2
+    v01 = (gw[R] + gw[R - 1]) / gw.sum()
+    thr = 0.0849 / (5.65686 * v01) - 1e-5
+    assert thr > 0.039                      # sigma 2.0: 0.0400, sigma 2.5: 0.0489 (STP_FLAT_RANGE is 0.015)
+    S = 400
+    yy, xx = np.mgrid[0:S, 0:S]
+    rng = np.random.default_rng(17)
+    pats = [(xx > 200), (xx > 200) ^ (yy > 200), (xx + yy > 400), ((xx // 3) + (yy // 3)) % 2 == 0, (xx // R) % 2 == 0,
+            ((xx // (R + 1)) + (yy // (R + 1))) % 2 == 0, rng.random((S, S)) < 0.5, (xx - 200) ** 2 + (yy - 200) ** 2 < 90 ** 2]
+    for pi, pat in enumerate(pats):
+        for base in (0.0, 0.5, 1.0 - thr):
+            for amp, flat in ((thr * 0.9995, True), (thr * 1.3, False)):
+                img = np.ascontiguousarray(np.clip(base + amp * pat, 0, 1), dtype=np.float32)
+                oe, dbg = O.canny(img, gw, R, debug=True)
+                if flat:
+                    inner = dbg['mag'][R + 2:S - R - 2, R + 2:S - R - 2]        # pixels whose windows lie inside the image
+                    assert float(inner.max()) < 0.085, (pi, base, float(inner.max()))
+                cls32, _ = _canny_f32(emu, img, S, R, gw)
+                assert np.array_equal(cls32, dbg['cls']), 'pattern %d base %.2f amp %.4f: %d pixels differ' % (
+                    pi, base, amp, int((cls32 != dbg['cls']).sum()))

@@ -32,8 +32,15 @@ for _ in range(rep):
 for _ in range(rep):
     for ci, pv, sc in jobs:
         hb.stripiness(W.bands[names[ci]], W.EV[ci], sc)
+for _ in range(rep):
+    for ci, pv, sc in jobs:
+        hb.score(W.bands[names[ci]], W.bs, W.EV[ci], pv, sc)
+h = np.concatenate([j[1]['row1'] - j[1]['row0'] for j in jobs])
+print('stripes: h median %d, p90 %d, max %d; %.1f %% above 192 rows (block kernels)' % (np.median(h), np.percentile(h, 90), h.max(), 100.0 * (h > 192).mean()))
 st = W.stats()
-for k in ('pvalue', 'stripiness'):
+for k in ('pvalue', 'stripiness', 'score', 'pvalue_block', 'stripiness_block'):
+    if k not in st:
+        continue
     v = st[k]
     print('%-10s %6.3f ms per launch, %5.2f us per 100 stripes (%d launches, %d stripes per pass of %d units)'
           % (k, v['ms'] / v['launches'], v['ms'] * 1e3 / (rep * nst) * 100, v['launches'], nst, len(jobs)))
