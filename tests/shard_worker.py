@@ -49,3 +49,9 @@ def run(rank, world, port, outdir, numcores=2):
                                 a['bfilter'], a['seed'], force=True, backend_factory=_factory, write=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _factory_hip_device0(rank):
+    """every rank on device 0 with the HIP backend (tools/rehearse_pool_hip.py: the multi-process driver on a one-GPU box)"""
+    from stripenn_amd.backend import HipBackend
+    return HipBackend(0)
