@@ -27,6 +27,10 @@ typedef unsigned long long stp_u64;
 #define STP_NW 7      /* u64 words per bit-row (448 >= 400) */
 #define STP_RCAP 128  /* record slots per image in the sweep */
 #define STP_RCAP_MAX 400  /* slots of the re-run: neighbouring X values pair at most once per direction -> < 400 records */
+/* Class bit-planes of an image in global memory (Canny kernels -> k_lines): word w of row y.  Word-column-major since round 5:
+   a Canny tile owns ONE word column over 32 rows, so its 32 words are 256 contiguous bytes (row-major they lay 56 bytes
+   apart: one sector write per word, WRITE_SIZE 3.2x the payload); k_lines' loader reads a column with consecutive lanes. */
+#define STP_CLS(y, w) ((w) * STP_FRAME_MAX + (y))
 
 // ---------------------------------------------------------------------------------------------
 // tile geometry
@@ -969,8 +973,8 @@ STP_HD void canny_p5(int tid, int nt, stp_tile T, const uint8_t* sC, stp_u64* __
             lo |= (stp_u64)(c >= 1) << xx;
             hi |= (stp_u64)(c == 2) << xx;
         }
-        low_img[y * STP_NW + (T.tx0 >> 6)] = lo;
-        high_img[y * STP_NW + (T.tx0 >> 6)] = hi;
+        low_img[STP_CLS(y, T.tx0 >> 6)] = lo;
+        high_img[STP_CLS(y, T.tx0 >> 6)] = hi;
     }
 }
 
@@ -1024,11 +1028,11 @@ STP_HD void lines_load(int tid, int nt, int S, const stp_u64* __restrict__ low_i
                        const stp_u64* __restrict__ high_img, stp_u64* sLow, stp_u64* sE)
 {
     const int nwu = (S + 63) >> 6;
-    for (int i = tid; i < S * STP_NW; i += nt) {
-        int w = i % STP_NW;
+    for (int i = tid; i < S * STP_NW; i += nt) {         // consecutive lanes: consecutive rows of one word column (STP_CLS)
+        const int w = i / S, r = i - w * S;
         stp_u64 lo = 0, hi = 0;
-        if (w < nwu) { lo = low_img[i]; hi = high_img[i]; }
-        sLow[i] = lo; sE[i] = hi;
+        if (w < nwu) { lo = low_img[STP_CLS(r, w)]; hi = high_img[STP_CLS(r, w)]; }
+        sLow[r * STP_NW + w] = lo; sE[r * STP_NW + w] = hi;
     }
 }
 

@@ -330,8 +330,8 @@ __device__ __forceinline__ void canny_nms_pack(int tid, stp_tile T, const double
     if (lane < 8) {
         const int yy = wv * 8 + lane, y = T.ty0 + yy;
         if (y < T.S) {
-            low_img[y * STP_NW + (T.tx0 >> 6)] = lowB[yy];
-            high_img[y * STP_NW + (T.tx0 >> 6)] = highB[yy];
+            low_img[STP_CLS(y, T.tx0 >> 6)] = lowB[yy];
+            high_img[STP_CLS(y, T.tx0 >> 6)] = highB[yy];
         }
     }
 }
@@ -557,8 +557,8 @@ __device__ __forceinline__ void canny_pipe_tile(const float* __restrict__ gray, 
             for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
             if (mx - mn < STP_FLAT_RANGE) {          // flat window: no pixel of this tile can reach the low threshold
                 if (tid < CT_Y && T.ty0 + tid < S) {
-                    low[img * (STP_FRAME_MAX * STP_NW) + (T.ty0 + tid) * STP_NW + (T.tx0 >> 6)] = 0ull;
-                    high[img * (STP_FRAME_MAX * STP_NW) + (T.ty0 + tid) * STP_NW + (T.tx0 >> 6)] = 0ull;
+                    low[img * (STP_FRAME_MAX * STP_NW) + STP_CLS(T.ty0 + tid, T.tx0 >> 6)] = 0ull;
+                    high[img * (STP_FRAME_MAX * STP_NW) + STP_CLS(T.ty0 + tid, T.tx0 >> 6)] = 0ull;
                 }
                 continue;
             }
@@ -615,8 +615,8 @@ __device__ __forceinline__ void canny_pipe_tile(const float* __restrict__ gray, 
             const stp_u64 lo = sBits[tid], hi = sBits[CT_Y + tid];
             sBits[tid] = 0ull; sBits[CT_Y + tid] = 0ull;
             if (y < S) {
-                low[img * (STP_FRAME_MAX * STP_NW) + y * STP_NW + (T.tx0 >> 6)] = lo;
-                high[img * (STP_FRAME_MAX * STP_NW) + y * STP_NW + (T.tx0 >> 6)] = hi;
+                low[img * (STP_FRAME_MAX * STP_NW) + STP_CLS(y, T.tx0 >> 6)] = lo;
+                high[img * (STP_FRAME_MAX * STP_NW) + STP_CLS(y, T.tx0 >> 6)] = hi;
             }
         }
         if (tid == 64) *sQn = 0;
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     for (int i = tid; i < nb * CT_Y; i += nt) {      // the tile's class words of every image
         const int bi = i / CT_Y, row = i - bi * CT_Y, y = T.ty0 + row;
         if (y < S) {
-            const size_t o = (img0 + bi) * (STP_FRAME_MAX * STP_NW) + y * STP_NW + (T.tx0 >> 6);
+            const size_t o = (img0 + bi) * (STP_FRAME_MAX * STP_NW) + STP_CLS(y, T.tx0 >> 6);   // 32 rows = 256 contiguous bytes per plane
             low[o] = sBits[bi * 2 * CT_Y + row];
             high[o] = sBits[bi * 2 * CT_Y + CT_Y + row];
         }
@@ -2788,8 +2788,11 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
         for (int y = 0; y < S; y++) memcpy(gray + (size_t)y * S, hg.data() + (size_t)y * STP_PITCH, S * sizeof(float));
     if (cls) {
         std::vector<uint8_t> lo((size_t)S * S), hi((size_t)S * S);
-        unpack_bits(hl.data(), S, lo.data());
-        unpack_bits(hh.data(), S, hi.data());
+        std::vector<stp_u64> rl(BW), rh(BW);                         // the class planes are stored word-column-major (STP_CLS)
+        for (int y = 0; y < STP_FRAME_MAX; y++)
+            for (int w = 0; w < STP_NW; w++) { rl[y * STP_NW + w] = hl[STP_CLS(y, w)]; rh[y * STP_NW + w] = hh[STP_CLS(y, w)]; }
+        unpack_bits(rl.data(), S, lo.data());
+        unpack_bits(rh.data(), S, hi.data());
         for (size_t i = 0; i < (size_t)S * S; i++) cls[i] = (uint8_t)(lo[i] + hi[i]);
     }
     if (edges) unpack_bits(hd.data(), S, edges);

@@ -35,12 +35,17 @@ def _unpack(words, S):
     return b[:S, :S]
 
 
+def _unpack_cls(words, S):
+    """a class bit-plane as the Canny kernels hand it to k_lines: word-column-major (STP_CLS: word w of row y at w * 400 + y)"""
+    return _unpack(np.ascontiguousarray(words.reshape(7, 400).T), S)
+
+
 def _canny_f32(emu, full, S, R, gw):
     """Replay of k_canny_f32 (stp_canny32.h): f32 phases, certified class test, exact per-pixel resolver.
     Returns the class map and (candidates, pixels sent to the resolver)."""
     low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64); cnt = np.zeros(2, np.int64)
     emu.emu_canny_f32(_p(np.ascontiguousarray(full)), S, R, _p(gw), _p(low), _p(high), _p(cnt))
-    return _unpack(low, S).astype(np.uint8) + _unpack(high, S), cnt
+    return _unpack_cls(low, S).astype(np.uint8) + _unpack_cls(high, S), cnt
 
 
 @pytest.mark.parametrize('ci', [0, 2, 4, 5])
@@ -72,7 +77,7 @@ def test_emulated_kernels_match_oracle(emu, golden_stages, chr7, ci):
         low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64)
         emu.emu_canny(_p(gray[bi]), S, 8, _p(gw), _p(low), _p(high))
         oe, dbg = O.canny(og, gw, 8, debug=True)
-        assert np.array_equal(_unpack(low, S).astype(np.uint8) + _unpack(high, S), dbg['cls'])
+        assert np.array_equal(_unpack_cls(low, S).astype(np.uint8) + _unpack_cls(high, S), dbg['cls'])
         cls32, cnt = _canny_f32(emu, gray[bi], S, 8, gw)       # k_canny_f32's phases: same classes, few exact resolutions
         assert np.array_equal(cls32, dbg['cls']) and cnt[1] < 0.01 * cnt[0] + 50
         dbgw = np.zeros(4 * 2800, np.uint64); cols = np.zeros(1200, np.int16); recs = (ER * 128)(); sw = C.c_int(0)
@@ -99,7 +104,8 @@ def test_vertical_line_bitsliced_random(emu):
         high = low & (rng.random((S, S)) < 0.2)
         def pack(m):
             full = np.zeros((400, 448), np.uint8); full[:S, :S] = m
-            return np.packbits(full, axis=1, bitorder='little').view(np.uint64).reshape(-1).copy()
+            rowmajor = np.packbits(full, axis=1, bitorder='little').view(np.uint64).reshape(400, 7)
+            return np.ascontiguousarray(rowmajor.T).reshape(-1)          # class planes are word-column-major (STP_CLS)
         lw, hg = pack(low), pack(high)
         band = np.zeros((S + 8, 1024)); nz = np.arange(400, dtype=np.int16)
         dbgw = np.zeros(4 * 2800, np.uint64); cols = np.zeros(1200, np.int16); recs = (ER * 128)(); sw = C.c_int(0)
@@ -137,7 +143,7 @@ def test_canny_ties_and_plateaus(emu, S, golden_stages):
         low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64)
         emu.emu_canny(_p(full), S, 8, _p(gw), _p(low), _p(high))
         oe, dbg = O.canny(img, gw, 8, debug=True)
-        got = _unpack(low, S).astype(np.uint8) + _unpack(high, S)
+        got = _unpack_cls(low, S).astype(np.uint8) + _unpack_cls(high, S)
         assert np.array_equal(got, dbg['cls']), 'plateau image %d (S=%d)' % (k, S)
         assert dbg['cls'].any()
         cls32, cnt = _canny_f32(emu, full, S, 8, gw)            # exact ties: (nearly) every candidate goes to the resolver
@@ -155,13 +161,13 @@ def test_generic_radius_path(emu, golden_stages):
     low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64)
     emu.emu_canny2(_p(full), 200, 8, _p(gw), _p(low), _p(high), 0)
     oe, dbg = O.canny(img, gw, 8, debug=True)
-    assert np.array_equal(_unpack(low, 200).astype(np.uint8) + _unpack(high, 200), dbg['cls'])
+    assert np.array_equal(_unpack_cls(low, 200).astype(np.uint8) + _unpack_cls(high, 200), dbg['cls'])
     # sigma 3.0 -> radius 12 exists only in the generic form
     from oracle.oracle import gauss_weights
     w3, r3 = gauss_weights(3.0)
     emu.emu_canny2(_p(full), 200, r3, _p(w3), _p(low), _p(high), 0)
     oe, dbg = O.canny(img, w3, r3, debug=True)
-    assert np.array_equal(_unpack(low, 200).astype(np.uint8) + _unpack(high, 200), dbg['cls'])
+    assert np.array_equal(_unpack_cls(low, 200).astype(np.uint8) + _unpack_cls(high, 200), dbg['cls'])
 
 
 # ----------------------------------------------------------------------------- certified FMA (stp_gauss_fma.h)
@@ -193,7 +199,7 @@ def test_canny_sizes_radii_and_exact_fallback(emu, emu_allnear, golden_stages, S
         for lib in (emu, emu_allnear):
             low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64)
             lib.emu_canny(_p(full), S, R, _p(gw), _p(low), _p(high))
-            got = _unpack(low, S).astype(np.uint8) + _unpack(high, S)
+            got = _unpack_cls(low, S).astype(np.uint8) + _unpack_cls(high, S)
             assert np.array_equal(got, dbg['cls']), 'image %d (S=%d, sigma %.1f)' % (k, S, sigma)
         cls32, cnt = _canny_f32(emu, full, S, R, gw)
         assert np.array_equal(cls32, dbg['cls']), 'f32 path, image %d (S=%d, sigma %.1f)' % (k, S, sigma)
@@ -331,7 +337,7 @@ def test_other_tiled_radii(emu, emu_allnear, S, sigma):
         for lib in (emu, emu_allnear):
             low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64)
             lib.emu_canny(_p(full), S, R, _p(gw), _p(low), _p(high))
-            got = _unpack(low, S).astype(np.uint8) + _unpack(high, S)
+            got = _unpack_cls(low, S).astype(np.uint8) + _unpack_cls(high, S)
             assert np.array_equal(got, dbg['cls']), 'image %d (S=%d, sigma %.1f)' % (k, S, sigma)
         cls32, cnt = _canny_f32(emu, full, S, R, gw)
         assert np.array_equal(cls32, dbg['cls']), 'f32 path, image %d (S=%d, sigma %.1f)' % (k, S, sigma)

@@ -21,7 +21,7 @@ def check(gray, sigma):
     low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64); cnt = np.zeros(2, np.int64)
     E.emu_canny_f32(_p(full), S, gr, _p(gw), _p(low), _p(high), _p(cnt))
     _, d = O.canny(np.ascontiguousarray(gray), gw, gr, debug=True)
-    un = lambda w: np.unpackbits(w.view(np.uint8).reshape(400, 56), axis=1, bitorder='little')[:S, :S]
+    un = lambda w: np.unpackbits(np.ascontiguousarray(w.reshape(7, 400).T).view(np.uint8).reshape(400, 56), axis=1, bitorder='little')[:S, :S]   # class planes: word-column-major (STP_CLS)
     got = un(low).astype(np.uint8) + un(high)
     return int((got != d['cls']).sum()), cnt
 
