@@ -9,7 +9,7 @@ tag = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else 'genome'
 out = 'gpurun_out'
 SHORT = {'k_canny_f32': 'canny', 'k_canny_pipe': 'canny_f64', 'k_canny_pipe_list': 'canny_redo', 'k_canny': 'canny', 'k_gray': 'gray', 'k_gray_c3': 'gray', 'k_lines': 'lines', 'k_pvalue': 'pvalue',
-         'k_stripiness': 'stripiness', 'k_frame_prep': 'frame_prep'}
+         'k_stripiness': 'stripiness', 'k_frame_prep': 'frame_prep', 'k_score_wave': 'score'}
 
 
 def short(name):
