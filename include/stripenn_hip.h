@@ -83,6 +83,18 @@ typedef struct stp_select stp_select;
 int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1_id, const int64_t* bin2_id, const void* count, int32_t count_type,
                          int64_t npix, const double* weight, int64_t nbins_total, int64_t bin_lo, int64_t nrows,
                          int32_t halfwidth, stp_select* sel, stp_band** out);
+/* The same with the table's columns in their narrow form (round 5): bin1_id is sorted, so cooler keeps it as a CSR index too
+ * (`indexes/bin1_offset`), and a bin id fits 32 bits.  bin1_offset[r], r = 0 .. nrows: position -- among the npix pixels
+ * handed over -- of the first pixel of bin lo + r (bin1_offset[0] = 0, bin1_offset[nrows] = npix, non-decreasing); bin2_id as
+ * int64 (STP_ID_I64) or int32 (STP_ID_I32).  The bin1_id column (8 of a pixel's 20 bytes) never crosses PCIe: the device expands
+ * the index.  Every pixel's bin1 must lie in [lo, lo + nrows) by construction; pixels whose bin2 does not are skipped as in
+ * stp_band_pack.  Same band, nearest-pixel table and select contents as stp_band_pack_select on the expanded columns. */
+#define STP_ID_I64 0
+#define STP_ID_I32 1
+int stp_band_pack_csr(stp_ctx* ctx, const int64_t* bin1_offset, const void* bin2_id, int32_t bin2_type, const void* count, int32_t count_type,
+                      int64_t npix, const double* weight, int64_t nbins_total, int64_t lo, int64_t nrows, int32_t hw, stp_select* select,
+                      stp_band** out);
+
 /* For a band built by stp_band_pack: the distance from every bin to the nearest stored pixel with a positive
  * value in its row of the symmetric matrix, to the right (column >= row; 0 = a positive diagonal pixel) and to
  * the left (column < row); INT32_MAX where there is none.  Every cis pixel handed to stp_band_pack takes part,

@@ -89,7 +89,8 @@ class HipBackend:
     def pack_chrom(self, px, hw, select=None):
         """Band of one chromosome straight from its cis pixels (dict of stripenn_amd.pixels.PixelSelector.chrom_pixels);
         `select`: an order-statistic select that receives the pixel values in the same pass (one PCIe trip)."""
-        return self.ctx.band_pack(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], hw, select)
+        return self.ctx.band_pack(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], hw, select,
+                                  bin1_offset=px.get('off'))
 
     def close_chrom(self, band):
         band.close()

@@ -28,14 +28,14 @@ struct stp_sel_state {
 };
 
 // balanced value of every stored pixel, twice for off-diagonal ones (slot 2p+1 stays 0 = ignored on the diagonal)
-template <typename CT>     // pixels/count as stored: int32, or float64 (coolers written with --count-as-float, merged / scaled ones)
-__global__ __launch_bounds__(256) void k_sel_pixel_values(const int64_t* __restrict__ b1, const int64_t* __restrict__ b2,
+template <typename CT, typename I2>     // pixels/count as stored: int32, or float64 (coolers written with --count-as-float, merged / scaled ones); bin2_id: int64 or int32
+__global__ __launch_bounds__(256) void k_sel_pixel_values(const int64_t* __restrict__ b1, const I2* __restrict__ b2,
                                                            const CT* __restrict__ cnt, long long n,
                                                            const double* __restrict__ w /* bias of bins [lo, lo + nbins) */,
                                                            long long nbins, double* __restrict__ out, long long lo)
 {
     for (long long p = blockIdx.x * 256ll + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
-        const long long i = b1[p] - lo, j = b2[p] - lo;
+        const long long i = b1[p] - lo, j = (long long)b2[p] - lo;
         double v = (double)cnt[p];
         if (w) v = (i >= 0 && j >= 0 && i < nbins && j < nbins) ? v * (w[i] * w[j]) : 0.0;
         out[2 * p] = v;

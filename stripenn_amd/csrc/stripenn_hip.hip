@@ -1437,15 +1437,30 @@ __global__ __launch_bounds__(256) void k_band_init(const double* __restrict__ wl
     }
 }
 
-template <typename CT>     // pixels/count as stored: int32 or float64
-__global__ __launch_bounds__(256) void k_band_pack(const int64_t* __restrict__ bin1, const int64_t* __restrict__ bin2,
+// bin1_id of the pixels [p0, p0 + n) of a chunk from cooler's CSR index (indexes/bin1_offset): row r owns the pixels
+// off[r] .. off[r + 1] - 1.  One wave per row of [r_lo, r_hi] (the rows that reach into the chunk: found on the host), lanes
+// over the row's pixels: coalesced 8-byte stores, no search.  The column itself (8 bytes per pixel) never crosses PCIe.
+__global__ __launch_bounds__(256) void k_expand_bin1(const int64_t* __restrict__ off, int64_t r_lo, int64_t r_hi, int64_t lo, int64_t p0,
+                                                      int64_t n, int64_t* __restrict__ bin1)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t r = r_lo + wave; r <= r_hi; r += nwaves) {
+        int64_t a = off[r] - p0, b = off[r + 1] - p0;
+        a = a < 0 ? 0 : a; b = b > n ? n : b;
+        for (int64_t p = a + lane; p < b; p += 64) bin1[p] = lo + r;
+    }
+}
+
+template <typename CT, typename I2>     // pixels/count as stored: int32 or float64; bin2_id: int64 or int32
+__global__ __launch_bounds__(256) void k_band_pack(const int64_t* __restrict__ bin1, const I2* __restrict__ bin2,
                                                     const CT* __restrict__ count, int64_t npix,
                                                     const double* __restrict__ wloc /* bias of [lo, lo+nrows) or null */,
                                                     int64_t lo, int64_t nrows, int W, int hw, double* __restrict__ band,
                                                     int32_t* __restrict__ near)
 {
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-        int64_t i = bin1[p] - lo, j = bin2[p] - lo;
+        int64_t i = bin1[p] - lo, j = (int64_t)bin2[p] - lo;
         if (i < 0 || j < 0 || i >= nrows || j >= nrows) continue;
         if (j < i) { const int64_t t = i; i = j; j = t; }
         const int64_t d = j - i;
@@ -2216,14 +2231,40 @@ int stp_band_pack(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2, const 
     return stp_band_pack_select(ctx, bin1, bin2, count, STP_COUNT_I32, npix, weight, nbins_total, lo, nrows, hw, nullptr, out);
 }
 
+static int band_pack_impl(stp_ctx* ctx, const int64_t* bin1, const int64_t* off, const void* bin2_v, int32_t id2_type, const void* count_v,
+                          int32_t count_type, int64_t npix, const double* weight, int64_t nbins_total, int64_t lo, int64_t nrows, int32_t hw,
+                          stp_select* sel, stp_band** out);
+
 int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2, const void* count_v, int32_t count_type,
                          int64_t npix, const double* weight, int64_t nbins_total, int64_t lo, int64_t nrows, int32_t hw,
                          stp_select* sel, stp_band** out)
 {
+    if (!ctx || (npix > 0 && !bin1)) return STP_E_ARG;
+    return band_pack_impl(ctx, bin1, nullptr, bin2, STP_ID_I64, count_v, count_type, npix, weight, nbins_total, lo, nrows, hw, sel, out);
+}
+
+int stp_band_pack_csr(stp_ctx* ctx, const int64_t* bin1_offset, const void* bin2, int32_t bin2_type, const void* count_v, int32_t count_type,
+                      int64_t npix, const double* weight, int64_t nbins_total, int64_t lo, int64_t nrows, int32_t hw, stp_select* sel,
+                      stp_band** out)
+{
+    if (!ctx || !bin1_offset || nrows < 1 || npix < 0) return STP_E_ARG;
+    if (bin2_type != STP_ID_I64 && bin2_type != STP_ID_I32) return set_err(ctx, STP_E_ARG, "bin2_type must be STP_ID_I64 or STP_ID_I32");
+    if (bin1_offset[0] != 0 || bin1_offset[nrows] != npix) return set_err(ctx, STP_E_ARG, "bin1_offset must run from 0 to npix over nrows + 1 entries");
+    for (int64_t r = 0; r < nrows; r++)
+        if (bin1_offset[r] > bin1_offset[r + 1]) return set_err(ctx, STP_E_ARG, "bin1_offset must not decrease");
+    return band_pack_impl(ctx, nullptr, bin1_offset, bin2, bin2_type, count_v, count_type, npix, weight, nbins_total, lo, nrows, hw, sel, out);
+}
+
+static int band_pack_impl(stp_ctx* ctx, const int64_t* bin1, const int64_t* off, const void* bin2_v, int32_t id2_type, const void* count_v,
+                          int32_t count_type, int64_t npix, const double* weight, int64_t nbins_total, int64_t lo, int64_t nrows, int32_t hw,
+                          stp_select* sel, stp_band** out)
+{
     if (count_type != STP_COUNT_I32 && count_type != STP_COUNT_F64) return set_err(ctx, STP_E_ARG, "count_type must be STP_COUNT_I32 or STP_COUNT_F64");
     const size_t csz = count_type == STP_COUNT_F64 ? sizeof(double) : sizeof(int32_t);
+    const size_t i2sz = id2_type == STP_ID_I32 ? sizeof(int32_t) : sizeof(int64_t);
     const char* count = (const char*)count_v;
-    if (!ctx || !out || npix < 0 || (npix > 0 && (!bin1 || !bin2 || !count))) return STP_E_ARG;
+    const char* bin2 = (const char*)bin2_v;
+    if (!ctx || !out || npix < 0 || (npix > 0 && (!(bin1 || off) || !bin2 || !count))) return STP_E_ARG;
     if (lo < 0 || (weight && lo + nrows > nbins_total)) return set_err(ctx, STP_E_ARG, "bin range outside the weight column");
     int rc = check_hw(ctx, nrows, hw);
     if (rc) return rc;
@@ -2239,10 +2280,10 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
     //  runtime's own pageable path; what does pay is pinning the caller's columns IN PLACE for the call: host_pin)
     const int64_t CH = (int64_t)1 << 23;                 // pixels per staged chunk (160 MB of table columns)
     const int64_t nch = npix < CH ? npix : CH;
-    dev_buf b1, b2, bc, bw;
+    dev_buf b1, b2, bc, bw, bo;
     host_pin pin1, pin2, pinc;                            // (declared after the device buffers: released first)
-    pin1.pin(bin1, (size_t)npix * sizeof(int64_t), ctx->io);
-    pin2.pin(bin2, (size_t)npix * sizeof(int64_t), ctx->io);
+    if (bin1) pin1.pin(bin1, (size_t)npix * sizeof(int64_t), ctx->io);
+    pin2.pin(bin2, (size_t)npix * i2sz, ctx->io);
     pinc.pin(count, (size_t)npix * csz, ctx->io);
     stp_xfer x(ctx, ctx->io);                               // columns too small to pin (< 1 MB), the weights: staged
     auto up = [&](const host_pin& pin, void* dst, const void* src, size_t n) {
@@ -2255,9 +2296,11 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
     }
     hipError_t e = hipMemsetD32Async((hipDeviceptr_t)near, 0x7FFFFFFF, (size_t)nrows * 2, ctx->io);
     if (e == hipSuccess && nch) e = b1.alloc(ctx, (size_t)nch * sizeof(int64_t));
-    if (e == hipSuccess && nch) e = b2.alloc(ctx, (size_t)nch * sizeof(int64_t));
+    if (e == hipSuccess && nch) e = b2.alloc(ctx, (size_t)nch * i2sz);
     if (e == hipSuccess && nch) e = bc.alloc(ctx, (size_t)nch * csz);
     if (e == hipSuccess && weight) e = bw.alloc(ctx, (size_t)nrows * sizeof(double));
+    if (e == hipSuccess && off) e = bo.alloc(ctx, (size_t)(nrows + 1) * sizeof(int64_t));
+    if (e == hipSuccess && off) e = x.h2d(bo.p, off, (size_t)(nrows + 1) * sizeof(int64_t));     // the CSR index: 8 bytes per BIN
     if (e == hipSuccess && weight)
         e = x.h2d(bw.p, weight + lo, (size_t)nrows * sizeof(double));
     if (e == hipSuccess && weight) {
@@ -2271,19 +2314,28 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
         const int64_t n = npix - p0 < CH ? npix - p0 : CH;
         // (measured and dropped in round 4: bin2_id on a second upload stream, i.e. a second copy engine -- the 5.3 GB of the
         //  mm10-size table took the same 0.15-0.16 s: ~35 GB/s is what this host's memory feeds the link)
-        e = up(pin1, b1.p, bin1 + p0, (size_t)n * sizeof(int64_t));
-        if (e == hipSuccess) e = up(pin2, b2.p, bin2 + p0, (size_t)n * sizeof(int64_t));
+        if (bin1) e = up(pin1, b1.p, bin1 + p0, (size_t)n * sizeof(int64_t));
+        else {      // bin1_id of this chunk's pixels from the CSR index, on the device
+            const int64_t* hi_it = std::upper_bound(off, off + nrows + 1, p0);                    // first row starting beyond p0
+            const int64_t r_lo = std::max<int64_t>(0, (hi_it - off) - 1);
+            const int64_t r_hi = std::min<int64_t>(nrows - 1, (std::lower_bound(off, off + nrows + 1, p0 + n) - off) - 1);
+            if (r_hi >= r_lo)
+                hipLaunchKernelGGL(k_expand_bin1, dim3((unsigned)std::min<int64_t>((r_hi - r_lo + 4) / 4, 4096)), dim3(256), 0, ctx->io,
+                                   (const int64_t*)bo.p, r_lo, r_hi, lo, p0, n, (int64_t*)b1.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = up(pin2, b2.p, bin2 + (size_t)p0 * i2sz, (size_t)n * i2sz);
         if (e == hipSuccess) e = up(pinc, bc.p, count + (size_t)p0 * csz, (size_t)n * csz);
         if (e != hipSuccess) break;
         {
             prof_scope ps(ctx, "band_pack", (double)n * 36.0, ctx->io);    // 20 B of table read + two 8 B cells written
             const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 64);
-            if (count_type == STP_COUNT_F64)
-                hipLaunchKernelGGL(k_band_pack<double>, dim3(grid), dim3(256), 0, ctx->io, (const int64_t*)b1.p, (const int64_t*)b2.p,
-                                   (const double*)bc.p, n, weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d, near);
-            else
-                hipLaunchKernelGGL(k_band_pack<int32_t>, dim3(grid), dim3(256), 0, ctx->io, (const int64_t*)b1.p, (const int64_t*)b2.p,
-                                   (const int32_t*)bc.p, n, weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d, near);
+#define STP_PACK(CT, I2)                                                                                                                    \
+            hipLaunchKernelGGL((k_band_pack<CT, I2>), dim3(grid), dim3(256), 0, ctx->io, (const int64_t*)b1.p, (const I2*)b2.p, (const CT*)bc.p, n, \
+                               weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d, near)
+            if (count_type == STP_COUNT_F64) { if (id2_type == STP_ID_I32) STP_PACK(double, int32_t); else STP_PACK(double, int64_t); }
+            else { if (id2_type == STP_ID_I32) STP_PACK(int32_t, int32_t); else STP_PACK(int32_t, int64_t); }
+#undef STP_PACK
         }
         e = hipGetLastError();
         if (e == hipSuccess && sel) {
@@ -2293,14 +2345,12 @@ int stp_band_pack_select(stp_ctx* ctx, const int64_t* bin1, const int64_t* bin2,
             e = pool_alloc(ctx, (size_t)n * 2 * sizeof(double), (void**)&vals);
             if (e == hipSuccess) {
                 prof_scope ps(ctx, "select_pixels", 36.0 * n, ctx->io);
-                if (count_type == STP_COUNT_F64)
-                    hipLaunchKernelGGL(k_sel_pixel_values<double>, dim3(sel_grid(n)), dim3(256), 0, ctx->io, (const int64_t*)b1.p,
-                                       (const int64_t*)b2.p, (const double*)bc.p, (long long)n, weight ? (const double*)bw.p : nullptr,
-                                       (long long)nrows, vals, (long long)lo);
-                else
-                    hipLaunchKernelGGL(k_sel_pixel_values<int32_t>, dim3(sel_grid(n)), dim3(256), 0, ctx->io, (const int64_t*)b1.p,
-                                       (const int64_t*)b2.p, (const int32_t*)bc.p, (long long)n, weight ? (const double*)bw.p : nullptr,
-                                       (long long)nrows, vals, (long long)lo);
+#define STP_SELV(CT, I2)                                                                                                                    \
+                hipLaunchKernelGGL((k_sel_pixel_values<CT, I2>), dim3(sel_grid(n)), dim3(256), 0, ctx->io, (const int64_t*)b1.p, (const I2*)b2.p, \
+                                   (const CT*)bc.p, (long long)n, weight ? (const double*)bw.p : nullptr, (long long)nrows, vals, (long long)lo)
+                if (count_type == STP_COUNT_F64) { if (id2_type == STP_ID_I32) STP_SELV(double, int32_t); else STP_SELV(double, int64_t); }
+                else { if (id2_type == STP_ID_I32) STP_SELV(int32_t, int32_t); else STP_SELV(int32_t, int64_t); }
+#undef STP_SELV
                 e = hipGetLastError();
                 sel->chunks.push_back(std::make_pair(vals, (long long)(2 * n)));
                 sel->npos = -1;
@@ -3343,11 +3393,11 @@ int stp_select_append_pixels_ex(stp_ctx* ctx, stp_select* s, const int64_t* bin1
         if (e == hipSuccess) {
             prof_scope ps(ctx, "select_pixels", 36.0 * n, ctx->io);
             if (count_type == STP_COUNT_F64)
-                hipLaunchKernelGGL(k_sel_pixel_values<double>, dim3(sel_grid(n)), dim3(256), 0, ctx->io, (const int64_t*)d1.p,
+                hipLaunchKernelGGL((k_sel_pixel_values<double, int64_t>), dim3(sel_grid(n)), dim3(256), 0, ctx->io, (const int64_t*)d1.p,
                                    (const int64_t*)d2.p, (const double*)dc.p, (long long)n, weight ? (const double*)dw.p : nullptr,
                                    (long long)nbins_total, out, 0ll);
             else
-                hipLaunchKernelGGL(k_sel_pixel_values<int32_t>, dim3(sel_grid(n)), dim3(256), 0, ctx->io, (const int64_t*)d1.p,
+                hipLaunchKernelGGL((k_sel_pixel_values<int32_t, int64_t>), dim3(sel_grid(n)), dim3(256), 0, ctx->io, (const int64_t*)d1.p,
                                    (const int64_t*)d2.p, (const int32_t*)dc.p, (long long)n, weight ? (const double*)dw.p : nullptr,
                                    (long long)nbins_total, out, 0ll);
             e = hipGetLastError();

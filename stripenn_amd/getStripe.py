@@ -138,6 +138,7 @@ class getStripe:
             if (ra, rb) != (0, nb):                                # stored pixels (i <= j) that land in rows [ra, rb)
                 a, b = np.searchsorted(px['bin1'], [px['lo'] + ra - hw, px['lo'] + rb], side='left')
                 px = dict(px, bin1=px['bin1'][a:b], bin2=px['bin2'][a:b], count=px['count'][a:b])
+                px.pop('off', None)                                # (the CSR index describes the whole chromosome's pixels)
                 select = None                                      # (a partial band does not see every pixel)
             self._bands[chrom] = self.backend.pack_chrom(px, hw, select) if select is not None else self.backend.pack_chrom(px, hw)
             self.timing['band_build_s'] = self.timing.get('band_build_s', 0.0) + time.time() - t0

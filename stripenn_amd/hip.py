@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get('STP_LIB') or os.path.join(_HERE, 'libstripenn_hip.so'
 
 STP_FRAME_MAX = 400
 STP_OK, STP_E_ARG, STP_E_CAPACITY, STP_E_HIP, STP_E_NOMEM, STP_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+STP_ID_I64, STP_ID_I32 = 0, 1          # bin2_id column type of stp_band_pack_csr
 _ERRNAMES = {-1: 'STP_E_ARG', -2: 'STP_E_CAPACITY', -3: 'STP_E_HIP', -4: 'STP_E_NOMEM', -5: 'STP_E_UNSUPPORTED'}
 
 EXPORTS = [
@@ -73,6 +74,7 @@ def load():
     L.stp_band_wrap_device.argtypes = [vp, vp, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.stp_band_pack.argtypes = [vp, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.stp_band_pack_select.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, vp, C.POINTER(vp)]
+    L.stp_band_pack_csr.argtypes = [vp, vp, vp, C.c_int32, vp, C.c_int32, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, vp, C.POINTER(vp)]
     L.stp_band_download.argtypes = [vp, vp, vp]
     L.stp_band_nearest.argtypes = [vp, vp, vp, vp]
     L.stp_band_free.argtypes = [vp, vp]
@@ -218,16 +220,29 @@ class Context:
             raise ValueError('band width must be 2*halfwidth (columns d = -hw .. hw-1), got %d' % W)
         return Band(self, band_host=band, nrows=nrows, hw=W // 2)
 
-    def band_pack(self, bin1, bin2, count, weight, lo, nrows, hw, select=None):
+    def band_pack(self, bin1, bin2, count, weight, lo, nrows, hw, select=None, bin1_offset=None):
         """Band of bins [lo, lo + nrows) built on the device from cooler's pixel table (stp_band_pack); with `select`
-        (an stp_select handle) the same pass appends the balanced pixel values to it (stp_band_pack_select)."""
-        bin1 = np.ascontiguousarray(bin1, dtype=np.int64)
-        bin2 = np.ascontiguousarray(bin2, dtype=np.int64)
+        (an stp_select handle) the same pass appends the balanced pixel values to it (stp_band_pack_select).
+        `bin1_offset` (nrows + 1 positions: cooler's indexes/bin1_offset of these pixels) replaces the bin1 column on the way
+        to the device, and an int32 bin2 column travels as it is (stp_band_pack_csr)."""
         count, ctype = count_column(count)
-        if not (len(bin1) == len(bin2) == len(count)):
-            raise ValueError('pixel columns differ in length')
         w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float64)
         h = C.c_void_p()
+        if bin1_offset is not None:
+            off = np.ascontiguousarray(bin1_offset, dtype=np.int64)
+            b2 = np.asarray(bin2)
+            narrow = b2.dtype == np.int32
+            b2 = np.ascontiguousarray(b2, dtype=np.int32 if narrow else np.int64)
+            if len(off) != int(nrows) + 1 or len(b2) != len(count):
+                raise ValueError('pixel columns / bin1_offset differ in length')
+            self._chk(self.L.stp_band_pack_csr(self.h, _ptr(off), _ptr(b2), STP_ID_I32 if narrow else STP_ID_I64, _ptr(count), ctype,
+                                               len(b2), _ptr(w), 0 if w is None else len(w), int(lo), int(nrows), int(hw), select,
+                                               C.byref(h)))
+            return Band(self, handle=h, nrows=nrows, hw=hw)
+        bin1 = np.ascontiguousarray(bin1, dtype=np.int64)
+        bin2 = np.ascontiguousarray(bin2, dtype=np.int64)
+        if not (len(bin1) == len(bin2) == len(count)):
+            raise ValueError('pixel columns differ in length')
         self._chk(self.L.stp_band_pack_select(self.h, _ptr(bin1), _ptr(bin2), _ptr(count), ctype, len(bin1), _ptr(w),
                                               0 if w is None else len(w), int(lo), int(nrows), int(hw), select, C.byref(h)))
         return Band(self, handle=h, nrows=nrows, hw=hw)

@@ -61,7 +61,9 @@ class PixelTable:
         self.binsize = int(binsize)
         self.chrom_offset = np.asarray(chrom_offset, dtype=np.int64)          # len(chromnames) + 1
         self.bin1_id = np.ascontiguousarray(bin1_id, dtype=np.int64)
-        self.bin2_id = np.ascontiguousarray(bin2_id, dtype=np.int64)
+        # bin2_id keeps a 32-bit type when it arrives as one (a bin id fits; the column then crosses PCIe at half the bytes)
+        b2 = np.asarray(bin2_id)
+        self.bin2_id = np.ascontiguousarray(b2, dtype=np.int32 if b2.dtype == np.int32 else np.int64)
         self.count = _counts(count)
         self.weights = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in (weights or {}).items()}
         if len(self.chrom_offset) != len(self.chromnames) + 1:
@@ -71,6 +73,9 @@ class PixelTable:
         self._trans = {}              # chromosome -> does its row range hold trans pixels (asked once per chromosome)
         if len(self.bin1_id) and (np.any(np.diff(self.bin1_id) < 0) or np.any(self.bin1_id > self.bin2_id)):
             raise ValueError('pixels must be sorted by bin1_id and upper-triangular (bin1_id <= bin2_id)')
+        # cooler's indexes/bin1_offset: first pixel of every bin (bin1_id is sorted, so the column is this index expanded).
+        # The band packer takes the index instead of the column (stp_band_pack_csr): 8 bytes per BIN instead of per pixel.
+        self.bin1_offset = np.searchsorted(self.bin1_id, np.arange(int(self.chrom_offset[-1]) + 1), side='left').astype(np.int64)
 
     # ------------------------------------------------------------------ geometry
     def chrom_index(self, chrom):
@@ -126,6 +131,14 @@ class PixelTable:
                 return b1[keep], b2[keep], self.count[a:b][keep], lo, hi - lo
         return b1, b2, self.count[a:b], lo, hi - lo
 
+    def chrom_offsets(self, chrom):
+        """CSR index of chrom_pixels(chrom)'s rows (position of the first pixel of every bin of the chromosome, + the
+        pixel count), or None when the chromosome's rows hold trans pixels (the filtered columns have no stored index)."""
+        lo, hi = self.chrom_bins(chrom)
+        if self._trans.get(str(chrom), True) and len(self.chrom_pixels(chrom)[0]) != int(self.bin1_offset[hi] - self.bin1_offset[lo]):
+            return None
+        return self.bin1_offset[lo:hi + 1] - self.bin1_offset[lo]
+
     # ------------------------------------------------------------------ I/O
     def save(self, path, compressed=False):
         """.npz; uncompressed by default (loading a deflated 14 M-pixel table costs more than the whole GPU run)."""
@@ -151,8 +164,11 @@ class PixelTable:
             sizes = g['chroms/length'][:]
             binsize = int(g.attrs['bin-size'])
             w = {k: g['bins'][k][:] for k in g['bins'].keys() if k not in ('chrom', 'start', 'end')}
-            return cls(names, sizes, binsize, g['indexes/chrom_offset'][:], g['pixels/bin1_id'][:],
-                       g['pixels/bin2_id'][:], g['pixels/count'][:], w)
+            co = g['indexes/chrom_offset'][:]
+            b2 = g['pixels/bin2_id'][:]
+            if int(co[-1]) < 2**31:
+                b2 = b2.astype(np.int32)                     # (as the lazy reader hands it over: a bin id fits 32 bits)
+            return cls(names, sizes, binsize, co, g['pixels/bin1_id'][:], b2, g['pixels/count'][:], w)
 
     @classmethod
     def from_synth(cls, names, chroms, resol, hw_limit=None):
@@ -300,7 +316,8 @@ class CoolTable:
         lo, hi = self.chrom_bins(chrom)
         a, b = self.rows_slice(lo, hi)
         n = 0
-        o1 = np.empty(b - a, np.int64); o2 = np.empty(b - a, np.int64)
+        # (bin2_id is narrowed to 32 bits while the pieces are copied: half the host memory of the column and half its PCIe bytes)
+        o1 = np.empty(b - a, np.int64); o2 = np.empty(b - a, np.int32 if int(self.chrom_offset[-1]) < 2**31 else np.int64)
         cdt = np.dtype(self.count.dtype)                     # (wider integer columns keep their type: _counts decides)
         oc = np.empty(b - a, np.float64 if cdt.kind == 'f' else (np.int32 if cdt.itemsize <= 4 and cdt.kind == 'i' else cdt))
         for x in range(a, b, self.chunk):
@@ -316,6 +333,11 @@ class CoolTable:
                 o2[n:n + m] = p2[keep]; o1[n:n + m] = p1[keep]; oc[n:n + m] = pc[keep]
             n += m
         return o1[:n], o2[:n], _counts(oc[:n]), lo, hi - lo
+
+    def chrom_offsets(self, chrom):
+        """None: the cis columns of a file are filtered copies (trans pixels dropped), the stored index does not describe
+        them; PixelSelector derives the index of what it got from the sorted bin1 column."""
+        return None
 
     def _read_piece(self, x, y):
         """Rows [x, y) of the three pixel columns.  HDF5 inflates one chunk at a time under the library's global lock
@@ -413,7 +435,13 @@ class PixelSelector:
 
     def chrom_pixels(self, chrom):
         b1, b2, cn, lo, n = self.table.chrom_pixels(chrom)
-        return dict(bin1=b1, bin2=b2, count=cn, weight=self.w, lo=lo, nrows=n)
+        px = dict(bin1=b1, bin2=b2, count=cn, weight=self.w, lo=lo, nrows=n)
+        off = self.table.chrom_offsets(chrom) if hasattr(self.table, 'chrom_offsets') else None
+        if off is None and len(b1):      # (filtered columns: the index of what is left, one search per bin in the sorted column)
+            off = np.searchsorted(b1, np.arange(lo, lo + n + 1), side='left').astype(np.int64)
+        if off is not None:
+            px['off'] = off              # the CSR form of bin1 (stp_band_pack_csr takes it instead of the column)
+        return px
 
     def prefetch(self, chrom):
         """Hint: `chrom_pixels(chrom)` comes next (a lazily read table starts the read on a host thread)."""

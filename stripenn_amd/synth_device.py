@@ -90,9 +90,10 @@ class DeviceChrom:
             out[a:b] = torch.where(ok, val, torch.zeros_like(val))
         return out
 
-    def pixels(self, bin_offset=0, chunk=8192):
+    def pixels(self, bin_offset=0, chunk=8192, narrow=False):
         """Upper-triangle stored pixels (bin1 <= bin2, count > 0) as host arrays (global ids = local + bin_offset),
-        sorted by (bin1, bin2) like cooler's pixel table."""
+        sorted by (bin1, bin2) like cooler's pixel table.  narrow: bin2_id as int32 (as a reader that narrows the column
+        while it inflates the file's chunks hands it over)."""
         import torch
         lim = synth.BAND_LIMIT
         b1, b2, cn = [], [], []
@@ -105,18 +106,18 @@ class DeviceChrom:
             cnt = self._counts(r, c.clamp(0, self.nbins - 1))
             keep = ok & (cnt > 0)
             b1.append((r[keep] + bin_offset).cpu().numpy())
-            b2.append((c[keep] + bin_offset).cpu().numpy())
+            b2.append((c[keep] + bin_offset).to(torch.int32).cpu().numpy() if narrow else (c[keep] + bin_offset).cpu().numpy())
             cn.append(cnt[keep].to(torch.int32).cpu().numpy())
         return np.concatenate(b1), np.concatenate(b2), np.concatenate(cn)
 
 
-def pixel_table(names, chroms, resol):
-    """stripenn_amd.pixels.PixelTable of device-generated chromosomes (dict name -> DeviceChrom)."""
+def pixel_table(names, chroms, resol, narrow=True):
+    """stripenn_amd.pixels.PixelTable of device-generated chromosomes (dict name -> DeviceChrom); narrow: bin2_id as int32."""
     from . import pixels
     b1, b2, cn, ws, off, sizes = [], [], [], [], [0], []
     for nm in names:
         ch = chroms[nm]
-        p = ch.pixels(bin_offset=off[-1])
+        p = ch.pixels(bin_offset=off[-1], narrow=narrow)
         b1.append(p[0]); b2.append(p[1]); cn.append(p[2])
         w = ch.host.w.astype(np.float64).copy()
         w[ch.host.nan_bins] = np.nan

@@ -115,7 +115,8 @@ def test_chunk_decoder_equals_hdf5s_filter_pipeline(tmp_path, layout):
         lazy.threads = threads
         for nm in names:
             a, b = lazy.chrom_pixels(nm), t.chrom_pixels(nm)
-            assert all(np.array_equal(x, y) and x.dtype == y.dtype for x, y in zip(a[:3], b[:3])), (layout, threads, nm)
+            assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])) and a[2].dtype == b[2].dtype, (layout, threads, nm)
+            assert a[1].dtype == np.int32        # bin2_id is narrowed while the pieces are copied
         n = len(t.count)
         p = lazy._read_piece(n - 1500, n)                   # the short last chunk
         assert np.array_equal(p[0], t.bin1_id[n - 1500:]) and np.array_equal(p[2], t.count[n - 1500:])

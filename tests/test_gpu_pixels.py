@@ -58,6 +58,60 @@ def test_pack_chromosome_sized_table_in_chunks(hip_ctx):
     band.close()
 
 
+def test_pack_from_csr_index_and_narrow_bin2(hip_ctx):
+    """stp_band_pack_csr: the bin1 column as cooler's CSR index (expanded on the device), bin2_id as int32 or int64, int32 and
+    float64 counts -- band, nearest-pixel table and the quantile's select equal those of the column form (stp_band_pack_select)
+    and the CPU restatement; more than one staging chunk; empty rows; argument errors."""
+    names = ['chrA', 'chrB']
+    chroms = {'chrA': synth.SynthChrom(900, 41), 'chrB': synth.SynthChrom(1300, 42, nan_frac=0.02)}
+    t = pixels.PixelTable.from_synth(names, chroms, RESOL)
+    hb = BK.HipBackend(0)
+    for balance in (True, False):
+        sel = pixels.PixelSelector(t, balance)
+        for nm in names:
+            px = sel.chrom_pixels(nm)
+            assert 'off' in px and len(px['off']) == px['nrows'] + 1 and px['off'][-1] == len(px['bin2'])
+            exp = O.band_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], 512)
+            ref = hb.ctx.band_pack(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], 512)
+            rn = ref.nearest()
+            for b2 in (px['bin2'].astype(np.int64), px['bin2'].astype(np.int32)):
+                for cnt in (px['count'], px['count'].astype(np.float64) * 0.5):
+                    e = exp if cnt is px['count'] else O.band_from_pixels(px['bin1'], px['bin2'], cnt, px['weight'], px['lo'], px['nrows'], 512)
+                    s1, s2 = hb.select_open(), hb.select_open()
+                    a = hb.ctx.band_pack(None, b2, cnt, px['weight'], px['lo'], px['nrows'], 512, s1, bin1_offset=px['off'])
+                    b = hb.ctx.band_pack(px['bin1'], px['bin2'], cnt, px['weight'], px['lo'], px['nrows'], 512, s2)
+                    assert _same(a.download(), e) and _same(b.download(), e), (balance, nm, b2.dtype, cnt.dtype)
+                    an = a.nearest()
+                    assert np.array_equal(an[0], rn[0]) and np.array_equal(an[1], rn[1])
+                    n1, n2 = hb.select_count(s1), hb.select_count(s2)
+                    assert n1 == n2 and n1 > 0
+                    ranks = np.array([0, n1 // 3, n1 // 2, n1 - 1], dtype=np.int64)
+                    assert np.array_equal(hb.select_ranks(s1, ranks), hb.select_ranks(s2, ranks))
+                    hb.select_close(s1); hb.select_close(s2)
+                    a.close(); b.close()
+            ref.close()
+    # a chromosome-size table (more than one staging chunk), int32 bin2, through pack_chrom as the driver calls it
+    ch = synth.SynthChrom(19642, 16)
+    t16 = pixels.PixelTable.from_synth(['chr16'], {'chr16': ch}, RESOL)
+    t16.bin2_id = t16.bin2_id.astype(np.int32)
+    px = pixels.PixelSelector(t16, True).chrom_pixels('chr16')
+    assert px['bin2'].dtype == np.int32 and len(px['count']) > (1 << 23)
+    band = hb.pack_chrom(px, 512)
+    assert _same(band.download(), O.band_from_pixels(px['bin1'], px['bin2'], px['count'], px['weight'], px['lo'], px['nrows'], 512))
+    band.close()
+    # rows without pixels at both ends and in the middle
+    off = np.array([0, 0, 2, 2, 2, 5, 5], dtype=np.int64)
+    b1 = np.array([1, 1, 4, 4, 4], dtype=np.int64); b2 = np.array([1, 3, 4, 5, 5], dtype=np.int32); cn = np.array([3, 1, 4, 1, 5], dtype=np.int32)
+    a = hb.ctx.band_pack(None, b2, cn, None, 0, 6, 448, bin1_offset=off)
+    assert _same(a.download(), O.band_from_pixels(b1, b2.astype(np.int64), cn, None, 0, 6, 448))
+    a.close()
+    from stripenn_amd import hip
+    for bad in (np.array([1, 0, 2, 2, 2, 5, 5]), np.array([0, 0, 2, 2, 2, 5, 4]), np.array([0, 3, 2, 2, 2, 5, 5])):
+        with pytest.raises(hip.StripennHipError):
+            hb.ctx.band_pack(None, b2, cn, None, 0, 6, 448, bin1_offset=bad.astype(np.int64))
+    hb.close()
+
+
 def test_compute_from_pixel_table_equals_dense_route(tmp_path, monkeypatch):
     names = ['chrA', 'chrB']
     chroms = {'chrA': synth.SynthChrom(1500, 51, stripe_every=90, stripe_gain=3.0),

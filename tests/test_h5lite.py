@@ -70,7 +70,8 @@ def test_lazy_table_through_the_builtin_reader(tiny):
     for nm in names:
         lazy.prefetch(nm)
         a, b = lazy.chrom_pixels(nm), t.chrom_pixels(nm)
-        assert all(np.array_equal(x, y) and x.dtype == y.dtype for x, y in zip(a[:3], b[:3])) and a[3:] == b[3:]
+        assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])) and a[2].dtype == b[2].dtype and a[3:] == b[3:]
+        assert a[1].dtype == np.int32            # the file readers narrow bin2_id while they copy the pieces (half the PCIe bytes)
     assert lazy.direct_reads > 0 and 0 < lazy.max_read <= 50000
     for balance in ('weight', 'KR', False):
         sl, sm = pixels.PixelSelector(lazy, balance), pixels.PixelSelector(t, balance)
