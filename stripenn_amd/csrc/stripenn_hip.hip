@@ -1252,10 +1252,17 @@ __global__ __launch_bounds__(512, RCAP == STP_RCAP ? 6 : 4) void k_lines(const s
         const bool has = tid < nitem;
         stp_hyst_item hit;
         hyst_item_load(has ? tid : 0, S, bufA, bufB, &hit);
+        // (measured and dropped in round 5: an item sweeping again only if it or one of its eight neighbours changed in the previous
+        //  sweep -- images need 5 sweeps on average, profiles/r05_hyst_sweeps.txt -- 11.2 -> 11.1 ms per step: a wave holds nine strips
+        //  over the full width and almost always has a changed item in or next to its band, so whole waves rarely sit a sweep out)
+        int sweeps = 0;
         for (int it = 0; it < 4 * STP_FRAME_MAX * STP_FRAME_MAX; it++) {
             const int ch = has ? hyst_item_sweep(S, &hit, bufA, bufB) : 0;
+            sweeps++;
             if (!__syncthreads_or(ch)) break;
         }
+        // (diagnostic of the timing-only build, STP_LINES_STOP=99: the image reports its number of sweeps as its record count)
+        if (dbg_stop == 99) { if (tid == 0) rec_count[img] = min(sweeps, RCAP); return; }
     }
     if (dbg_stop == 2) { if (tid == 0) rec_count[img] = (int)(bufB[3] & 0); return; }
     lines_vline(tid, nt, S, bufB, bufA);               // low is dead: vert goes to bufA
@@ -2571,7 +2578,7 @@ static void search_release(stp_ctx* ctx, stp_search* s)
     pool_release(ctx, s->d_out, s->out_bytes);
     pool_release(ctx, s->d_tot, s->tot_bytes);
     if (s->pin) {
-        if (ctx->pin_free.size() < 8) ctx->pin_free.push_back(std::make_pair(s->pin_bytes, s->pin));
+        if (ctx->pin_free.size() < 64) ctx->pin_free.push_back(std::make_pair(s->pin_bytes, s->pin));
         else (void)stp_hfree(__LINE__, s->pin);
     }
     if (s->done) (void)hipEventDestroy(s->done);

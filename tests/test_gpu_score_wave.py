@@ -100,3 +100,42 @@ def test_wave_form_equals_block_form_fused_call_and_oracle(seed, resol, hmax):
             assert _same(a[idx], b, nm == 'g'), 'Stripiness output %s vs oracle' % nm
     gb.close()
     hb.close()
+
+
+def test_symmetric_reads_are_used_only_for_symmetric_bands():
+    """The score kernels read a stripe's pixels as M[c][r] (coalesced) only after k_band_symcheck has found the band bit for bit
+    symmetric.  (i) A symmetric band: the symmetric reads and the row reads (STP_SCORE_NOSYM=1) give identical outputs, and the
+    oracle's.  (ii) A band with ONE asymmetric cell pair far from every stripe, and one whose upper triangle is perturbed
+    everywhere: the library must fall back to the row reads -- outputs equal the oracle's, which reads M[r][c] from row r."""
+    from oracle import oracle as O
+    from stripenn_amd import backend as BK, synth
+    O.build()
+    rng = np.random.default_rng(77)
+    nb, bs = 1500, 10
+    ch = synth.SynthChrom(nb, 777, nan_frac=0.01)
+    sym = ch.band(512)
+    one = sym.copy(); one[1400, 512 + 7] += 1.0                    # M[1400][1407] != M[1407][1400]
+    allp = sym.copy(); allp[:, 513:] *= 1.0 + 1e-3 * rng.random((nb, 511))
+    ncol = 500
+    bg = [np.sort(rng.normal(0, 3, (400, ncol)), axis=1) for _ in range(4)]
+    EV = 240.0 / (1.0 + np.arange(400)) + 1.0 + rng.random(400)
+    pv, sc = _stripes(rng, nb, bs, 300, 190)
+    keep = pv['row1'] < 1300                                       # (the single asymmetric pair stays outside every patch)
+    pv, sc = pv[keep], sc[keep]
+    hb = BK.HipBackend(0); ob = OracleBackend()
+    hb.set_background(*bg); ob.set_background(*bg)
+    idx = np.arange(0, len(pv), 2)
+    for name, band_h in (('symmetric', sym), ('one cell pair', one), ('upper triangle perturbed', allp)):
+        gb = hb.open_chrom(band_h); cb = ob.open_chrom(band_h)
+        p, g, m, t = hb.score(gb, bs, EV, pv, sc)
+        os.environ['STP_SCORE_NOSYM'] = '1'
+        try:
+            p2, g2, m2, t2 = hb.score(gb, bs, EV, pv, sc)
+        finally:
+            os.environ.pop('STP_SCORE_NOSYM', None)
+        assert _same(p, p2, True) and _same(g, g2, True) and _same(m, m2, True) and _same(t, t2, True), name
+        assert _same(p[idx], ob.pvalue(cb, bs, pv[idx]), True), name + ': p-values vs oracle'
+        eg, em, et = ob.stripiness(cb, EV, sc[idx])
+        assert _same(g[idx], eg, True) and _same(m[idx], em, False) and _same(t[idx], et, False), name + ': Stripiness vs oracle'
+        gb.close()
+    hb.close()
