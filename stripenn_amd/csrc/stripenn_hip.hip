@@ -3141,17 +3141,18 @@ static int run_score(stp_ctx* ctx, const stp_band* band, const stp_background* b
     HIPCHK(bO.alloc(ctx, (size_t)n * 4 * sizeof(double) + (size_t)n * sizeof(int)));
     const bool need_idx = small.size() != (size_t)n;                     // (everything in one wave launch: no list, stripes in order)
     if (need_idx) HIPCHK(bI.alloc(ctx, (size_t)n * sizeof(int)));
+    std::vector<int> all;                                                // the index lists' host copy: declared before the transfer object, so it outlives every copy
     stp_xfer x(ctx, ctx->aux);
     if (pst) HIPCHK(x.h2d(bP.p, pst, (size_t)n * sizeof(stp_pv_stripe)));
     if (sst) HIPCHK(x.h2d(bS.p, sst, (size_t)n * sizeof(stp_score_stripe)));
     if (sst) HIPCHK(x.h2d(bE.p, exval400, STP_NDIAG * sizeof(double)));
     int *d_small = nullptr, *d_tall = nullptr, *d_big = nullptr;
     if (need_idx) {
-        std::vector<int> all(small);
+        all = small;
         all.insert(all.end(), tall.begin(), tall.end());
         all.insert(all.end(), big.begin(), big.end());
         d_small = (int*)bI.p; d_tall = d_small + small.size(); d_big = d_tall + tall.size();
-        HIPCHK(x.h2d(d_small, all.data(), all.size() * sizeof(int)));     // (staged: `all` may go out of scope)
+        HIPCHK(x.h2d(d_small, all.data(), all.size() * sizeof(int)));
     }
     double* o = (double*)bO.p;                                           // p | g | mean | total | status
     double* o_p = o; double* o_g = o + n; double* o_m = o + 2 * n; double* o_t = o + 3 * n;
