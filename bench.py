@@ -9,7 +9,8 @@ the timed region.
 
 A "step" = one pass of the GPU hot path over the rank's share of the genome: per chromosome (or frame span
 of one) frame compaction + medpixel -> image build / Canny / line joining for every (frame, level,
-brightness) -> candidate records on the host -> p-value + Stripiness kernels for every candidate.
+brightness) -> candidate records on the host -> p-value + Stripiness kernels for every candidate.  Every step drains (its last
+candidate is scored) before the next one starts.
 
 N > 1 (`--gpus N`): STRONG scaling of the same genome.  The (chromosome x frame) grid is cut into N
 contiguous spans of equal frame count (stripenn_amd.shard.frame_spans; all maxpixel levels of a frame stay
@@ -273,8 +274,11 @@ def main():
     W.reset_stats()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        nrec, contact_px = W.step()
+    if os.environ.get('STP_BENCH_PIPELINE_STEPS') == '1':        # (diagnostic: the K steps as ONE pipeline, no drain between two steps --
+        nrec, contact_px = W.run(args.steps)                     #  71.0 against 71.8 ms per step in round 5: fill and drain are 1 % of a step)
+    else:
+        for _ in range(args.steps):                              # every step drains before the next one starts
+            nrec, contact_px = W.step()
     barrier()
     dt_rank = time.perf_counter() - t0
     stats = W.stats()
@@ -390,7 +394,9 @@ def main():
                           'rank_ms_per_step': [round(t, 3) for t in rank_ms], 'setup_s': round(setup_s, 1),
                           'host_wait_ms_per_step': round(host_wait_ms, 2),      # of ms_per_step the search thread spent waiting for searches ...
                           'host_blocked_ms_per_step': round(host_wait_ms + host_call_ms, 2),   # ... and inside every blocking device call (searches, frame preparation, p-value, Stripiness); the rest is Python / numpy work (score inputs, bookkeeping)
-                          'score_thread': W.hb2 is not None,                     # p-value / Stripiness calls on a host thread and context of their own
+                          'score_thread': W._thr is not None,                    # p-value / Stripiness calls on a host thread and context of their own
+                          'search_contexts': 2 if W.two_ctx else 1,              # contexts (streams, workspaces) taking alternate units
+                          'steps_pipelined': os.environ.get('STP_BENCH_PIPELINE_STEPS') == '1',
 
                           'comm': comm, 'comm_note': comm_note, 'devices': devnames,
                           'library': hip.LIB_PATH,
@@ -542,7 +548,19 @@ class _Workload:
         # search thread then waits 54 of 80 ms instead of 13 -- and the step takes the same 80 ms: it is device-bound either way
         # (chain 75 ms + pipeline fill / drain), so the single thread stays the default (STP_BENCH_SCORE_THREAD=1 selects this).
         self.hb2, self.bands2, self._q, self._thr, self._err = None, {}, None, None, []
+        # Two search contexts (two HIP streams, two workspaces) taking alternate units: the kernels of two units share the device,
+        # so one unit's launch tails, its latency-bound k_lines and the drain behind its last kernel are filled by the other's chain
+        # Measured and NOT the default (round 5, STP_BENCH_CTX=2): 74.8-75.2 against 71.8 ms per step -- kernels of two streams that
+        # really run side by side slow each other down by more than the filled tails give back (round 2 had found the same).
+        self.two_ctx = os.environ.get('STP_BENCH_CTX', '1') == '2' and not emulate_rank
+        if self.two_ctx and not (score and os.environ.get('STP_BENCH_SCORE_THREAD', '0') == '1'):
+            self.hb2 = BK.HipBackend(dev.index or 0)
+            if score:
+                self.hb2.set_background(*bg)
+            for nm in self.bands:
+                self.bands2[nm] = self.hb2.ctx.band_wrap(self.tens[nm].data_ptr(), nbins[names.index(nm)], hw, keepalive=self.tens[nm])
         if score and os.environ.get('STP_BENCH_SCORE_THREAD', '0') == '1':
+            self.two_ctx = False
             import queue
             import threading
             prio = os.environ.get('STP_BENCH_SCORE_PRIORITY')      # stream priority of the scoring context (measurement hook)
@@ -607,50 +625,66 @@ class _Workload:
         if self.hb2 is not None:
             self.hb2.ctx.synchronize()
 
-    def _launch(self, unit):
+    def _launch(self, unit, k=0):
         """frame compaction + medpixel of one unit (small kernels on the context's auxiliary stream) and its whole
-        StripeSearch chain enqueued on the main stream; returns without waiting for the chain"""
+        StripeSearch chain enqueued on the main stream of context k; returns without waiting for the chain"""
         ci, f0, f1 = unit
         st, en = self.tabs[ci]
-        fr = self.bands[self.names[ci]].frames(st[f0:f1], en[f0:f1])
+        fr = (self.bands2 if k else self.bands)[self.names[ci]].frames(st[f0:f1], en[f0:f1])
         return unit, fr, fr.stripe_search_begin(self.Ms[ci], sigma=self.sigma)
 
     def step(self, digest=None):
-        """Two searches are kept in flight: while the device runs the chain of unit u+1 (and u+2 is queued behind
-        it), the host collects the records of unit u, builds the score inputs and enqueues its p-value /
-        Stripiness kernels -- the single in-order stream never runs dry."""
+        return self.run(1, digest)
+
+    def run(self, nsteps, digest=None):
+        """`nsteps` steps (each: every unit of this rank once).  Two searches are kept in flight: while the device runs the
+        chain of unit u+1 (and u+2 is queued behind it), the host collects the records of unit u, builds the score inputs and
+        enqueues its p-value / Stripiness kernel -- the single in-order stream never runs dry.  The benchmark calls run(1) per
+        step (the pipeline drains at every step's end); with nsteps > 1 (STP_BENCH_PIPELINE_STEPS=1, a diagnostic) the first
+        units of step s + 1 are launched while the last units of step s are collected and scored.  All work is finished when
+        run() returns.  Returns the records and contact pixels of ONE step (every step does the same work)."""
         nrec, px = 0, 0.0
-        todo = list(self.my_units)[::-1]
-        depth = int(os.environ.get('STP_BENCH_FLIGHT', '2'))
+        nu = len(self.my_units)
+        todo = [(s, u) for s in range(nsteps) for u in self.my_units][::-1]
+        nctx = 2 if self.two_ctx else 1
+        depth = int(os.environ.get('STP_BENCH_FLIGHT', '2')) * nctx     # searches in flight: two per context
         tw = time.perf_counter()
-        flight = [self._launch(todo.pop()) for _ in range(min(depth, len(todo)))]
+        flight, nl = [], 0
+        def launch():
+            nonlocal nl
+            sidx, unit = todo.pop()
+            flight.append((sidx, nl % nctx) + self._launch(unit, nl % nctx)); nl += 1
+        for _ in range(min(depth, len(todo))):
+            launch()
         self.host_call_s += time.perf_counter() - tw
         while flight:
-            (ci, f0, f1), fr, pend = flight.pop(0)
+            sidx, k, (ci, f0, f1), fr, pend = flight.pop(0)
             tw = time.perf_counter()
             recs = pend.wait()
             self.host_wait_s += time.perf_counter() - tw           # time the host spent waiting for the device
             if todo:
                 tw = time.perf_counter()
-                flight.append(self._launch(todo.pop()))
+                launch()
                 self.host_call_s += time.perf_counter() - tw       # frame preparation (blocking: S / nz / medpixel come back) + enqueue
             if self.score and self._q is not None:
                 self._q.put((ci, recs, np.array(fr.nz), self.tabs[ci][0][f0:f1]))
             elif self.score:
                 st = self.tabs[ci][0]
-                sband = self.bands[self.names[ci]]
+                hbk = self.hb2 if k else self.hb
+                sband = (self.bands2 if k else self.bands)[self.names[ci]]
                 pv, sc = self.BK.score_inputs(recs, fr.nz, st[f0:f1], self.nbins[ci], self.bs)
                 tw = time.perf_counter()
                 if os.environ.get('STP_BENCH_SCORE_CALLS') == '2':  # (A/B hook: the two separate calls of rounds 1-4)
-                    self.hb.pvalue(sband, self.bs, pv)
-                    self.hb.stripiness(sband, self.EV[ci], sc)
+                    hbk.pvalue(sband, self.bs, pv)
+                    hbk.stripiness(sband, self.EV[ci], sc)
                 else:
-                    self.hb.score(sband, self.bs, self.EV[ci], pv, sc)     # p-value and Stripiness: one upload, one launch, one download
+                    hbk.score(sband, self.bs, self.EV[ci], pv, sc)        # p-value and Stripiness: one upload, one launch, one download
                 self.host_call_s += time.perf_counter() - tw       # one blocking call: copy in, kernel, copy out
             if digest is not None:
                 digest.update(np.ascontiguousarray(recs[:len(recs)]).tobytes())
-            nrec += len(recs)
-            px += float((fr.S.astype(np.float64) ** 2).sum())
+            if sidx == nsteps - 1:                                 # (the figures of one step: the last)
+                nrec += len(recs)
+                px += float((fr.S.astype(np.float64) ** 2).sum())
             fr.close()
         if self._q is not None:
             self._q.join()                      # every candidate of the step is scored
