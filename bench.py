@@ -504,9 +504,12 @@ class _Workload:
         if emulate_rank:
             er, en_ = (int(v) for v in emulate_rank.split('/'))
             my_units = shard.frame_spans(self.nframes, en_)[er]
-        # pipeline stages: pieces of at most one device chunk (3 072 images = 102 frames at 5 levels x 6 brightness), so that
+        # pipeline stages: pieces of at most one device chunk (6 144 images = 204 frames at 5 levels x 6 brightness: round 5), so that
         # filling and draining the two-deep pipeline costs a chunk's latency, not a chromosome's
-        piece = max(1, int(os.environ.get('STP_BENCH_PIECE', '102')))
+        # (a rank's span is cut into at least four stages -- a 1/8 share of the genome, 330 frames, into pieces of 83 -- so that
+        #  filling and draining the pipeline stays a small part of a short step; the whole genome runs in chromosome-size pieces)
+        nfr_rank = sum(f1 - f0 for _, f0, f1 in my_units)
+        piece = max(1, int(os.environ.get('STP_BENCH_PIECE', str(min(204, max(64, -(-nfr_rank // 4)))))))
         self.my_units = [(ci, a, min(a + piece, f1)) for ci, f0, f1 in my_units for a in range(f0, f1, piece)]
         # ---- untimed set-up: every band in HBM, maxpixel quantiles, expected values, background tables
         self.chroms, self.tens, self.bands = {}, {}, {}

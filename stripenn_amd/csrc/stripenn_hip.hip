@@ -2592,8 +2592,12 @@ static int search_enqueue(stp_ctx* ctx, stp_search* s)
     const stp_search_params* prm = &s->prm;
     const int n_levels = s->nlev, nb = prm->n_bright, ipf = n_levels * nb, rcap = s->rcap;
     // (measured: smaller chunks, so that the grey images of a chunk stay in the 256 MB Infinity Cache between k_gray and the
-    //  Canny kernel, lose more to launch tails than they gain: chr16 chain 3.11 ms at 3 072 images, 3.19 / 3.47 / 4.20 at 1 536 / 768 / 384)
-    int chunk = 3072 / ipf;
+    //  Canny kernel, lose more to launch tails than they gain: chr16 chain 3.11 ms at 3 072 images, 3.19 / 3.47 / 4.20 at 1 536 / 768 / 384.
+    //  Round 5, on the faster kernels: 6 144 images per launch -- a whole chromosome of up to 204 frames at 5 levels x 6 images -- instead
+    //  of 3 072: 72.0 -> 70.0 ms per genome step (20 instead of 36 launches of each chain kernel: fewer tails, fewer small stream
+    //  operations between units); 4 608: 70.3, 9 216: 69.9.  3.9 GB of grey workspace.  STP_CHUNK_IMAGES: measurement hook.)
+    static const int chunk_images = getenv("STP_CHUNK_IMAGES") ? std::max(64, atoi(getenv("STP_CHUNK_IMAGES"))) : 6144;
+    int chunk = chunk_images / ipf;
     if (chunk < 1) chunk = 1;
     if (chunk > fr->n) chunk = fr->n;
     const size_t cimg = (size_t)chunk * ipf;
