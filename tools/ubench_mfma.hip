@@ -33,8 +33,10 @@ __global__ void k_num(const float* A /*16x4*/, const float* B /*4x16*/, const fl
     for (int i = 0; i < 4; i++) Z[(4 * g + i) * 16 + n] = z[i];
 }
 
-// role of a wave: its index / 4 < nM -> MFMA loop, else vector loop of kind vop
-template <int VOP>
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+// role of a wave: its index / 4 < nM -> MFMA loop, else vector loop of kind vop.  BF: the MFMA waves issue v_mfma_f32_16x16x32_bf16
+// (the real matrix pipe) instead of v_mfma_f32_16x16x4_f32 -- the control experiment for the co-execution counters
+template <int VOP, bool BF = false>
 __global__ __launch_bounds__(1024) void k_mix(int nM, int iters, float* out, long long* cyc, float a0)
 {
     const int w = threadIdx.x >> 6;
@@ -46,6 +48,16 @@ __global__ __launch_bounds__(1024) void k_mix(int nM, int iters, float* out, lon
         f4 acc[4];
         for (int j = 0; j < 4; j++) acc[j] = f4{a0, a0, a0, a0};
         const float a = a0 + threadIdx.x, b = a0 * 0.5f;
+        if (BF) {
+            bf8 ab, bb;
+            for (int i = 0; i < 8; i++) { ab[i] = (__bf16)(a0 + 0.01f * i); bb[i] = (__bf16)(0.5f * a0); }
+            for (int it = 0; it < iters; it++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, acc[j], 0, 0, 0);
+            }
+        } else
         for (int it = 0; it < iters; it++) {
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -146,15 +158,15 @@ static void numerics()
            badD, badDrev, badY, badZ);
 }
 
-template <int VOP>
+template <int VOP, bool BF = false>
 static void mix(const char* vname, int nM, int nV, float* out, long long* cyc)
 {
     const int waves = 4 * (nM + nV), iters = 4096, blocks = 256;
-    hipLaunchKernelGGL(k_mix<VOP>, dim3(blocks), dim3(64 * waves), 0, 0, nM, iters, out, cyc, 1.0f);
+    hipLaunchKernelGGL((k_mix<VOP, BF>), dim3(blocks), dim3(64 * waves), 0, 0, nM, iters, out, cyc, 1.0f);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    hipLaunchKernelGGL(k_mix<VOP>, dim3(blocks), dim3(64 * waves), 0, 0, nM, iters, out, cyc, 1.0f);
+    hipLaunchKernelGGL((k_mix<VOP, BF>), dim3(blocks), dim3(64 * waves), 0, 0, nM, iters, out, cyc, 1.0f);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     std::vector<long long> h(blocks * 16);
@@ -165,7 +177,7 @@ static void mix(const char* vname, int nM, int nV, float* out, long long* cyc)
     if (nM) cm /= (double)blocks * 4 * nM;
     if (nV) cv /= (double)blocks * 4 * nV;
     // per SIMD: nM waves x iters x 16 MFMAs, nV waves x iters x 16 vector instructions
-    printf("  %d MFMA + %d %-12s waves/SIMD: %.3f ms", nM, nV, vname, ms);
+    printf("  %d %s + %d %-12s waves/SIMD: %.3f ms", nM, BF ? "bf16-MFMA" : "MFMA", nV, vname, ms);
     if (nM) printf(" | MFMA wave %.0f cyc = %.1f cyc per MFMA and SIMD", cm, cm / (iters * 16.0 * nM));
     if (nV) printf(" | vector wave %.0f cyc = %.2f cyc per instruction and SIMD", cv, cv / (iters * 16.0 * nV));
     printf("\n");
@@ -199,6 +211,9 @@ int main()
     mix<1>("v_pk_fma_f32", 0, 2, out, cyc); mix<2>("v_add_f32", 0, 2, out, cyc);
     mix<0>("v_fma_f32", 1, 1, out, cyc); mix<0>("v_fma_f32", 1, 2, out, cyc); mix<0>("v_fma_f32", 1, 3, out, cyc); mix<0>("v_fma_f32", 2, 2, out, cyc);
     mix<1>("v_pk_fma_f32", 1, 2, out, cyc); mix<2>("v_add_f32", 1, 2, out, cyc); mix<2>("v_add_f32", 1, 3, out, cyc);
+    printf("control: v_mfma_f32_16x16x32_bf16 (the matrix pipe proper) beside the same vector waves:\n");
+    mix<0, true>("-", 1, 0, out, cyc); mix<0, true>("v_fma_f32", 1, 1, out, cyc); mix<0, true>("v_fma_f32", 1, 2, out, cyc); mix<0, true>("v_fma_f32", 1, 3, out, cyc);
+    mix<1, true>("v_pk_fma_f32", 1, 2, out, cyc);
     printf("one wave per SIMD, fillers in the MFMA's shadow:\n");
     shadow<0, 0>(out, cyc); shadow<2, 0>(out, cyc); shadow<4, 0>(out, cyc); shadow<6, 0>(out, cyc); shadow<8, 0>(out, cyc); shadow<12, 0>(out, cyc);
     shadow<4, 1>(out, cyc); shadow<8, 1>(out, cyc); shadow<12, 1>(out, cyc);
