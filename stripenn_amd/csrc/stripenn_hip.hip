@@ -1466,20 +1466,49 @@ __global__ __launch_bounds__(256) void k_band_pack(const int64_t* __restrict__ b
                                                     int64_t lo, int64_t nrows, int W, int hw, double* __restrict__ band,
                                                     int32_t* __restrict__ near)
 {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-        int64_t i = bin1[p] - lo, j = (int64_t)bin2[p] - lo;
-        if (i < 0 || j < 0 || i >= nrows || j >= nrows) continue;
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // (whole waves walk the loop together: the trip count is rounded up per wave, lanes beyond the table are masked)
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); p0 < npix; p0 += stride) {
+        const int64_t p = p0 + lane;
+        bool ok = p < npix;
+        int64_t i = 0, j = 0;
+        if (ok) {
+            i = bin1[p] - lo; j = (int64_t)bin2[p] - lo;
+            ok = !(i < 0 || j < 0 || i >= nrows || j >= nrows);
+        }
         if (j < i) { const int64_t t = i; i = j; j = t; }
         const int64_t d = j - i;
-        double v = (double)count[p];
-        if (wloc) v = v * (wloc[i] * wloc[j]);
-        if (v > 0.0) {
-            atomicMin(&near[i], (int32_t)d);                       // row i holds a positive pixel d columns to the right
-            if (d > 0) atomicMin(&near[nrows + j], (int32_t)d);    // row j holds its mirror image d columns to the left
+        double v = 0.0;
+        if (ok) {
+            v = (double)count[p];
+            if (wloc) v = v * (wloc[i] * wloc[j]);
         }
-        if (d > hw) continue;
+        // nearest positive pixel to the right of row i / to the left of row j.  Round 5: the table is sorted by bin1, so the
+        // positive pixels of a wave nearly always share ONE row -- 64 atomics on one address, which the memory system takes one
+        // after the other (3.9 of the kernel's 4.2 ms per 20 M pixels).  The wave reduces its distances first and sends one.
+        const bool pos = ok && v > 0.0;
+#if !defined(STP_ABLATE_PACK) || STP_ABLATE_PACK != 2
+        const unsigned long long act = __ballot(pos);
+        if (act) {
+            const int lead = __ffsll((long long)act) - 1;
+            const int ilead = __shfl((int)i, lead);
+            if (__ballot(pos && (int)i != ilead) == 0ull) {
+                int m = pos ? (int)d : 0x7FFFFFFF;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o));
+                if (lane == lead) atomicMin(&near[ilead], m);
+            } else if (pos) {
+                atomicMin(&near[i], (int32_t)d);                   // (a wave that straddles a row boundary: one per lane, as before)
+            }
+        }
+        if (pos && d > 0) atomicMin(&near[nrows + j], (int32_t)d);    // row j holds the mirror image d columns to the left (distinct addresses within a wave)
+#endif
+        if (!ok || d > hw) continue;
         if (d < hw) band[i * (int64_t)W + (d + hw)] = v;
+#if !defined(STP_ABLATE_PACK) || STP_ABLATE_PACK != 1
         band[j * (int64_t)W + (hw - d)] = v;
+#endif
     }
 }
 
@@ -1632,6 +1661,7 @@ struct stp_ctx {
     hipStream_t io = nullptr;              // band packing and the quantile's order-statistic select: PCIe uploads of the pixel
                                            // table and streaming kernels that must not queue behind the searches in flight
     hipStream_t aux = nullptr;             // frame compaction / medpixel and the per-stripe score kernels: small kernels
+    hipStream_t pk = nullptr;              // the band packer's kernels (round 5): they run beside the next chunk's PCIe copies on `io`
                                            // with a host round trip each, which must not queue behind (and thereby
                                            // drain) the searches in flight on `stream`
     std::string err;
@@ -1830,6 +1860,9 @@ int stp_ctx_create(int device_ordinal, stp_ctx** out)
     if (hipStreamCreateWithFlags(&ctx->io, hipStreamNonBlocking) != hipSuccess) {
         (void)hipStreamDestroy(ctx->aux); (void)hipStreamDestroy(ctx->stream); delete ctx; return STP_E_HIP;
     }
+    if (hipStreamCreateWithFlags(&ctx->pk, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->io); (void)hipStreamDestroy(ctx->aux); (void)hipStreamDestroy(ctx->stream); delete ctx; return STP_E_HIP;
+    }
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
     stp_install_fault_report();
@@ -1853,6 +1886,7 @@ void stp_ctx_destroy(stp_ctx* ctx)
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
     if (ctx->io) { (void)hipStreamSynchronize(ctx->io); (void)hipStreamDestroy(ctx->io); }
+    if (ctx->pk) { (void)hipStreamSynchronize(ctx->pk); (void)hipStreamDestroy(ctx->pk); }
     delete ctx;
 }
 
@@ -2287,7 +2321,14 @@ static int band_pack_impl(stp_ctx* ctx, const int64_t* bin1, const int64_t* off,
     //  runtime's own pageable path; what does pay is pinning the caller's columns IN PLACE for the call: host_pin)
     const int64_t CH = (int64_t)1 << 23;                 // pixels per staged chunk (160 MB of table columns)
     const int64_t nch = npix < CH ? npix : CH;
-    dev_buf b1, b2, bc, bw, bo;
+    // Round 5: two sets of device staging buffers.  The PCIe copies of chunk k + 1 (stream `io`) run beside the kernels of chunk k
+    // (stream `pk`: index expansion, packing, the select's values); events order the two streams and say when a set is free again.
+    const int nset = npix > CH ? 2 : 1;
+    dev_buf b1s[2], b2s[2], bcs[2], bw, bo;
+    struct evpair {
+        hipEvent_t c[2] = {nullptr, nullptr}, k[2] = {nullptr, nullptr}, setup = nullptr;
+        ~evpair() { for (int q = 0; q < 2; q++) { if (c[q]) (void)hipEventDestroy(c[q]); if (k[q]) (void)hipEventDestroy(k[q]); } if (setup) (void)hipEventDestroy(setup); }
+    } ev;
     host_pin pin1, pin2, pinc;                            // (declared after the device buffers: released first)
     if (bin1) pin1.pin(bin1, (size_t)npix * sizeof(int64_t), ctx->io);
     pin2.pin(bin2, (size_t)npix * i2sz, ctx->io);
@@ -2301,45 +2342,60 @@ static int band_pack_impl(stp_ctx* ctx, const int64_t* bin1, const int64_t* off,
         (void)stp_dfree(__LINE__, d); delete b;
         return set_err(ctx, STP_E_NOMEM, "hipMalloc(band nearest-pixel table) failed");
     }
-    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)near, 0x7FFFFFFF, (size_t)nrows * 2, ctx->io);
-    if (e == hipSuccess && nch) e = b1.alloc(ctx, (size_t)nch * sizeof(int64_t));
-    if (e == hipSuccess && nch) e = b2.alloc(ctx, (size_t)nch * i2sz);
-    if (e == hipSuccess && nch) e = bc.alloc(ctx, (size_t)nch * csz);
+    hipError_t e = hipSuccess;
+    for (int q = 0; q < nset && e == hipSuccess; q++) {
+        e = hipEventCreateWithFlags(&ev.c[q], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev.k[q], hipEventDisableTiming);
+        if (e == hipSuccess && nch) e = b1s[q].alloc(ctx, (size_t)nch * sizeof(int64_t));
+        if (e == hipSuccess && nch) e = b2s[q].alloc(ctx, (size_t)nch * i2sz);
+        if (e == hipSuccess && nch) e = bcs[q].alloc(ctx, (size_t)nch * csz);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev.setup, hipEventDisableTiming);
     if (e == hipSuccess && weight) e = bw.alloc(ctx, (size_t)nrows * sizeof(double));
     if (e == hipSuccess && off) e = bo.alloc(ctx, (size_t)(nrows + 1) * sizeof(int64_t));
     if (e == hipSuccess && off) e = x.h2d(bo.p, off, (size_t)(nrows + 1) * sizeof(int64_t));     // the CSR index: 8 bytes per BIN
     if (e == hipSuccess && weight)
         e = x.h2d(bw.p, weight + lo, (size_t)nrows * sizeof(double));
+    if (e == hipSuccess) e = hipEventRecord(ev.setup, ctx->io);          // the small uploads the kernels read
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->pk, ev.setup, 0);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)near, 0x7FFFFFFF, (size_t)nrows * 2, ctx->pk);
     if (e == hipSuccess && weight) {
-        prof_scope ps(ctx, "band_init", (double)bytes, ctx->io);
-        hipLaunchKernelGGL(k_band_init, dim3(256 * 16), dim3(256), 0, ctx->io, (const double*)bw.p, nrows, b->W, hw, d);
+        prof_scope ps(ctx, "band_init", (double)bytes, ctx->pk);
+        hipLaunchKernelGGL(k_band_init, dim3(256 * 16), dim3(256), 0, ctx->pk, (const double*)bw.p, nrows, b->W, hw, d);
         e = hipGetLastError();
     } else if (e == hipSuccess) {
-        e = hipMemsetAsync(d, 0, bytes, ctx->io);
+        e = hipMemsetAsync(d, 0, bytes, ctx->pk);
     }
-    for (int64_t p0 = 0; e == hipSuccess && p0 < npix; p0 += CH) {
+    int64_t kchunk = 0;
+    for (int64_t p0 = 0; e == hipSuccess && p0 < npix; p0 += CH, kchunk++) {
         const int64_t n = npix - p0 < CH ? npix - p0 : CH;
+        const int q = (int)(kchunk % nset);
+        if (kchunk >= nset) e = hipEventSynchronize(ev.k[q]);             // the kernels that read this set two chunks ago are done
+        if (e != hipSuccess) break;
         // (measured and dropped in round 4: bin2_id on a second upload stream, i.e. a second copy engine -- the 5.3 GB of the
         //  mm10-size table took the same 0.15-0.16 s: ~35 GB/s is what this host's memory feeds the link)
-        if (bin1) e = up(pin1, b1.p, bin1 + p0, (size_t)n * sizeof(int64_t));
-        else {      // bin1_id of this chunk's pixels from the CSR index, on the device
+        if (bin1) e = up(pin1, b1s[q].p, bin1 + p0, (size_t)n * sizeof(int64_t));
+        if (e == hipSuccess) e = up(pin2, b2s[q].p, bin2 + (size_t)p0 * i2sz, (size_t)n * i2sz);
+        if (e == hipSuccess) e = up(pinc, bcs[q].p, count + (size_t)p0 * csz, (size_t)n * csz);
+        if (e == hipSuccess) e = hipEventRecord(ev.c[q], ctx->io);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->pk, ev.c[q], 0);
+        if (e != hipSuccess) break;
+        if (!bin1) {      // bin1_id of this chunk's pixels from the CSR index, on the device
             const int64_t* hi_it = std::upper_bound(off, off + nrows + 1, p0);                    // first row starting beyond p0
             const int64_t r_lo = std::max<int64_t>(0, (hi_it - off) - 1);
             const int64_t r_hi = std::min<int64_t>(nrows - 1, (std::lower_bound(off, off + nrows + 1, p0 + n) - off) - 1);
             if (r_hi >= r_lo)
-                hipLaunchKernelGGL(k_expand_bin1, dim3((unsigned)std::min<int64_t>((r_hi - r_lo + 4) / 4, 4096)), dim3(256), 0, ctx->io,
-                                   (const int64_t*)bo.p, r_lo, r_hi, lo, p0, n, (int64_t*)b1.p);
+                hipLaunchKernelGGL(k_expand_bin1, dim3((unsigned)std::min<int64_t>((r_hi - r_lo + 4) / 4, 4096)), dim3(256), 0, ctx->pk,
+                                   (const int64_t*)bo.p, r_lo, r_hi, lo, p0, n, (int64_t*)b1s[q].p);
             e = hipGetLastError();
+            if (e != hipSuccess) break;
         }
-        if (e == hipSuccess) e = up(pin2, b2.p, bin2 + (size_t)p0 * i2sz, (size_t)n * i2sz);
-        if (e == hipSuccess) e = up(pinc, bc.p, count + (size_t)p0 * csz, (size_t)n * csz);
-        if (e != hipSuccess) break;
         {
-            prof_scope ps(ctx, "band_pack", (double)n * 36.0, ctx->io);    // 20 B of table read + two 8 B cells written
+            prof_scope ps(ctx, "band_pack", (double)n * 36.0, ctx->pk);    // 20 B of table read + two 8 B cells written
             const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 256 * 64);
 #define STP_PACK(CT, I2)                                                                                                                    \
-            hipLaunchKernelGGL((k_band_pack<CT, I2>), dim3(grid), dim3(256), 0, ctx->io, (const int64_t*)b1.p, (const I2*)b2.p, (const CT*)bc.p, n, \
-                               weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d, near)
+            hipLaunchKernelGGL((k_band_pack<CT, I2>), dim3(grid), dim3(256), 0, ctx->pk, (const int64_t*)b1s[q].p, (const I2*)b2s[q].p,    \
+                               (const CT*)bcs[q].p, n, weight ? (const double*)bw.p : nullptr, lo, nrows, b->W, hw, d, near)
             if (count_type == STP_COUNT_F64) { if (id2_type == STP_ID_I32) STP_PACK(double, int32_t); else STP_PACK(double, int64_t); }
             else { if (id2_type == STP_ID_I32) STP_PACK(int32_t, int32_t); else STP_PACK(int32_t, int64_t); }
 #undef STP_PACK
@@ -2351,10 +2407,11 @@ static int band_pack_impl(stp_ctx* ctx, const int64_t* bin1, const int64_t* off,
             double* vals = nullptr;
             e = pool_alloc(ctx, (size_t)n * 2 * sizeof(double), (void**)&vals);
             if (e == hipSuccess) {
-                prof_scope ps(ctx, "select_pixels", 36.0 * n, ctx->io);
+                prof_scope ps(ctx, "select_pixels", 36.0 * n, ctx->pk);
 #define STP_SELV(CT, I2)                                                                                                                    \
-                hipLaunchKernelGGL((k_sel_pixel_values<CT, I2>), dim3(sel_grid(n)), dim3(256), 0, ctx->io, (const int64_t*)b1.p, (const I2*)b2.p, \
-                                   (const CT*)bc.p, (long long)n, weight ? (const double*)bw.p : nullptr, (long long)nrows, vals, (long long)lo)
+                hipLaunchKernelGGL((k_sel_pixel_values<CT, I2>), dim3(sel_grid(n)), dim3(256), 0, ctx->pk, (const int64_t*)b1s[q].p,        \
+                                   (const I2*)b2s[q].p, (const CT*)bcs[q].p, (long long)n, weight ? (const double*)bw.p : nullptr,           \
+                                   (long long)nrows, vals, (long long)lo)
                 if (count_type == STP_COUNT_F64) { if (id2_type == STP_ID_I32) STP_SELV(double, int32_t); else STP_SELV(double, int64_t); }
                 else { if (id2_type == STP_ID_I32) STP_SELV(int32_t, int32_t); else STP_SELV(int32_t, int64_t); }
 #undef STP_SELV
@@ -2363,9 +2420,12 @@ static int band_pack_impl(stp_ctx* ctx, const int64_t* bin1, const int64_t* off,
                 sel->npos = -1;
             }
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->io);      // the staging buffers are reused
+        if (e == hipSuccess) e = hipEventRecord(ev.k[q], ctx->pk);
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->io);
+    {   // both streams drained before anything is released or handed on (also on the error path: the staging sets go back to the pool)
+        const hipError_t e1 = hipStreamSynchronize(ctx->pk), e2 = hipStreamSynchronize(ctx->io);
+        if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
+    }
     if (e != hipSuccess) {
         (void)stp_dfree(__LINE__, d); (void)stp_dfree(__LINE__, near); delete b;
         return set_err(ctx, e == hipErrorOutOfMemory ? STP_E_NOMEM : STP_E_HIP, std::string("band pack: ") + hipGetErrorString(e));
