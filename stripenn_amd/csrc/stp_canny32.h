@@ -163,6 +163,13 @@ STP_HD void c32_fma2(float p0, float p1, float w, float* a0, float* a1)
 // ---- vertical pass, one item = column xx of the tile window x C32_VRUN_R(R) output rows from yy0 (as canny_p1_item, with
 // its own run length: f32 windows are half the registers of k_canny_pipe's f64 ones).  Numbering as ct_p1_decode:
 // in-image columns first, then one zero-fill item per (outside column, row group). ----
+// Pitch (floats) of k_canny_f32's transposed vertical-pass tile.  The horizontal pass numbers its items (row, run) with the 36
+// rows fastest, so a 32-lane group of an LDS read covers the tail of one run's rows and the head of the next run's, whose
+// column is HRUN columns on: with HRUN x pitch = 36 (mod 32 banks) the second part continues the first part's bank sequence
+// -- 10 x 42 = 420 = 13 x 32 + 4 -- where CT_VP = 37 put it 18 banks on, on top of the first part (round 5: a third of that
+// pass's LDS cycles were conflicts).  The pitch is even, so the vertical pass stores its output pairs as one 8-byte word.
+// (radii 10 and 12 -- runs of 5 -- would need a pitch of 52: they keep CT_VP.)
+#define C32_VP_R(R) ((R) <= 8 ? CT_Y + 10 : CT_VP)
 #define C32_VRUN_R(R) ((R) <= 8 ? 12 : 6)      /* output rows per item: the window of VRUN + 2R rows must fit the registers of
                                                   five waves per SIMD (96): 28 at radius 8, 26 / 30 at radii 10 / 12 */
 struct stp_c32geo1 { int c_lo, ncv, nzc, ng, vrun; };
@@ -200,7 +207,7 @@ STP_HD void c32_p1_zero(int xx, int yy0, float* sVT)
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int q = 0; q < C32_VRUN_R(R); q++) sVT[xx * CT_VP + yy0 + q] = 0.0f;
+    for (int q = 0; q < C32_VRUN_R(R); q++) sVT[xx * C32_VP_R(R) + yy0 + q] = 0.0f;
 }
 // (guard bytes around the grey images: see canny_p1_item.)  On the device the element addresses are formed as the image's
 // wave-uniform base + a 32-bit byte offset per lane (an image is 640 000 bytes), so the loads take the scalar-base form
@@ -256,8 +263,16 @@ STP_HD void c32_p1_item(stp_tile T, int xx, int yy0, const stp_w32& W, const flo
             if (!(y >= 0 && y < T.S)) a0 = 0.0f;
             if (!(y + 1 >= 0 && y + 1 < T.S)) a1 = 0.0f;
         }
-        sVT[xx * CT_VP + yy0 + q] = a0;
-        sVT[xx * CT_VP + yy0 + q + 1] = a1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (C32_VP_R(R) % 2 == 0 && VRUN % 2 == 0) {        // (yy0 is a multiple of VRUN, the tile 16-byte aligned)
+            typedef float stp_f2 __attribute__((ext_vector_type(2)));
+            *(stp_f2*)__builtin_assume_aligned(sVT + xx * C32_VP_R(R) + yy0 + q, 8) = (stp_f2){a0, a1};
+        } else
+#endif
+        {
+            sVT[xx * C32_VP_R(R) + yy0 + q] = a0;
+            sVT[xx * C32_VP_R(R) + yy0 + q + 1] = a1;
+        }
     }
 }
 template <int R, bool YIN>
@@ -305,7 +320,7 @@ STP_HD void c32_p2_item(stp_tile T, int yy, int xx0, const stp_w32& W, const flo
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int k = 0; k < HRUN + 2 * R; k++) win[k] = sVT[(xx0 + k) * CT_VP + yy];
+    for (int k = 0; k < HRUN + 2 * R; k++) win[k] = sVT[(xx0 + k) * C32_VP_R(R) + yy];
     const float rb = XIN ? sRB[yy] : sRV[yy];
     float* srow = sS + yy * C32_SP + xx0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -429,6 +444,11 @@ STP_HD int c32_nms_E(const float* sS, const float* sM, stp_tile T, int y, int x,
     float gi, gj;
     c32_sobel(sS + (y - (T.ty0 - 2)) * C32_SP + (x - (T.tx0 - 2)), &gi, &gj);
     const float ai = fabsf(gi), aj = fabsf(gj);
+    // (round 5, measured and dropped: where exactly ONE of the three questions is open the reference used one of the two
+    //  sectors that meet there, so evaluating both and accepting an agreeing verdict decides a quarter of the pixels that go to
+    //  the resolver -- class maps identical, diagonal step edges no longer need the resolver at all -- but the kernel's time did
+    //  not move (the resolver costs a tile one pixel's latency whether it settles one pixel or three) and the extra code cost
+    //  radii 4 and 12 a wave of occupancy.)
     if (ai <= E.Eg || aj <= E.Eg || fabsf(ai - aj) <= 2.0f * E.Eg) return 3;      // a sign or the octant could differ
     const bool same = (gi > 0.0f) == (gj > 0.0f), ibig = ai > aj;
     const float num = ibig ? aj : ai, den = ibig ? ai : aj;

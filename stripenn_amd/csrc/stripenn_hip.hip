@@ -798,7 +798,7 @@ static __host__ __device__ stp_c32_layout canny32_layout(int R)
     L.sRC = o; o += (size_t)C32_SP * sizeof(float);
     L.sS = o; o += (size_t)VH * C32_SP * sizeof(float);      // smoothed tile (at the end: the resolver's per-wave scratch)
     L.sV = o;                                                 // vertical-pass tile | magnitude tile + candidate queue
-    const size_t v = (size_t)(CT_P2_COLS(R) > GW ? CT_P2_COLS(R) : GW) * CT_VP * sizeof(float);
+    const size_t v = (size_t)(CT_P2_COLS(R) > GW ? CT_P2_COLS(R) : GW) * C32_VP_R(R) * sizeof(float);
     const size_t mq = (size_t)(CT_Y + 2) * (CT_X + 2) * sizeof(float);
     L.sQ = o + mq;
     const size_t m = mq + 4 * C32_QSEG * sizeof(uint16_t);

@@ -223,7 +223,7 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
     memcpy(gpad.data() + guard, gray_in, npx * sizeof(float));
     const float* gray = gpad.data() + guard;
     const int GW = ct_gw(R), GH = CT_Y + 2 * R + 4, VH = CT_Y + 4;
-    std::vector<float> sG(GH * GW), sV((VH * GW > GW * CT_VP ? VH * GW : GW * CT_VP) + 8 * CT_VP);   // + the horizontal pass's padding columns
+    std::vector<float> sG(GH * GW), sV((VH * GW > GW * (CT_Y + 10) ? VH * GW : GW * (CT_Y + 10)) + 8 * (CT_Y + 10));   // + the horizontal pass's padding columns
     std::vector<double> sB(2 * VH), sS(VH * CT_SP);
     std::vector<float> sM((CT_Y + 2) * (CT_X + 2));
     std::vector<uint8_t> sC(CT_Y * CT_X);
