@@ -1251,13 +1251,20 @@ __global__ __launch_bounds__(512, RCAP == STP_RCAP ? 6 : 4) void k_lines(const s
         const int nitem = ((S + STP_HYST_STRIP - 1) / STP_HYST_STRIP) * STP_NW;       // <= 350 < blockDim
         const bool has = tid < nitem;
         stp_hyst_item hit;
-        hyst_item_load(has ? tid : 0, S, bufA, bufB, &hit);
+        static_assert((((STP_FRAME_MAX + STP_HYST_STRIP - 1) / STP_HYST_STRIP) * STP_NW + 1) * sizeof(uint16_t) <= sizeof(lrec),
+                      "the items' edge bits fit the record slots");
+        uint16_t* sEdge = (uint16_t*)lrec;             // the items' edge bits (hyst_edge_bits): no record exists before the grouping.
+                                                       // (not cnt[]: &cnt[tid] is formed again for the column statistics, and the compiler
+                                                       //  kept the common address alive across the whole kernel -- one spilled register)
+        hyst_item_load(has ? tid : 0, S, bufA, bufB, &hit, sEdge);
+        if (tid == 0) sEdge[nitem] = 0;                // neighbours beyond the image
+        __syncthreads();
         // (measured and dropped in round 5: an item sweeping again only if it or one of its eight neighbours changed in the previous
         //  sweep -- images need 5 sweeps on average, profiles/r05_hyst_sweeps.txt -- 11.2 -> 11.1 ms per step: a wave holds nine strips
         //  over the full width and almost always has a changed item in or next to its band, so whole waves rarely sit a sweep out)
         int sweeps = 0;
         for (int it = 0; it < 4 * STP_FRAME_MAX * STP_FRAME_MAX; it++) {
-            const int ch = has ? hyst_item_sweep(S, &hit, bufA, bufB) : 0;
+            const int ch = has ? hyst_item_sweep(S, &hit, bufA, bufB, sEdge) : 0;
             sweeps++;
             if (!__syncthreads_or(ch)) break;
         }

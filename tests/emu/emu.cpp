@@ -338,10 +338,11 @@ int emu_lines(const stp_u64* low, const stp_u64* high, const double* band, int W
     {   // k_lines' register form: every item keeps its rows across sweeps (items run in lane order here)
         const int nitem = ((S + STP_HYST_STRIP - 1) / STP_HYST_STRIP) * STP_NW;
         std::vector<stp_hyst_item> items(nitem);
-        for (int i = 0; i < nitem; i++) hyst_item_load(i, S, buf0.data(), buf1.data(), &items[i]);
+        std::vector<uint16_t> edge(nitem + 1, 0);       // the items' published edge bits; slot nitem = beyond the image
+        for (int i = 0; i < nitem; i++) hyst_item_load(i, S, buf0.data(), buf1.data(), &items[i], edge.data());
         for (;;) {
             int ch = 0;
-            for (int i = 0; i < nitem; i++) ch |= hyst_item_sweep(S, &items[i], buf0.data(), buf1.data());
+            for (int i = 0; i < nitem; i++) ch |= hyst_item_sweep(S, &items[i], buf0.data(), buf1.data(), edge.data());
             if (!ch) break;
             sweeps++;
         }
