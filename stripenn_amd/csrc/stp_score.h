@@ -559,40 +559,46 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
 #define SW_WAVES 4
 
 // stp_pw_leaf with its loads in batches of eight (the values of a batch are requested before the first is added: one memory
-// round trip per batch instead of one per element); same additions in the same order.
-template <class F>
-__device__ __forceinline__ double sw_pw_leaf(F get, int64_t o, int n)
+// round trip per batch instead of one per element); same additions in the same order.  An element comes in two steps --
+// `load(k)`: the memory access alone, `val(k, raw)`: what is added -- so that the short leaves and the tails (up to seven
+// elements behind wave-uniform tests; most blocks of a candidate stripe are 3 .. 10 columns wide) also have all their loads in
+// flight together: as one functor each element's NaN test sat next to its load, inside the element's own branch, and the
+// loads of a tail went out one round trip after the other (round 5, seen in the listing).
+template <class L, class V>
+__device__ __forceinline__ double sw_pw_leaf(L load, V val, int64_t o, int n)
 {
     if (n < 8) {
         double v[7];
 #pragma unroll
-        for (int i = 0; i < 7; i++) v[i] = (i < n) ? get(o + i) : 0.0;
+        for (int i = 0; i < 7; i++) v[i] = (i < n) ? load(o + i) : 0.0;
         double res = 0.;
 #pragma unroll
         for (int i = 0; i < 7; i++)
-            if (i < n) res += v[i];
+            if (i < n) res += val(o + i, v[i]);
         return res;
     }
     double r[8];
 #pragma unroll
-    for (int t = 0; t < 8; t++) r[t] = get(o + t);
+    for (int t = 0; t < 8; t++) r[t] = load(o + t);
+#pragma unroll
+    for (int t = 0; t < 8; t++) r[t] = val(o + t, r[t]);
     int i;
     for (i = 8; i < n - (n % 8); i += 8) {
         double v[8];
 #pragma unroll
-        for (int t = 0; t < 8; t++) v[t] = get(o + i + t);
+        for (int t = 0; t < 8; t++) v[t] = load(o + i + t);
 #pragma unroll
-        for (int t = 0; t < 8; t++) r[t] += v[t];
+        for (int t = 0; t < 8; t++) r[t] += val(o + i + t, v[t]);
     }
     double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
     {
         const int m = n - i;                                    // 0 .. 7 tail values, in order
         double v[7];
 #pragma unroll
-        for (int t = 0; t < 7; t++) v[t] = (t < m) ? get(o + i + t) : 0.0;
+        for (int t = 0; t < 7; t++) v[t] = (t < m) ? load(o + i + t) : 0.0;
 #pragma unroll
         for (int t = 0; t < 7; t++)
-            if (t < m) res += v[t];
+            if (t < m) res += val(o + i + t, v[t]);
     }
     return res;
 }
@@ -725,8 +731,9 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_score_wave(stp_bandref B, con
 #pragma unroll
             for (int p = 0; p < 3; p++) {
                 const int n = (int)(hi[p] - lo[p]);
-                if (tr) part[p] = sw_pw_leaf([&](int64_t k) { const double v = colp[k * cstep]; return (v != v) ? 0.0 : v; }, lo[p], n) / (double)n;
-                else part[p] = sw_pw_leaf([&](int64_t k) { const double v = rowp[k]; return (v != v) ? 0.0 : v; }, lo[p], n) / (double)n;
+                auto nan0 = [](int64_t, double v) { return (v != v) ? 0.0 : v; };
+                if (tr) part[p] = sw_pw_leaf([&](int64_t k) { return colp[k * cstep]; }, nan0, lo[p], n) / (double)n;
+                else part[p] = sw_pw_leaf([&](int64_t k) { return rowp[k]; }, nan0, lo[p], n) / (double)n;
             }
             dv[2 * q] = part[0] - part[1]; dv[2 * q + 1] = part[0] - part[2];
             int d, tab;
@@ -785,9 +792,14 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_score_wave(stp_bandref B, con
         // one pixel of block b: observed / (expected + 1e-8); a masked pixel is NaN (:701-707)
         const int cmin = min(s.col0[0], min(s.col0[1], s.col0[2]));
         const bool tr = B.sym && (s.row1 - 1 - cmin < B.hw);            // as above, for the three blocks
-        auto obs = [&](int b, int r, int c) -> double {
-            const int64_t gr = (int64_t)s.row0 + r, gc = (int64_t)s.col0[b] + c;
-            return tr ? B.d[gc * (int64_t)B.W + (gr - gc + B.hw)] : B.d[gr * (int64_t)B.W + (gc - gr + B.hw)];
+        // Pixel (r, c) of block b = obs_row(b, r)[c * cs]: the row's first pixel and ONE wave-uniform element stride (W - 1 through
+        // the symmetry, 1 in the band's own rows).  (round 5: formed per element -- a 64-bit product of a column number the
+        // compiler could not know to be wave-uniform and the tr / non-tr choice by selects -- the address took ~28 vector
+        // instructions per pixel, three of them quarter-rate integer multiplies; now one scalar product and one 64-bit add.)
+        const int64_t cs = tr ? (int64_t)B.W - 1 : 1;
+        auto obs_row = [&](int b, int r) -> const double* {
+            const int64_t gr = (int64_t)s.row0 + r, c0 = (int64_t)s.col0[b];
+            return tr ? B.d + c0 * (int64_t)B.W + (gr - c0 + B.hw) : B.d + gr * (int64_t)B.W + (c0 - gr + B.hw);
         };
         auto exv = [&](int b, int r, int c) -> double {
             int ix = (s.ex0[b] + c) - (s.ey0 + r);
@@ -808,12 +820,13 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_score_wave(stp_bandref B, con
                 for (int q = 0; q < nq && found != 15u; q++) {
                     const int r = lane + 64 * q;
                     const bool ron = r < h && !(r >= s.mrow0 && r <= s.mrow1);
+                    const double* orow = obs_row(b, ron ? r : 0);
                     double o[4], e[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const int c = c0 + u;
                         const bool con = ron && c < w && !(c >= s.mcol0[b] && c <= s.mcol1[b]);
-                        o[u] = con ? obs(b, r, c) : NAN;
+                        o[u] = con ? orow[(int64_t)c * cs] : NAN;
                         e[u] = con ? exv(b, r, c) : 1.0;
                     }
 #pragma unroll
@@ -877,10 +890,16 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_score_wave(stp_bandref B, con
                 for (int b = 0; b < 3; b++) {
                     const int n = nkc[b];
                     const bool full = n == wb[b];                // no column deleted: kept column k is column k
-                    const double sum = sw_pw_leaf([&](int64_t k) {
-                        const int c = full ? (int)k : (int)keepc[b][k];
+                    const double* orow = obs_row(b, r);
+                    // (the column of kept column k is the same for every lane: a scalar, so that its products are scalar too)
+                    auto colof = [&](int64_t k) { return full ? (int)k : __builtin_amdgcn_readfirstlane((int)keepc[b][k]); };
+                    const double sum = sw_pw_leaf([&](int64_t k) {                       // the observed pixel (0 under the mask: never read)
+                        const int c = colof(k);
+                        return (rmask || (c >= s.mcol0[b] && c <= s.mcol1[b])) ? 0.0 : orow[(int64_t)c * cs];
+                    }, [&](int64_t k, double o) {
+                        const int c = colof(k);
                         if (rmask || (c >= s.mcol0[b] && c <= s.mcol1[b])) return 0.0;
-                        const double v = obs(b, r, c) / exv(b, r, c);
+                        const double v = o / exv(b, r, c);
                         return (v != v) ? 0.0 : v;
                     }, 0, n);
                     const double mean = sum / (double)n;

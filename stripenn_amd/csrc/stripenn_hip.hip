@@ -37,6 +37,17 @@
 // (frame preparation -- zero-column removal and medpixel of every frame -- is k_frame_prep in stp_score.h)
 
 // K-A: image build + brightness + mean blur + grey for all brightness levels of one tile.
+// Lane exchanges inside a row of 16 lanes without LDS traffic (DPP): the value of lane ^ 8, ^ 4, ^ 2, ^ 1.  Every lane of the wave
+// must be active.  Used by k_lines' bit transposes and by the 16-lane cell reductions of k_gray_c3.
+__device__ __forceinline__ unsigned wt_dpp_xor8(unsigned w) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x128, 0xF, 0xF, false); }   // row_ror:8
+__device__ __forceinline__ unsigned wt_dpp_xor4(unsigned w)
+{
+    int p = __builtin_amdgcn_update_dpp(0, (int)w, 0x104, 0xF, 0x5, false);         // row_shl:4 -> banks 0, 2 (lane bit 2 clear) read lane + 4
+    return (unsigned)__builtin_amdgcn_update_dpp(p, (int)w, 0x114, 0xF, 0xA, false);  // row_shr:4 -> banks 1, 3 read lane - 4
+}
+__device__ __forceinline__ unsigned wt_dpp_xor2(unsigned w) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xF, 0xF, false); }    // quad_perm:[2,3,0,1]
+__device__ __forceinline__ unsigned wt_dpp_xor1(unsigned w) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, false); }    // quad_perm:[1,0,3,2]
+
 template <int AMAX>
 __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, int W, int hw,
                                                const int32_t* __restrict__ fstart, const int32_t* __restrict__ fS,
@@ -179,6 +190,10 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
     constexpr int HH = GT_Y + 2, WW = GT_X + 2, N = HH * WW, IT = (N + 255) / 256;
     __shared__ double sg[N], sd[N];
     __shared__ int16_t s_ny[HH], s_nx[WW];
+    constexpr int NCB = 16;
+    __shared__ double s_cb[NCB];                 // (1 / b) (1 / 9) of every brightness level: one division per workgroup and level
+                                                 // instead of one per image and lane (round 5: the division sequence, with its
+                                                 // quarter-rate reciprocal, was a tenth of the image loop's cycles)
     const int fl = blockIdx.z, f = f0 + fl;
     const int S = fS[f];
     if (S == 0) return;
@@ -187,6 +202,7 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
     T.S = S; T.ty0 = (blockIdx.x / tpr) * GT_Y; T.tx0 = (blockIdx.x % tpr) * GT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
     const int tid = threadIdx.x;
+    if (tid >= 128 && tid < 128 + NCB && tid - 128 < nb) s_cb[tid - 128] = stp_gray_cb(bvals[tid - 128]);   // (read after the barriers below)
     const int16_t* nzf = fnz + (size_t)f * STP_FRAME_MAX;
     if (tid < HH) s_ny[tid] = nzf[stp_refl101(min(T.ty0 + tid - 1, S), S)];
     if (tid >= 64 && tid < 64 + WW) s_nx[tid - 64] = nzf[stp_refl101(min(T.tx0 + (tid - 64) - 1, S), S)];
@@ -233,7 +249,7 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
         for (int bi = 0; bi < nb; bi++) {
             const size_t img = ((size_t)fl * nlev + lev) * nb + bi;
             float* gimg = gray + img * (size_t)(STP_PITCH * STP_PITCH) + (size_t)y0 * STP_PITCH + x;
-            const double b = bvals[bi], cb = stp_gray_cb(b);
+            const double b = bvals[bi], cb = bi < NCB ? s_cb[bi] : stp_gray_cb(b);
             float out[GS_ROWS];
             unsigned far = 0xFFFFFFFFu;
             double rs0 = 0.0, rs1 = 0.0;
@@ -276,11 +292,12 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
                 }
             }
             // min / max of the strip's grey values per 16-column cell (see STP_FLAT_RANGE)
-#pragma unroll
-            for (int o = 1; o < GC_CX; o <<= 1) {
-                vmn = min(vmn, (unsigned)__shfl_xor((int)vmn, o));
-                vmx = max(vmx, (unsigned)__shfl_xor((int)vmx, o));
-            }
+            // (round 5: DPP row exchanges instead of four dependent ds_bpermute round trips per image -- all 64 lanes are active here)
+            static_assert(GC_CX == 16, "a cell is one DPP row of 16 lanes");
+            vmn = min(vmn, wt_dpp_xor1(vmn)); vmx = max(vmx, wt_dpp_xor1(vmx));
+            vmn = min(vmn, wt_dpp_xor2(vmn)); vmx = max(vmx, wt_dpp_xor2(vmx));
+            vmn = min(vmn, wt_dpp_xor4(vmn)); vmx = max(vmx, wt_dpp_xor4(vmx));
+            vmn = min(vmn, wt_dpp_xor8(vmn)); vmx = max(vmx, wt_dpp_xor8(vmx));
             const int crow = T.ty0 / GC_CY + strip, ccol = (T.tx0 + lane) / GC_CX;
             if (cells && (lane & (GC_CX - 1)) == 0 && crow < GC_ROWS && ccol < GC_COLS)
                 cells[(img * GC_ROWS + crow) * GC_COLS + ccol] = make_float2(__uint_as_float(vmn), __uint_as_float(vmx));
@@ -1052,14 +1069,6 @@ struct stp_drec {
 // merges half-words with one v_perm_b32 whose selector depends on the lane's side; stages 8 .. 1 stay inside a row of 16
 // lanes: the partner's word arrives by a DPP move (row_ror:8, row_shl:4 / row_shr:4 by bank, quad_perm), stage 8 merges bytes by
 // v_perm_b32, stages 4 .. 1 rotate the partner's word into place (v_alignbit_b32) and insert it under a mask (v_bfi_b32).
-__device__ __forceinline__ unsigned wt_dpp_xor8(unsigned w) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x128, 0xF, 0xF, false); }   // row_ror:8
-__device__ __forceinline__ unsigned wt_dpp_xor4(unsigned w)
-{
-    int p = __builtin_amdgcn_update_dpp(0, (int)w, 0x104, 0xF, 0x5, false);         // row_shl:4 -> banks 0, 2 (lane bit 2 clear) read lane + 4
-    return (unsigned)__builtin_amdgcn_update_dpp(p, (int)w, 0x114, 0xF, 0xA, false);  // row_shr:4 -> banks 1, 3 read lane - 4
-}
-__device__ __forceinline__ unsigned wt_dpp_xor2(unsigned w) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xF, 0xF, false); }    // quad_perm:[2,3,0,1]
-__device__ __forceinline__ unsigned wt_dpp_xor1(unsigned w) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, false); }    // quad_perm:[1,0,3,2]
 // one word of a stage j <= 4: lanes with bit j clear keep their bits under m and take the partner's bits under m, moved up
 // by j; lanes with the bit set keep their bits under m << j (= ~m) and take the partner's bits under ~m, moved down by j
 __device__ __forceinline__ unsigned wt_bits(unsigned w, unsigned p, unsigned rot /* 32 - j | j */, unsigned ins /* ~m | m */)
