@@ -222,8 +222,11 @@ __device__ double block_median(const double* vals, int n, double* s_res)
 // Background rows sorted once per upload (ascending, NaN last): the rank "#(b >= x)" of :599-600
 // becomes nvalid - lower_bound(x).  One workgroup per table row, bitonic sort of <= 2048 values in LDS.
 #define STP_BG_MAXCOL 2048
+// `sorted_t` (round 5, may be null): the same sorted rows with the ROW index fastest -- element (table, column, row) at
+// (table * ncol + column) * STP_NDIAG + row.  k_score_wave's lanes search consecutive rows in lock step: in this layout the
+// first steps of all lanes (equal or neighbouring pivots) read one or a few cache lines instead of 64.
 __global__ __launch_bounds__(512) void k_bg_sort(const double* __restrict__ bg, int ncol, double* __restrict__ sorted,
-                                                  int* __restrict__ nvalid)
+                                                  int* __restrict__ nvalid, double* __restrict__ sorted_t)
 {
     __shared__ double v[STP_BG_MAXCOL];
     __shared__ int s_nv;
@@ -251,6 +254,10 @@ __global__ __launch_bounds__(512) void k_bg_sort(const double* __restrict__ bg, 
             __syncthreads();
         }
     for (int i = threadIdx.x; i < ncol; i += blockDim.x) sorted[row * ncol + i] = v[i];
+    if (sorted_t) {
+        const size_t tab = row / STP_NDIAG, d = row - tab * STP_NDIAG;
+        for (int i = threadIdx.x; i < ncol; i += blockDim.x) sorted_t[(tab * ncol + i) * STP_NDIAG + d] = v[i];
+    }
     if (threadIdx.x == 0) nvalid[row] = s_nv;
 }
 
@@ -610,25 +617,67 @@ __device__ __forceinline__ void sw_sync()
 }
 // Order statistics k0 <= k1 of arr[0..n) (this wave's LDS array): *r0 / *r1 = a value v with #(< v) <= k < #(<= v), 0.0 when
 // there is none -- block_median's rule; NaN entries are never counted and never chosen.  All lanes must call.
+// Round 5: selection by pivoting on wave-uniform masks.  Every lane holds its (up to SW_KR) elements in registers; the pivot is
+// the first element still in play (v_readlane, no LDS round trip), two ballots per chunk count the elements below and equal to
+// it, and the set in play shrinks to one side: ~2 ln n rounds of ~20 instructions instead of testing the candidates one LDS
+// read after the other (n / 2 .. n dependent reads; a fifth of the kernel's time in the round's ablation).  The value of an
+// order statistic does not depend on how it is found.
+template <int SW_KR>
+__device__ __forceinline__ double sw_kth(const double* m, const unsigned long long* act, int k)
+{
+    unsigned long long a[SW_KR];
+#pragma unroll
+    for (int q = 0; q < SW_KR; q++) a[q] = act[q];
+    for (int round = 0; round < 64 * SW_KR + 1; round++) {      // (every round removes at least the pivot: the bound is never reached)
+        double v = 0.0;
+        bool have = false;
+#pragma unroll
+        for (int q = 0; q < SW_KR; q++)
+            if (!have && a[q] != 0ull) {                        // wave-uniform
+                const int lp = __ffsll((long long)a[q]) - 1;
+                v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m[q]), lp), __builtin_amdgcn_readlane(__double2loint(m[q]), lp));
+                have = true;
+            }
+        if (!have) return 0.0;                                  // k beyond the elements that count
+        unsigned long long L[SW_KR], E[SW_KR];
+        int nl = 0, ne = 0;
+#pragma unroll
+        for (int q = 0; q < SW_KR; q++) {
+            L[q] = __ballot(m[q] < v) & a[q];
+            E[q] = __ballot(m[q] == v) & a[q];
+            nl += __popcll(L[q]); ne += __popcll(E[q]);
+        }
+        if (k < nl) {
+#pragma unroll
+            for (int q = 0; q < SW_KR; q++) a[q] = L[q];
+        } else if (k < nl + ne) {
+            return v;
+        } else {
+            k -= nl + ne;
+#pragma unroll
+            for (int q = 0; q < SW_KR; q++) a[q] &= ~(L[q] | E[q]);
+        }
+    }
+    return 0.0;
+}
 template <int SW_KR>
 __device__ __forceinline__ void sw_select(const double* arr, int n, int k0, int k1, int lane, double* r0, double* r1)
 {
     double m[SW_KR];
+    unsigned long long act[SW_KR];
     const int nq = (n + 63) >> 6;
 #pragma unroll
-    for (int q = 0; q < SW_KR; q++) { const int j = lane + 64 * q; m[q] = (q < nq && j < n) ? arr[j] : NAN; }
-    double a = 0.0, b = 0.0;
-    bool fa = false, fb = false;
-    for (int k = 0; k < n && !(fa && fb); k++) {               // wave-uniform
-        const double v = arr[k];
-        int less = 0, leq = 0;
-#pragma unroll
-        for (int q = 0; q < SW_KR; q++)
-            if (q < nq) { less += __popcll(__ballot(m[q] < v)); leq += __popcll(__ballot(m[q] <= v)); }
-        if (less <= k0 && k0 < leq) { a = v; fa = true; }
-        if (less <= k1 && k1 < leq) { b = v; fb = true; }
+    for (int q = 0; q < SW_KR; q++) {
+        const int j = lane + 64 * q;
+        m[q] = (q < nq && j < n) ? arr[j] : NAN;
+        act[q] = __ballot(m[q] == m[q]);                        // the elements that count: inside the array and not NaN
     }
-    *r0 = a; *r1 = b;
+#if defined(STP_ABLATE_SCORE) && STP_ABLATE_SCORE == 1      /* timing-only builds (tools: never shipped) */
+    if (n > 0) { *r0 = arr[k0 < n ? k0 : 0]; *r1 = arr[k1 < n ? k1 : 0]; return; }
+#endif
+    const double a = sw_kth<SW_KR>(m, act, k0);
+    *r0 = a;
+    *r1 = (k1 == k0) ? a : sw_kth<SW_KR>(m, act, k1);
 }
 // numpy's pairwise sum of v[0..n), n <= 256: stp_pw's recursion pw(o, n) = pw(o, n2) + pw(o + n2, n - n2), n2 = n / 2 - (n / 2) % 8,
 // ends in at most three leaves of <= 128 values here -- [0, nA), and [nA, n) either whole or split once more -- whose eight
@@ -690,9 +739,15 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_score_wave(stp_bandref B, con
     __shared__ double s_scr[SW_WAVES][24];
     __shared__ int16_t s_keepc[SW_WAVES][3][SW_MAXW];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (DO_SC) {
-        for (int i = tid; i < STP_NDIAG; i += 64 * SW_WAVES) exl[i] = exval[i] + .00000001;
-        __syncthreads();
+    bool e_pos = false;                                          // every expected value + 1e-8 is finite and > 0 (the usual table):
+    if (DO_SC) {                                                 // then observed / expected is NaN exactly where observed is
+        bool ok = true;
+        for (int i = tid; i < STP_NDIAG; i += 64 * SW_WAVES) {
+            const double e = exval[i] + .00000001;
+            exl[i] = e;
+            ok = ok && e > 0.0 && e < INFINITY;
+        }
+        e_pos = __syncthreads_and(ok) != 0;
     }
     const int slot = blockIdx.x * SW_WAVES + wv;
     if (slot >= nidx) return;                                    // (no workgroup barrier below)
@@ -742,15 +797,22 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_score_wave(stp_bandref B, con
             else { d = s.fixed_row; tab = s.fixed_tab; }
             if (s.mode != 2 && d >= 400) d = 399;
             if (d < 0) d += STP_NDIAG;
+#if defined(STP_ABLATE_SCORE) && STP_ABLATE_SCORE == 5      /* timing-only: every lane searches ONE row (what coalesced table reads could gain at most) */
+            d = 7;
+#endif
             const size_t rl = (size_t)(tab ? 2 : 0) * STP_NDIAG + d, rr = (size_t)(tab ? 3 : 1) * STP_NDIAG + d;
             nv[2 * q] = nvalid[rl]; nv[2 * q + 1] = nvalid[rr];
-            sp[2 * q] = srt + rl * ncolbg; sp[2 * q + 1] = srt + rr * ncolbg;
+            // (`srt` is k_bg_sort's row-fastest copy: element `mid` of row d of table t at srt[(t * ncolbg + mid) * STP_NDIAG + d])
+            sp[2 * q] = srt + (size_t)(tab ? 2 : 0) * ncolbg * STP_NDIAG + d; sp[2 * q + 1] = srt + (size_t)(tab ? 3 : 1) * ncolbg * STP_NDIAG + d;
         }
         // the lower bounds of all (row, side) pairs of a lane in lock step: 2 nq dependent load chains in flight
         int slo[2 * SW_KR], shi[2 * SW_KR];
 #pragma unroll
         for (int t = 0; t < 2 * SW_KR; t++) { slo[t] = 0; shi[t] = (t < 2 * nq) ? nv[t] : 0; }
         for (;;) {
+#if defined(STP_ABLATE_SCORE) && STP_ABLATE_SCORE == 2
+            break;
+#endif
             bool any = false;
             double xv[2 * SW_KR];
             int mid[2 * SW_KR];
@@ -759,7 +821,7 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_score_wave(stp_bandref B, con
                 const bool a = slo[t] < shi[t];
                 any = any || a;
                 mid[t] = (slo[t] + shi[t]) >> 1;
-                xv[t] = a ? sp[t][mid[t]] : 0.0;
+                xv[t] = a ? sp[t][(size_t)mid[t] * STP_NDIAG] : 0.0;
             }
             if (!any) break;
 #pragma unroll
@@ -815,25 +877,32 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_score_wave(stp_bandref B, con
             const int w = s.col1[b] - s.col0[b];
             wb[b] = w;
             unsigned long long m = 0ull;
+#if defined(STP_ABLATE_SCORE) && STP_ABLATE_SCORE == 4
+            m = w >= 64 ? ~0ull : ((1ull << w) - 1ull);
+            for (int c0 = 0; c0 < 0; c0 += 4) {
+#else
             for (int c0 = 0; c0 < w; c0 += 4) {                  // wave-uniform; four columns' pixels requested together
+#endif                                                           // (eight per round trip measured slower: 0.189 against 0.165 ms per
+                                                                 //  11 k stripes -- blocks are 3 .. 10 columns wide, the idle slots cost)
                 unsigned found = 0u;
                 for (int q = 0; q < nq && found != 15u; q++) {
                     const int r = lane + 64 * q;
                     const bool ron = r < h && !(r >= s.mrow0 && r <= s.mrow1);
                     const double* orow = obs_row(b, ron ? r : 0);
-                    double o[4], e[4];
+                    double o[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const int c = c0 + u;
                         const bool con = ron && c < w && !(c >= s.mcol0[b] && c <= s.mcol1[b]);
                         o[u] = con ? orow[(int64_t)c * cs] : NAN;
-                        e[u] = con ? exv(b, r, c) : 1.0;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        bool al;
-                        if (e[u] > 0.0 && e[u] < INFINITY) al = (o[u] == o[u]);      // o / e is NaN exactly when o is
-                        else { const double v = o[u] / e[u]; al = (v == v); }
+                        bool al = (o[u] == o[u]);                                    // o / e is NaN exactly when o is ...
+                        if (!e_pos && al) {                                          // ... unless the table holds something else (workgroup-uniform)
+                            const double v = o[u] / exv(b, r, c0 + u);               // (o is not NaN: the pixel is inside the block and unmasked)
+                            al = (v == v);
+                        }
                         if (__ballot(al) != 0ull) found |= 1u << u;
                     }
                 }
@@ -899,7 +968,11 @@ __global__ __launch_bounds__(64 * SW_WAVES) void k_score_wave(stp_bandref B, con
                     }, [&](int64_t k, double o) {
                         const int c = colof(k);
                         if (rmask || (c >= s.mcol0[b] && c <= s.mcol1[b])) return 0.0;
+#if defined(STP_ABLATE_SCORE) && STP_ABLATE_SCORE == 3
+                        const double v = o * exv(b, r, c);
+#else
                         const double v = o / exv(b, r, c);
+#endif
                         return (v != v) ? 0.0 : v;
                     }, 0, n);
                     const double mean = sum / (double)n;

@@ -2950,6 +2950,7 @@ int stp_dbg_stages(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* 
 struct stp_background {
     double* d = nullptr;        // lu | ru | ld | rd, each 400 x ncol
     double* sorted = nullptr;   // the same rows sorted ascending (NaN last)
+    double* sorted_t = nullptr; // ... and with the row index fastest (k_score_wave: lanes = consecutive rows)
     int* nvalid = nullptr;      // non-NaN count of each of the 1600 rows
     int ncol = 0;
 };
@@ -3130,6 +3131,7 @@ int stp_background_upload(stp_ctx* ctx, const double* lu, const double* ru, cons
     }
     if (ncol > STP_BG_MAXCOL) { (void)stp_dfree(__LINE__, bg->d); delete bg; return set_err(ctx, STP_E_UNSUPPORTED, "background tables wider than 2048 columns"); }
     if (stp_dmalloc(__LINE__, (void**)&bg->sorted, 4 * tn * sizeof(double)) != hipSuccess ||
+        stp_dmalloc(__LINE__, (void**)&bg->sorted_t, 4 * tn * sizeof(double)) != hipSuccess ||
         stp_dmalloc(__LINE__, (void**)&bg->nvalid, 4 * STP_NDIAG * sizeof(int)) != hipSuccess) {
         stp_background_free(ctx, bg);
         return set_err(ctx, STP_E_NOMEM, "hipMalloc(sorted background)");
@@ -3137,7 +3139,7 @@ int stp_background_upload(stp_ctx* ctx, const double* lu, const double* ru, cons
     {
         prof_scope ps(ctx, "bg_sort", 16.0 * 4 * tn, ctx->aux);
         hipLaunchKernelGGL(k_bg_sort, dim3(4 * STP_NDIAG), dim3(512), 0, ctx->aux, (const double*)bg->d, ncol, bg->sorted,
-                           bg->nvalid);
+                           bg->nvalid, bg->sorted_t);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(x.finish());
@@ -3151,6 +3153,7 @@ void stp_background_free(stp_ctx* ctx, stp_background* bg)
     if (ctx) (void)hipSetDevice(ctx->device);
     if (bg->d) (void)stp_dfree(__LINE__, bg->d);
     if (bg->sorted) (void)stp_dfree(__LINE__, bg->sorted);
+    if (bg->sorted_t) (void)stp_dfree(__LINE__, bg->sorted_t);
     if (bg->nvalid) (void)stp_dfree(__LINE__, bg->nvalid);
     delete bg;
 }
@@ -3243,6 +3246,7 @@ static int run_score(stp_ctx* ctx, const stp_band* band, const stp_background* b
         if (!(e2 && e2[0] == '1')) { int rcs = band_symmetric(ctx, band, &br.sym); if (rcs) return rcs; }
     }
     const double* d_srt = bg ? (const double*)bg->sorted : nullptr;
+    const double* d_srt_t = bg ? (const double*)bg->sorted_t : nullptr;      // the wave kernel's layout
     const int* d_nv = bg ? (const int*)bg->nvalid : nullptr;
     const int ncolbg = bg ? bg->ncol : 0;
     const char* scope = (pst && sst) ? "score" : (pst ? "pvalue" : "stripiness");
@@ -3254,7 +3258,7 @@ static int run_score(stp_ctx* ctx, const stp_band* band, const stp_background* b
         const double frac = (double)L.size() / (double)n;
         prof_scope ps(ctx, scope, ((pst ? bytes_pv : 0.0) + (sst ? bytes_sc : 0.0)) * frac, ctx->aux);
 #define STP_SW_LAUNCH(PV, SC, KR)                                                                                                      \
-        hipLaunchKernelGGL((k_score_wave<PV, SC, KR>), dim3(grid), dim3(64 * SW_WAVES), 0, ctx->aux, br, d_idx, (int)L.size(), bs, d_srt, d_nv, ncolbg, \
+        hipLaunchKernelGGL((k_score_wave<PV, SC, KR>), dim3(grid), dim3(64 * SW_WAVES), 0, ctx->aux, br, d_idx, (int)L.size(), bs, d_srt_t, d_nv, ncolbg, \
                            (const stp_pv_stripe*)bP.p, o_p, (const double*)bE.p, (const stp_score_stripe*)bS.p, o_g, o_m, o_t, o_s)
         if (pst && sst) { if (cls) STP_SW_LAUNCH(true, true, SW_KR_TALL); else STP_SW_LAUNCH(true, true, SW_KR_SHORT); }
         else if (pst) { if (cls) STP_SW_LAUNCH(true, false, SW_KR_TALL); else STP_SW_LAUNCH(true, false, SW_KR_SHORT); }

@@ -102,6 +102,53 @@ def test_wave_form_equals_block_form_fused_call_and_oracle(seed, resol, hmax):
     hb.close()
 
 
+@pytest.mark.parametrize('kind', ['zero', 'negative', 'inf', 'nan'])
+def test_expected_values_that_are_not_finite_and_positive(kind):
+    """The wave kernel takes "observed / expected is NaN exactly where observed is" only when every expected value + 1e-8 is
+    finite and > 0 (tested once per workgroup); a table with a zero, a negative, an infinite or a NaN entry takes the general
+    path (the quotient itself is tested): wave form == block form == oracle."""
+    from oracle import oracle as O
+    from stripenn_amd import backend as BK, synth
+    O.build()
+    rng = np.random.default_rng(77)
+    nb, bs = 1500, 10
+    ch = synth.SynthChrom(nb, 811, nan_frac=0.01)
+    band_h = ch.band(512)
+    hb = BK.HipBackend(0); ob = OracleBackend()
+    gb = hb.open_chrom(band_h); cb = ob.open_chrom(band_h)
+    EV = 240.0 / (1.0 + np.arange(400)) + 1.0 + rng.random(400)
+    bad = rng.choice(60, 12, replace=False)                      # near-diagonal entries: every stripe meets some of them
+    EV[bad] = {'zero': -1e-8, 'negative': -3.0, 'inf': np.inf, 'nan': np.nan}[kind]
+    pv, sc = _stripes(rng, nb, bs, 240, 150)
+    with np.errstate(all='ignore'):
+        try:
+            s = hb.stripiness(gb, EV, sc)
+        except IndexError:
+            s = None
+        os.environ['STP_SCORE'] = 'block'
+        try:
+            try:
+                sb = hb.stripiness(gb, EV, sc)
+            except IndexError:
+                sb = None
+        finally:
+            os.environ.pop('STP_SCORE', None)
+        assert (s is None) == (sb is None)
+        idx = np.arange(0, 240, 2)
+        try:
+            so = ob.stripiness(cb, EV, sc[idx])
+        except IndexError:
+            so = None
+    if s is not None:
+        for a, b, nm in zip(s, sb, 'gmt'):
+            assert _same(a, b, nm == 'g'), 'Stripiness output %s: wave form vs block form (%s)' % (nm, kind)
+        if so is not None:
+            for a, b, nm in zip(s, so, 'gmt'):
+                assert _same(a[idx], b, nm == 'g'), 'Stripiness output %s vs oracle (%s)' % (nm, kind)
+    gb.close()
+    hb.close()
+
+
 def test_symmetric_reads_are_used_only_for_symmetric_bands():
     """The score kernels read a stripe's pixels as M[c][r] (coalesced) only after k_band_symcheck has found the band bit for bit
     symmetric.  (i) A symmetric band: the symmetric reads and the row reads (STP_SCORE_NOSYM=1) give identical outputs, and the
