@@ -489,10 +489,19 @@ STP_HD int c32_nms(const float* sS, const float* sM, stp_tile T, int y, int x, s
 template <int R>
 STP_HD void c32_gauss_taps(const float* centre, int stride, int lo, int hi, float* v)
 {
+    // Every tap is READ -- the rows / columns beyond the image lie in the guard regions around the grey images or in a
+    // neighbouring image: valid memory, as for the vertical pass -- and the masked ones are then replaced by 0.  (round 5: as one
+    // conditional expression per tap each load sat in its own branch with its conversion right behind it, and the 2R+1
+    // loads of a lane went out one memory round trip after the other: the resolver's time was mostly that.)
+    float raw[2 * R + 1];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int k = 0; k <= 2 * R; k++) v[k] = (k >= lo && k <= hi) ? centre[(k - R) * stride] : 0.0f;
+    for (int k = 0; k <= 2 * R; k++) raw[k] = centre[(k - R) * stride];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k <= 2 * R; k++) v[k] = (k >= lo && k <= hi) ? raw[k] : 0.0f;
 }
 template <int R>
 STP_HD float c32_gauss_sum(const float* v, const double* w)
@@ -513,8 +522,9 @@ STP_HD float c32_gauss_exact(const float* centre, int stride, const double* w, i
 #pragma unroll 4
 #endif
         for (int k = R; k >= 1; k--) {                // (four tap pairs -- eight loads -- in flight at a time)
-            const double xl = (R - k >= lo && R - k <= hi) ? (double)centre[-k * stride] : 0.0;
-            const double xh = (R + k >= lo && R + k <= hi) ? (double)centre[k * stride] : 0.0;
+            const float rl = centre[-k * stride], rh = centre[k * stride];           // (read, then masked: see c32_gauss_taps)
+            const double xl = (R - k >= lo && R - k <= hi) ? (double)rl : 0.0;
+            const double xh = (R + k >= lo && R + k <= hi) ? (double)rh : 0.0;
             a += (xl + xh) * w[R - k];
         }
         return (float)a;

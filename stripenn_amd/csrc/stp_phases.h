@@ -1651,16 +1651,26 @@ STP_HD int lines_group_pairs(int S, int ud, int maxW, int nrow, const int16_t* m
 STP_HD void lines_rowsum(int tid, int nt, int S, const double* __restrict__ band, int W, int hw, int64_t st,
                          const int16_t* nz, stp_lrec rc, double* rs)
 {
+    // (round 5: the pixels of a row are requested EIGHT at a time and then added in order -- the one-by-one form waited a memory
+    //  round trip per pixel: k_lines' listing)
+    const int x1 = (rc.x + rc.w < S) ? rc.x + rc.w : S;
     for (int i = tid; i < rc.h; i += nt) {
         int y = rc.y + i;
         double s = 0.0;
         if (y >= 0 && y < S) {
-            int oy = nz[y];
-            for (int x = rc.x; x < rc.x + rc.w && x < S; x++) {
-                int ox = nz[x];
-                double v = band[(st + oy) * (int64_t)W + (ox - oy + hw)];
-                if (v != v) v = 0.0;
-                s += v;
+            const int oy = nz[y];
+            const double* row = band + (st + oy) * (int64_t)W + (hw - oy);
+            for (int x0 = rc.x; x0 < x1; x0 += 8) {
+                double v[8];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                for (int t = 0; t < 8; t++) v[t] = (x0 + t < x1) ? row[nz[x0 + t]] : 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+                for (int t = 0; t < 8; t++)
+                    if (x0 + t < x1) s += (v[t] != v[t]) ? 0.0 : v[t];
             }
         }
         rs[i] = s;

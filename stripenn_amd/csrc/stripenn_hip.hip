@@ -1360,7 +1360,15 @@ __global__ __launch_bounds__(512, RCAP == STP_RCAP ? 6 : 4) void k_lines(const s
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
                 double tot = 0.0;
-                for (int i = 0; i < rc.h; i++) tot += rsw[i];
+                int i = 0;
+                for (; i + 8 <= rc.h; i += 8) {                  // (eight LDS reads in flight, then the eight additions in order)
+                    double v[8];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) v[t] = rsw[i + t];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) tot += v[t];
+                }
+                for (; i < rc.h; i++) tot += rsw[i];
                 stp_drec d;
                 d.ud = rc.ud; d.x = rc.x; d.y = rc.y; d.w = rc.w; d.h = rc.h; d.pad0 = d.pad1 = d.pad2 = 0;
                 d.total = tot;
