@@ -1116,11 +1116,18 @@ __device__ __forceinline__ stp_u64 wave_transpose64(stp_u64 x, int lane)
 // column (64 * cg + lane) of a row-major bit matrix as 7 words, all 64 lanes of the wave cooperating
 __device__ __forceinline__ void wave_load_cols(const stp_u64* m, int S, int cg, int lane, stp_u64* col)
 {
+    // (all seven words are requested before the first transpose: as one conditional read per block each LDS round trip was
+    //  waited for in turn.  A row beyond the image reads row S - 1's word -- inside the matrix -- and is then replaced by 0.)
+    stp_u64 x[STP_NW];
 #pragma unroll
     for (int k = 0; k < STP_NW; k++) {
         const int r = 64 * k + lane;
-        const stp_u64 x = (r < S) ? m[r * STP_NW + cg] : 0ull;
-        col[k] = wave_transpose64(x, lane);
+        x[k] = m[(r < S ? r : S - 1) * STP_NW + cg];
+    }
+#pragma unroll
+    for (int k = 0; k < STP_NW; k++) {
+        const int r = 64 * k + lane;
+        col[k] = wave_transpose64((r < S) ? x[k] : 0ull, lane);
     }
 }
 
