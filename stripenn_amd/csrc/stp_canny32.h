@@ -335,8 +335,8 @@ STP_HD void c32_p2_item(stp_tile T, int yy, int xx0, const stp_w32& W, const flo
         for (int k = R; k >= 1; k--)
             c32_fma2(win[q + R - k] + win[q + R + k], win[q + 1 + R - k] + win[q + 1 + R + k], W.w[R - k], &a0, &a1);
         srow[q] = XIN ? a0 * rb : (a0 * rb) * sRC[xx0 + q];     // columns outside the image: sRC = 0 (their sums are finite)
-        srow[q + 1] = XIN ? a1 * rb : (a1 * rb) * sRC[xx0 + q + 1];
-    }
+        srow[q + 1] = XIN ? a1 * rb : (a1 * rb) * sRC[xx0 + q + 1];   // (round 5: requesting the pair's factors before its chain -- the
+    }                                                                 //  listing shows them read one LDS round trip at a time -- changed nothing: 36.1 / 36.0 ms)
     if (HRUN & 1) {
         const int q = HRUN - 1;
         float a = win[q + R] * W.w[R];

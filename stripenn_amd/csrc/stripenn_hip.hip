@@ -260,8 +260,10 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
                 const double rs2 = (a0 + a1) + a2;
                 if (r >= 2) {
                     const double blur = ((rs0 + rs1) + rs2) * cb;
+#if !(defined(STP_ABLATE_GRAY) && STP_ABLATE_GRAY == 2)   /* ... no rounding-boundary test */
                     const unsigned nw = stp_near_word(blur, STP_GRAY_NEAR);
                     far = nw < far ? nw : far;
+#endif
                     out[r - 2] = stp_gray_rgb((float)blur);
                 }
                 rs0 = rs1; rs1 = rs2;
@@ -277,9 +279,16 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
 #if defined(STP_ABLATE_GRAY_ST)        /* timing-only build: a quarter of the store instructions */
                         if (j % 4 == 0)
 #endif
+#if defined(STP_ABLATE_GRAY) && STP_ABLATE_GRAY == 1      /* timing-only builds (never shipped): no pixel stores ... */
+                        if (out[j] == 12345.0f)
+#endif
                         gimg[j * STP_PITCH] = out[j];
                         const unsigned bits = __float_as_uint(out[j]);       // grey values are >= +0: their bit patterns order like the values
+#if !(defined(STP_ABLATE_GRAY) && STP_ABLATE_GRAY == 3)   /* ... no cell minima / maxima ... */
                         vmn = min(vmn, bits); vmx = max(vmx, bits);
+#else
+                        vmn = bits;
+#endif
                     }
                 } else {
 #pragma unroll
