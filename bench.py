@@ -459,21 +459,21 @@ def main():
             try:
                 spec4 = dict(names=['chr1_1kb'], nbins=[248957], seeds=[5], wl='configs[4]: 1kb chr1-size band')
                 W4 = _Workload(hb, dev, spec4, 1, 0, '', score=False, sigma=args.canny)
-                W4.step()
-                ctx.reset_stats(); barrier()
+                W4.step(); W4.step()                  # (two untimed steps: the genome workload's buffers were released a moment ago;
+                ctx.reset_stats(); barrier()          #  one run in round 5 saw the first timed step at 1.5x)
                 t0 = time.perf_counter()
-                for _ in range(3):
+                for _ in range(5):
                     _, px4 = W4.step()
                 barrier()
                 dt4 = time.perf_counter() - t0
                 s4 = ctx.stats()
                 cw = s4['chain_wall']['ms'] if 'chain_wall' in s4 else sum(v['ms'] for k, v in s4.items() if k in BYTES_PER_IMAGE_PX)
                 out['band_1kb'] = {'what': 'configs[4]: synthetic 1 kb chr1-size band (248 957 bins, 1 245 frames x 5 levels x 6 images), '
-                                           'frame preparation + StripeSearch chain, shipped kernels, 3 steps',
-                                   'value': round(px4 * 3 / dt4 / 1e6, 2), 'unit': 'contact-Mpx/s', 'ms_per_step': round(dt4 / 3 * 1e3, 3),
+                                           'frame preparation + StripeSearch chain, shipped kernels, 5 steps',
+                                   'value': round(px4 * 5 / dt4 / 1e6, 2), 'unit': 'contact-Mpx/s', 'ms_per_step': round(dt4 / 5 * 1e3, 3),
                                    'contact_px_per_step': px4,
-                                   'chain_frac_of_hbm_peak': round(26.0 * px4 * 6 * 3 / (cw * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                   'kernels_ms_per_step': {k: round(v['ms'] / 3, 3) for k, v in s4.items()}}
+                                   'chain_frac_of_hbm_peak': round(26.0 * px4 * 6 * 5 / (cw * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   'kernels_ms_per_step': {k: round(v['ms'] / 5, 3) for k, v in s4.items()}}
                 W4.release()
             except Exception as e:      # noqa: BLE001 -- an extra line must not cost the metric line
                 out['band_1kb'] = {'error': str(e)[:200]}
