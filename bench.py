@@ -560,6 +560,8 @@ class _Workload:
         # so one unit's launch tails, its latency-bound k_lines and the drain behind its last kernel are filled by the other's chain
         # Measured and NOT the default (round 5, STP_BENCH_CTX=2): 74.8-75.2 against 71.8 ms per step -- kernels of two streams that
         # really run side by side slow each other down by more than the filled tails give back (round 2 had found the same).
+        # (end of round 5: 65.2 against 63.3 ms; the two contexts driven by two host THREADS, alternate units each: 66.9 -- although
+        #  two rank PROCESSES on the one device finish the genome step in 60.7 ms: profiles/r05_rehearse_2ranks.json)
         self.two_ctx = os.environ.get('STP_BENCH_CTX', '1') == '2' and not emulate_rank
         if self.two_ctx and not (score and os.environ.get('STP_BENCH_SCORE_THREAD', '0') == '1'):
             self.hb2 = BK.HipBackend(dev.index or 0)
