@@ -46,6 +46,33 @@
 //   Everything else ("uncertain": ~1e-4 of the pixels of noisy data, every edge pixel of a synthetic step) is
 //   resolved by c32_res_*: the reference's arithmetic on the 5 x 5 smoothed values around the pixel, recomputed
 //   from the grey image in the exact order (c32_gauss_exact), glibc's hypot, the literal tests.
+//
+// Symmetry (round 6).  The contact matrix is symmetric and a frame keeps the same bins as rows and as columns (getStripe.py:
+// 812-822), so D[r][c] == D[c][r] bit for bit (the host verifies the band: k_band_symcheck) and every per-pixel step up to the
+// brightness image is the same function of the same number at (r, c) and at (c, r).  From the box blur on the reference is
+// symmetric only up to the ORDER of its roundings: cv2.filter2D sums the nine window terms row-major, so the mirror pixel sums
+// the same nine terms column-major; scipy's gaussian_filter runs axis 0 before axis 1, so the mirror pixel sees the passes in the
+// other order; isobel and jsobel change places, the four sectors of the local-maximum test are mirrored onto each other
+// (0-45 <-> 45-90, 90-135 <-> 135-180 degrees: _canny.py:204-267 with rows and columns swapped).  k_canny_f32 with `mirror` does
+// not compute the tiles strictly below the diagonal and takes their class words from the transposes of the tiles above:
+//   * grey.  k_gray_c3's certificate bounds |blur~ - T| and |blur - T| against the real-number sum T of the nine terms, whatever
+//     the order (10.1 u T for nine sequential additions in ANY order): a pixel the near-boundary test does not flag has the same
+//     float -- hence the same grey value -- as its mirror image.  A flagged lane forms its outputs in both orders
+//     (gray_c3_redo) and reports the image if one differs; such an image is not mirrored (its tiles below the diagonal go
+//     to the exact kernel).  So below, grey(r, c) == grey(c, r) for every pixel of a mirrored image.
+//   * budget.  Every bound above is |f32 value - T| + |T - reference value| with T the real-number value, and the second term
+//     counts the reference's roundings (one per pass, the f64 dust, glibc's hypot), not their order: T is the same number at
+//     both positions, the reference's value at the mirror position obeys the same bound as at the position itself, and the
+//     bleed-over factor there (column factor x row factor, formed in the other order) differs by 2^-52 relative, inside the
+//     slack of E_S (27 used, 26.2 needed).  So a verdict the f32 test reaches for (r, c) -- below the threshold, class by
+//     the decided sector and the decided comparisons -- is the reference's verdict for (c, r) too: the mirror pixel's test is
+//     the same test with the roles of i and j, and of the axis neighbours, exchanged, on values inside the same error bands.
+//   * the undecidable pixels are settled per position: (r, c) as before, (c, r) by the same resolver at that position
+//     (c32_res_S_any: bleed-over factors straight from the weights), each in the reference's own arithmetic and order there.
+//   * a tile-image that overflows the list is flagged together with the two tiles its transpose covers.
+// Checked on the CPU replay (tests/test_emu_kernels.py::test_canny_mirrored_tiles*: sizes that end inside a tile / word half,
+// five radii, plateaus and exact ties on and across the diagonal) and on the device (tests/test_gpu_sym.py; every GPU test runs
+// with `mirror` on, STP_SYM=0 switches it off).
 #pragma once
 
 #define C32_SP (CT_X + 6)          /* pitch (floats) of the f32 smoothed tile: even (aligned pairs), 6 mod 64 banks per row */
@@ -583,6 +610,21 @@ STP_HD double c32_res_S(stp_tile T, int y, int x, int l, const double* w, const 
     const float f = c32_gauss_exact<R>(Vp + r * NC + (cx - (x - 2 - R)), 1, w, 0, 2 * R);
     const int yyt = yy - (T.ty0 - 2);
     const double bl = (cx >= R && cx + R < T.S) ? sB[VH + yyt] : stp_bleed_h(sB[yyt], cx, T.S, R, w);
+    return (double)f / (bl + DBL_EPSILON);       // _canny.py:49
+}
+// The same element for a pixel ANYWHERE in the image (the mirrored resolver of a tile above the diagonal settles pixels of
+// the tiles below it): the bleed-over factors straight from the weights -- stp_bleed_v / stp_bleed_h are what canny_p1b
+// tabulates, and for an interior column stp_bleed_h(V, cx) performs the very operations of the tabulated stp_bleed_h(V, R).
+template <int R>
+STP_HD double c32_res_S_any(int S, int y, int x, int l, const double* w, const float* Vp)
+{
+    constexpr int NC = 2 * R + 5;
+    const int r = l / 5, c = l - r * 5;
+    int yy = y - 2 + r, cx = x - 2 + c;
+    yy = yy < 0 ? 0 : (yy > S - 1 ? S - 1 : yy);
+    cx = cx < 0 ? 0 : (cx > S - 1 ? S - 1 : cx);
+    const float f = c32_gauss_exact<R>(Vp + r * NC + (cx - (x - 2 - R)), 1, w, 0, 2 * R);
+    const double bl = stp_bleed_h(stp_bleed_v(yy, S, R, w), cx, S, R, w);
     return (double)f / (bl + DBL_EPSILON);       // _canny.py:49
 }
 // magnitude (glibc hypot of the f64 Sobel sums) of pixel l = 3 * (dy + 1) + (dx + 1) of the 3 x 3 block around the

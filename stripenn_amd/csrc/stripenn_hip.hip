@@ -156,8 +156,13 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
 // Grey images and cell minima / maxima are bit for bit those of k_gray<1> (STP_GRAY=exact selects that kernel).
 // the rare path: one lane's strip of eight outputs from the band in the reference's operations, stored; returns the
 // smallest / largest bit pattern stored (not inlined: it must not cost the common path registers)
+// asym_flag (round 6, image symmetry): in a symmetric contact matrix the mirror pixel (column, row) sums the SAME nine terms in
+// column-major order; only a sum this close to a float rounding boundary can round differently there.  The strip's outputs
+// are therefore also formed in that order, and an image in which one of them differs is reported: k_canny_f32 then does
+// not hand the transposed class words of that image to the tiles below the diagonal (see there).
 __device__ __noinline__ static uint2 gray_c3_redo(const double* __restrict__ band, int W, int hw, int64_t st, const int16_t* s_ny,
-                                                  const int16_t* s_nx, int yy0, int xx, int nrows, double M, double b, float* gcol)
+                                                  const int16_t* s_nx, int yy0, int xx, int nrows, double M, double b, float* gcol,
+                                                  uint8_t* asym_flag)
 {   // (yy0 + j, xx): window coordinates of the output pixels' centres in the (GT_Y + 2) x (GT_X + 2) plane
     unsigned vmn = 0x7F800000u, vmx = 0u;
 #pragma unroll 1
@@ -177,6 +182,19 @@ __device__ __noinline__ static uint2 gray_c3_redo(const double* __restrict__ ban
         gcol[j * STP_PITCH] = v;
         const unsigned bits = __float_as_uint(v);
         vmn = min(vmn, bits); vmx = max(vmx, bits);
+        if (asym_flag != nullptr) {
+            double acct = 0.0;
+#pragma unroll 1
+            for (int i = 0; i < 9; i++) {                                  // the mirror pixel's order: window columns outermost
+                const int oy = s_ny[yy0 + j - 1 + i % 3], ox = s_nx[xx - 1 + i / 3];
+                double d = band[(st + oy) * (int64_t)W + (ox - oy + hw)];
+                if (d != d) d = 0.0;
+                acct = acct + kv * stp_bright_px(stp_gplane_px(d, M), b, k);
+            }
+            if (acct < 0.0) acct = 0.0;
+            if (acct > 1.0) acct = 1.0;
+            if (__float_as_uint(stp_gray_rgb((float)acct)) != bits) *asym_flag = 1;
+        }
     }
     return make_uint2(vmn, vmx);
 }
@@ -185,7 +203,8 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
                                                   const int16_t* __restrict__ fnz, int f0,
                                                   const double* __restrict__ Mlev, int nlev,
                                                   const double* __restrict__ bvals, int nb,
-                                                  float* __restrict__ gray, float2* __restrict__ cells)
+                                                  float* __restrict__ gray, float2* __restrict__ cells,
+                                                  uint8_t* __restrict__ asym /* per image, or null: see gray_c3_redo */)
 {
     constexpr int HH = GT_Y + 2, WW = GT_X + 2, N = HH * WW, IT = (N + 255) / 256;
     __shared__ double sg[N], sd[N];
@@ -201,6 +220,9 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
     stp_tile T;
     T.S = S; T.ty0 = (blockIdx.x / tpr) * GT_Y; T.tx0 = (blockIdx.x % tpr) * GT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
+#if defined(STP_ABLATE_REUSE) && STP_ABLATE_REUSE == 2     /* upper bound only: the canny tiles beside the hole need these grey values */
+    if (S >= 395 && T.ty0 >= 224 && T.ty0 < 384 && T.tx0 >= 256 && T.tx0 < 384) return;
+#endif
     const int tid = threadIdx.x;
     if (tid >= 128 && tid < 128 + NCB && tid - 128 < nb) s_cb[tid - 128] = stp_gray_cb(bvals[tid - 128]);   // (read after the barriers below)
     const int16_t* nzf = fnz + (size_t)f * STP_FRAME_MAX;
@@ -271,7 +293,8 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
             unsigned vmn = 0x7F800000u, vmx = 0u;                            // +inf / +0: a cell without pixels unites to nothing
             if (xin && nrows > 0) {
                 if (far < 16u * STP_GRAY_NEAR) {                              // ~1e-6 of the lanes: the reference's own operations
-                    const uint2 mm = gray_c3_redo(band, W, hw, st, s_ny, s_nx, strip * GS_ROWS + 1, lane + 1, nrows, M, b, gimg);
+                    const uint2 mm = gray_c3_redo(band, W, hw, st, s_ny, s_nx, strip * GS_ROWS + 1, lane + 1, nrows, M, b, gimg,
+                                                  asym ? asym + img : nullptr);
                     vmn = mm.x; vmx = mm.y;
                 } else if (nrows == GS_ROWS) {                                // (whole strip inside the image: no test per row)
 #pragma unroll
@@ -667,10 +690,14 @@ template <int RT>
 __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe_list(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
                                                      int nf, int nlev, int nb, const double* __restrict__ gw,
                                                      stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_fastdiv fd,
-                                                     uint8_t* __restrict__ xflags)
+                                                     uint8_t* __restrict__ xflags, uint8_t* __restrict__ asym)
 {
     constexpr int TPI = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);   // 91
     const int n = nf * nlev * nb * TPI;
+    // k_gray_c3's per-image asymmetry reports have been read by k_canny_f32: cleared here, like the flags served below, so
+    // that both buffers are all zero between launches
+    if (asym != nullptr)
+        for (int i = blockIdx.x * 256 + (int)threadIdx.x; i < nf * nlev * nb; i += gridDim.x * 256) asym[i] = 0;
     __shared__ stp_u64 sAny[4];
     for (int k0 = blockIdx.x * 256; k0 < n; k0 += gridDim.x * 256) {     // 256 flags at a time
         const int kk = k0 + (int)threadIdx.x;
@@ -700,6 +727,7 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe_list(const
 // LDS reads: consecutive lanes, consecutive words); the two halo columns 0 and CT_X + 1 (neighbours only, never
 // candidates) pixel by pixel.  Candidates (magnitude >= thr inside the tile's candidate window) go to the wave's own
 // segment of the queue -- its fill count is a wave-uniform register, so a row costs one ballot and no atomic.
+__device__ __forceinline__ stp_u64 wave_transpose64(stp_u64 x, int lane);      // (defined with k_lines' helpers below)
 #define C32_QSEG (((CT_Y + 2 + 3) / 4) * 64)       /* candidates one wave can find: its rows x 64 columns */
 __device__ __forceinline__ void canny32_mag_rows(int tid, stp_cwin C, int my_lo, int nmh, int mx_lo, int nmw, float thr,
                                                  const float* sS, float* sM, uint16_t* sQ, int* sQcnt)
@@ -773,13 +801,17 @@ __device__ __forceinline__ void canny32_nms_queue(int tid, int bi, stp_tile T, s
     }
 }
 // one pixel, one wave: the 5 x (2R+5) vertical-pass values, the 5 x 5 smoothed values, nine magnitudes, the literal test
-template <int R>
+// MIR (image symmetry, see k_canny_f32): the pixel settled is the MIRROR image (column, row) of tile pixel e -- a pixel of a
+// tile below the diagonal that no workgroup computes -- and its class goes to the tile's transposed words sT[plane][tile column]
+template <int R, bool MIR = false>
 __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, const double* sW, const double* sB,
-                                                const float* __restrict__ gimg, float* Vp, double* Sp, stp_u64* sBits)
+                                                const float* __restrict__ gimg, float* Vp, double* Sp, stp_u64* sBits,
+                                                uint32_t* sT = nullptr)
 {
     constexpr int NV = 5 * (2 * R + 5);
-    const int yy = e >> 6, xx = e & 63, y = T.ty0 + yy, x = T.tx0 + xx;
-    if constexpr (R <= 8) {   // the taps of a lane's two elements are requested together (one memory round trip instead of two)
+    const int yy = e >> 6, xx = e & 63, y = MIR ? T.tx0 + xx : T.ty0 + yy, x = MIR ? T.ty0 + yy : T.tx0 + xx;
+    if constexpr (R <= 8 && !MIR) {   // the taps of a lane's two elements are requested together (one memory round trip instead of two;
+                                      //  the mirror form takes the lean loop: both forms inlined with 34 tap registers each spilled at radius 8)
         float va[2 * R + 1], vb[2 * R + 1];
         const bool hb = lane + 64 < NV;
         c32_res_V_taps<R>(T, y, x, lane, gimg, va);
@@ -792,7 +824,7 @@ __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, con
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (lane < 25) Sp[lane] = c32_res_S<R>(T, y, x, lane, sW, sB, Vp);
+    if (lane < 25) Sp[lane] = MIR ? c32_res_S_any<R>(T.S, y, x, lane, sW, Vp) : c32_res_S<R>(T, y, x, lane, sW, sB, Vp);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     double* M9 = (double*)Vp;                    // the vertical-pass values are dead: nine magnitudes in their place
@@ -801,8 +833,13 @@ __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, con
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
         const int cls = c32_res_class(Sp, M9);
-        if (cls >= 1) atomicOr(&sBits[yy], 1ull << xx);
-        if (cls == 2) atomicOr(&sBits[CT_Y + yy], 1ull << xx);
+        if (MIR) {
+            if (cls >= 1) atomicOr(&sT[xx], 1u << yy);
+            if (cls == 2) atomicOr(&sT[CT_X + xx], 1u << yy);
+        } else {
+            if (cls >= 1) atomicOr(&sBits[yy], 1ull << xx);
+            if (cls == 2) atomicOr(&sBits[CT_Y + yy], 1ull << xx);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -837,6 +874,22 @@ static __host__ __device__ stp_c32_layout canny32_layout(int R)
     return L;
 }
 
+// mirror geometry of a tile (k_canny_f32, image symmetry): does its transpose cover tiles below the diagonal, and which
+struct stp_c32mgeo { bool mir, t1_in; int t0, tyi; };
+__device__ __forceinline__ stp_c32mgeo c32_mgeo(int mirror, int S)
+{
+    constexpr int TPI = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
+    constexpr int tpr = (STP_FRAME_MAX + CT_X - 1) / CT_X;
+    int b = blockIdx.x;
+    asm volatile("" : "+s"(b));                      // (opaque: recomputed at every use)
+    const int tile = (b >> 3) % TPI, tyi = tile / tpr, txi = tile - tyi * tpr;
+    stp_c32mgeo g;
+    g.mir = mirror && txi > (tyi >> 1);
+    g.t0 = (2 * txi) * tpr + (tyi >> 1);             // the two tiles the transpose covers (t0, t0 + tpr), one word half each
+    g.t1_in = (2 * txi + 1) * CT_Y < S;
+    g.tyi = tyi;
+    return g;
+}
 // DBG (stp_dbg_canny_f32 only; the product launches <RT, false>): after the magnitudes of image dbg_bi the tile's own pixels
 // are dumped -- f32 smoothed value, Sobel sums, magnitude, the scale g and the E_G budget (u g) the tile used, six planes of
 // pitch STP_PITCH -- and dbg_cnt counts the image's candidates, the pixels sent to the resolver and the flagged tile-images.
@@ -845,6 +898,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
                                                     int nf, int nlev, int nb, const double* __restrict__ gw,
                                                     stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_w32 W32,
                                                     const float2* __restrict__ cells, uint8_t* __restrict__ xflags,
+                                                    int mirror /* the images are symmetric: see below */, const uint8_t* __restrict__ asym,
                                                     float* __restrict__ dbg = nullptr, int dbg_bi = -1,
                                                     unsigned long long* __restrict__ dbg_cnt = nullptr)
 {
@@ -861,6 +915,19 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     stp_tile T;
     T.S = S; T.ty0 = (tile / tpr) * CT_Y; T.tx0 = (tile % tpr) * CT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
+#if defined(STP_ABLATE_REUSE)            /* timing-only build (never shipped): the tiles inside the block a frame shares with its successor are skipped */
+    if (S >= 395 && T.ty0 >= 224 && T.ty0 < 384 && T.tx0 >= 256 && T.tx0 < 384) return;
+#endif
+    // Image symmetry (round 6).  The contact matrix is symmetric and a frame keeps the same bins as rows and as columns, so
+    // every image is the transpose of itself up to the ORDER of the reference's roundings (box sum row-major, Gaussian rows
+    // before columns).  With `mirror` set (the host has verified the band's symmetry bit for bit and k_gray_c3 reports, per
+    // image, a grey value that differs from its mirror image: `asym`) the tiles that lie strictly below the diagonal
+    // (tile row >= 2 x tile column + 2) are not computed: a tile whose transpose lies there (tile column > tile row / 2)
+    // hands its class words over transposed -- a verdict of the f32 test holds for the mirror pixel too (stp_canny32.h,
+    // "Symmetry"), an undecidable pixel is settled twice, once per position, each in the reference's own arithmetic there.
+    // (the mirror geometry is re-derived from the block index where it is needed -- c32_mgeo -- so that nothing of it lives
+    //  across the image loop: held there it cost radius 8 three spilled registers)
+    if (mirror && tile / tpr >= 2 * (tile % tpr) + 2) return;
     const stp_c32_layout L = canny32_layout(R);
     double* sW = (double*)smem;
     float* sRB = (float*)(smem + L.sRB);
@@ -966,6 +1033,11 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
             *sOv = 0;
             *sDn = C32_DCAP;
             xflags[(img0 + prev) * TPI + tile] = 1;
+            const stp_c32mgeo mg = c32_mgeo(mirror, S);
+            if (mg.mir) {                             // ... and the tiles below the diagonal that would have received its transpose
+                xflags[(img0 + prev) * TPI + mg.t0] = 1;
+                if (mg.t1_in) xflags[(img0 + prev) * TPI + mg.t0 + tpr] = 1;
+            }
         }
         prev = bi;
         const stp_c32tol E = c32_tol_u(sG[bi], W32.eu[et][0], W32.eu[et][1], W32.eu[et][2]);
@@ -1036,10 +1108,32 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         }
     }
     __syncthreads();
+    const stp_c32mgeo mg = c32_mgeo(mirror, S);
+    const bool mir = mg.mir, mtile1_in = mg.t1_in;
+    const int mtile0 = mg.t0, tyi = mg.tyi;
     if (tid == 64 && prev >= 0 && *sOv) {            // (the last image's overflow)
         *sOv = 0;
         *sDn = C32_DCAP;
         xflags[(img0 + prev) * TPI + tile] = 1;
+        if (mir) {
+            xflags[(img0 + prev) * TPI + mtile0] = 1;
+            if (mtile1_in) xflags[(img0 + prev) * TPI + mtile0 + tpr] = 1;
+        }
+    }
+    uint32_t* sT = (uint32_t*)sV;                    // transposed class words [image][low | high][tile column] (the pass buffers are dead)
+    if (mir) {
+        // an image whose grey values are not their own mirror image (k_gray_c3 found a pixel whose two summation orders
+        // round differently: ~1e-8 of the pixels) is not mirrored: its tiles below the diagonal go to the exact kernel
+        if (tid >= 128 && tid < 128 + nb && asym != nullptr && asym[img0 + (tid - 128)]) {
+            xflags[(img0 + (tid - 128)) * TPI + mtile0] = 1;
+            if (mtile1_in) xflags[(img0 + (tid - 128)) * TPI + mtile0 + tpr] = 1;
+        }
+        // the verdicts of the f32 test, transposed: 32 rows x 64 columns -> 64 half words (the undecidable pixels are still
+        // 0 in both forms; the resolver below sets them per position)
+        for (int k = wv; k < nb * 2; k += 4) {       // wave-uniform
+            const stp_u64 t = wave_transpose64(lane < CT_Y ? sBits[k * CT_Y + lane] : 0ull, lane);
+            sT[k * CT_X + lane] = (uint32_t)t;
+        }
     }
     __syncthreads();
 #if STP_ABLATE_C32 == 0                  /* (4: ... or with the undecidable pixels left unsettled) */
@@ -1049,7 +1143,15 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         double* sSp = (double*)(smem + L.sS + wv * C32_RES_WAVE_BYTES);
         for (int k = wv; k < nd; k += 4) {           // wave-uniform
             const int d = sD[k], bi = d >> 11;
-            canny32_resolve<R>(T, d & 2047, lane, sW, sB, gray + (img0 + bi) * (STP_PITCH * STP_PITCH), sVp, sSp, sBits + bi * 2 * CT_Y);
+            const float* gimg = gray + (img0 + bi) * (STP_PITCH * STP_PITCH);
+            int ln = lane;
+            asm volatile("" : "+v"(ln));             // (opaque per pixel and form: the element geometry a lane derives from its number is
+                                                     //  recomputed, not kept live across both inlined forms -- that spilled at radius 8)
+            canny32_resolve<R>(T, d & 2047, ln, sW, sB, gimg, sVp, sSp, sBits + bi * 2 * CT_Y);
+            if (mir) {
+                asm volatile("" : "+v"(ln));
+                canny32_resolve<R, true>(T, d & 2047, ln, sW, sB, gimg, sVp, sSp, nullptr, sT + bi * 2 * CT_X);
+            }
         }
     }
     __syncthreads();
@@ -1060,6 +1162,22 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
             const size_t o = (img0 + bi) * (STP_FRAME_MAX * STP_NW) + STP_CLS(y, T.tx0 >> 6);   // 32 rows = 256 contiguous bytes per plane
             low[o] = sBits[bi * 2 * CT_Y + row];
             high[o] = sBits[bi * 2 * CT_Y + CT_Y + row];
+        }
+    }
+    if (mir) {
+        // ... and their transposes: rows tx0 .. tx0 + 63 of word column ty0 / 64, the half word of this tile's 32 rows.  The
+        // other half belongs to the tile row's partner (ty0 +- 32, same word); where that partner lies beyond the image the
+        // whole word is written, so that k_lines never reads a word nobody wrote.
+        const int wcol = tyi >> 1, half = tyi & 1;
+        const bool solo = half == 0 && T.ty0 + CT_Y >= S;
+        for (int i = tid; i < nb * CT_X; i += nt) {
+            const int bi = i / CT_X, xx = i - bi * CT_X, row = T.tx0 + xx;
+            if (row < S) {
+                const size_t o = (img0 + bi) * (STP_FRAME_MAX * STP_NW) + STP_CLS(row, wcol);
+                const uint32_t l32 = sT[(bi * 2) * CT_X + xx], h32 = sT[(bi * 2 + 1) * CT_X + xx];
+                if (solo) { low[o] = l32; high[o] = h32; }
+                else { ((uint32_t*)low)[2 * o + half] = l32; ((uint32_t*)high)[2 * o + half] = h32; }
+            }
         }
     }
 }
@@ -2535,6 +2653,7 @@ static stp_fastdiv make_fastdiv(stp_ctx* ctx, const double* w, int R)
 static bool canny_tiled_radius(int R) { return R == 4 || R == 6 || R == 8 || R == 10 || R == 12; }
 #define STP_CANNY_RADII(X) X(4) X(6) X(8) X(10) X(12)
 
+static int band_symmetric(stp_ctx* ctx, const stp_band* b, int* out);
 // shared by stp_stripe_search and stp_dbg_stages: run the three image kernels on frames
 // [f0, f0+nf) for n_levels levels; buffers sized by the caller.
 static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, int f0, int nf,
@@ -2561,16 +2680,42 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         HIPCHK(ws_get(ctx, WS_CELLS, nimg * GC_ROWS * GC_COLS * sizeof(float2), &p_cells));
     // (measured and dropped: running k_lines of one sub-chunk on a second stream beside gray / canny of the
     //  next -- chain wall 5.99 ms alone vs 6.02 / 6.29 / 6.83 ms with 2 / 4 / 8 sub-chunks)
+    // Which kernels run (read per call: the tests compare them in one process).  STP_GRAY=exact selects k_gray<1> (every
+    // operation of the reference; the certified kernel needs finite 1 / M), STP_CANNY=exact k_canny_pipe (every intermediate
+    // in the reference's f64 arithmetic), STP_SYM=0 switches the use of the images' symmetry off.
+    const char* gray_env = getenv("STP_GRAY");
+    const bool gray_exact = (gray_env && strcmp(gray_env, "exact") == 0) || !levels_normal;
+    const char* canny_env = getenv("STP_CANNY");
+    const bool canny_exact = canny_env && strcmp(canny_env, "exact") == 0;
+    const bool canny_f32 = canny_tiled_radius(R) && nb <= C32_NBMAX && !canny_exact;
+    const int ctiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
+    // Image symmetry (k_canny_f32): the tiles below the diagonal take their class words from the transposes of the tiles above
+    // it.  Needs a band that is symmetric bit for bit (verified once per band: band_symmetric) and grey images whose every
+    // pixel equals its mirror image -- k_gray_c3 reports the images where one does not (the flags behind the tile flags).
+    int mirror = 0;
+    if (canny_f32 && a == 1 && !gray_exact) {
+        const char* sym_env = getenv("STP_SYM");
+        if (!(sym_env && sym_env[0] == '0')) { const int rcs = band_symmetric(ctx, band, &mirror); if (rcs) return rcs; }
+    }
+    void* p_x = nullptr;         // k_canny_f32's flags: tile-images for the exact kernel [nimg x tiles], asymmetric images [nimg]
+    const size_t nflags = nimg * ctiles;
+    if (canny_f32) {
+        HIPCHK(ws_get(ctx, WS_C32Q, nflags + nimg, &p_x));
+        // the flags are zero between launches: k_canny_pipe_list clears every flag it has served, so the buffer is
+        // cleared here only when it is new (no fill kernel -- two launch gaps -- between k_gray and the Canny kernel)
+        if (ctx->c32q_zero != p_x || ctx->c32q_zero_bytes < ctx->ws_bytes[WS_C32Q]) {
+            HIPCHK(hipMemsetAsync(p_x, 0, ctx->ws_bytes[WS_C32Q], ctx->stream));
+            ctx->c32q_zero = p_x; ctx->c32q_zero_bytes = ctx->ws_bytes[WS_C32Q];
+        }
+    }
+    uint8_t* p_asym = mirror ? (uint8_t*)p_x + nflags : nullptr;
     prof_scope chain_scope(ctx, "chain_wall", ipx * 26.0);     // gray + canny + lines as one interval
     {
         prof_scope ps(ctx, "gray", ipx * 12.0);          // stage A of SURVEY 8(d): 8 B read + 4 B written per image px
         const int tiles = ((STP_FRAME_MAX + GT_X - 1) / GT_X) * ((STP_FRAME_MAX + GT_Y - 1) / GT_Y);
-        // STP_GRAY=exact selects k_gray<1> (every operation of the reference); the certified kernel needs finite 1 / M
-        const char* gray_env = getenv("STP_GRAY");        // read per call: the tests compare both kernels in one process
-        const bool gray_exact = (gray_env && strcmp(gray_env, "exact") == 0) || !levels_normal;
         if (a == 1 && !gray_exact)
             hipLaunchKernelGGL(k_gray_c3, dim3(tiles, STP_GRAY_LEVRUNS < nlev ? STP_GRAY_LEVRUNS : nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
-                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (float2*)p_cells);
+                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (float2*)p_cells, p_asym);
         else if (a == 1)
             hipLaunchKernelGGL(k_gray<1>, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
                                fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray, (float2*)p_cells);
@@ -2584,32 +2729,20 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         const int tiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
         const dim3 cg(tiles, (unsigned)nimg);
         const unsigned pgrid = (unsigned)(((nf * nlev + 7) / 8) * 8 * tiles);
-        // STP_CANNY=exact selects k_canny_pipe (every intermediate in the reference's f64 arithmetic)
-        const char* canny_env = getenv("STP_CANNY");      // read per call: the tests compare both kernels in one process
-        const bool canny_exact = canny_env && strcmp(canny_env, "exact") == 0;
-        if (canny_tiled_radius(R) && nb <= C32_NBMAX && !canny_exact) {    // (without k_gray's cell maxima -- bfilter other than 3 -- g is the
-                                                                           //  largest grey value k_gray can write, and no tile is skipped as flat)
+        if (canny_f32) {    // (without k_gray's cell maxima -- bfilter other than 3 -- g is the largest grey value k_gray can write,
+                            //  and no tile is skipped as flat)
             stp_w32 W32;
             for (int k = 0; k <= CT_RMAX; k++) W32.w[k] = k <= R ? (float)prm->gauss_w[k] : 0.0f;
             c32_budget(prm->gauss_w, R, &W32);
-            const size_t nflags = nimg * tiles;       // tile-images k_canny_f32 hands over to the exact kernel (see there)
-            void* p_x = nullptr;
-            HIPCHK(ws_get(ctx, WS_C32Q, nflags, &p_x));
-            // the flags are zero between launches: k_canny_pipe_list clears every flag it has served, so the buffer is
-            // cleared here only when it is new (no fill kernel -- two launch gaps -- between k_gray and the Canny kernel)
-            if (ctx->c32q_zero != p_x || ctx->c32q_zero_bytes < ctx->ws_bytes[WS_C32Q]) {
-                HIPCHK(hipMemsetAsync(p_x, 0, ctx->ws_bytes[WS_C32Q], ctx->stream));
-                ctx->c32q_zero = p_x; ctx->c32q_zero_bytes = ctx->ws_bytes[WS_C32Q];
-            }
             const stp_fastdiv fd = make_fastdiv(ctx, prm->gauss_w, R);
             const size_t smem = canny32_layout(R).total, smem_x = canny_pipe_smem_bytes(R) + CANNY_PIPE_BITS_BYTES;
             const unsigned xgrid = (unsigned)std::min<size_t>(2048, (nflags + 255) / 256);
             switch (R) {
 #define STP_X(RR) case RR: \
                 hipLaunchKernelGGL(k_canny_f32<RR>, dim3(pgrid), dim3(256), smem, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, d_w, \
-                                   d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x); \
+                                   d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x, mirror, (const uint8_t*)p_asym); \
                 hipLaunchKernelGGL(k_canny_pipe_list<RR>, dim3(xgrid), dim3(256), smem_x, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, \
-                                   d_w, d_low, d_high, fd, (uint8_t*)p_x); \
+                                   d_w, d_low, d_high, fd, (uint8_t*)p_x, p_asym); \
                 break;
                 STP_CANNY_RADII(STP_X)
 #undef STP_X
@@ -3030,6 +3163,7 @@ int stp_dbg_canny_f32(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
 #define STP_X(RR) case RR: \
         hipLaunchKernelGGL((k_canny_f32<RR, true>), dim3(pgrid), dim3(256), smem, ctx->stream, (const float*)dGray, fr->d_S, f, 1, 1, nb, \
                            (const double*)bW.p, (stp_u64*)bLow.p, (stp_u64*)bHigh.p, W32, (const float2*)p_cells, (uint8_t*)bX.p, \
+                           0, (const uint8_t*)nullptr /* every tile computed: the dump covers the whole image */, \
                            (float*)bPl.p, (int)bi, (unsigned long long*)bC.p); \
         break;
         STP_CANNY_RADII(STP_X)

@@ -17,9 +17,11 @@ static long long g_c32_uncertain = 0, g_c32_candidates = 0;
 // and the scale g the tile used; pitch STP_PITCH
 static float g_c32_last_eg = 0.0f;
 static float *g_c32_dS = nullptr, *g_c32_dI = nullptr, *g_c32_dJ = nullptr, *g_c32_dM = nullptr, *g_c32_dG = nullptr, *g_c32_dE = nullptr;
+// sCm (image symmetry, k_canny_f32's `mirror`): class of the MIRROR image (column, row) of every tile pixel, [tile column][tile
+// row] -- the f32 verdict where there is one, the reference's arithmetic at the mirror position where there is not
 template <int R>
 static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float gmax, const double* sB, float* sV, float* sM,
-                         uint8_t* sC, bool xin, bool yin)
+                         uint8_t* sC, bool xin, bool yin, uint8_t* sCm = nullptr)
 {
     const int VH = CT_Y + 4;
     const float qnan = std::numeric_limits<float>::quiet_NaN();
@@ -53,6 +55,7 @@ static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float g
         if (y < T.S && x < T.S) {
             cls = c32_nms(sS.data(), sM, T, y, x, E);
             if (y >= 1 && x >= 1 && y < T.S - 1 && x < T.S - 1 && sM[(yy + 1) * (CT_X + 2) + xx + 1] >= E.thr) g_c32_candidates++;
+            if (sCm) sCm[xx * CT_Y + yy] = (uint8_t)cls;
             if (cls == 3) {
                 g_c32_uncertain++;
                 float Vp[NV];
@@ -62,8 +65,14 @@ static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float g
                 double M9[9];
                 for (int l = 0; l < 9; l++) M9[l] = c32_res_mag(Sp, l);
                 cls = c32_res_class(Sp, M9);
+                if (sCm) {                              // the mirror pixel (x, y): canny32_resolve<R, true>
+                    for (int l = 0; l < NV; l++) Vp[l] = c32_res_V<R>(T, x, y, l, w, gray);
+                    for (int l = 0; l < 25; l++) Sp[l] = c32_res_S_any<R>(T.S, x, y, l, w, Vp);
+                    for (int l = 0; l < 9; l++) M9[l] = c32_res_mag(Sp, l);
+                    sCm[xx * CT_Y + yy] = (uint8_t)c32_res_class(Sp, M9);
+                }
             }
-        }
+        } else if (sCm) sCm[xx * CT_Y + yy] = 0;
         sC[i] = (uint8_t)cls;
     }
 }
@@ -240,9 +249,17 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
             if (memcmp(&q, &t, 8) != 0) fd.ok = 0;
         }
     }
+    // blocked 3: k_canny_f32 with `mirror` -- the tiles strictly below the diagonal are not computed, the tiles whose transpose
+    // lies there hand their class words over transposed (the image must equal its transpose)
+    const bool mirror = blocked == 3;
+    if (mirror) blocked = 2;
+    std::vector<uint8_t> sCm(CT_Y * CT_X);
     for (int ty0 = 0; ty0 < S; ty0 += CT_Y)
         for (int tx0 = 0; tx0 < S; tx0 += CT_X) {
             stp_tile T; T.S = S; T.ty0 = ty0; T.tx0 = tx0;
+            const int tyi = ty0 / CT_Y, txi = tx0 / CT_X;
+            if (mirror && tyi >= 2 * txi + 2) continue;
+            const bool mir = mirror && txi > (tyi >> 1);
             float gmax = 1.0f;
             if (blocked && emu_tiled_radius(R)) {
                 // k_canny_pipe's flat-window rule, evaluated here straight from the grey image over the same
@@ -272,14 +289,23 @@ void emu_canny2(const float* gray_in /* pitch 400 */, int S, int R, const double
                 std::fill(sM.begin(), sM.end(), std::numeric_limits<float>::quiet_NaN());
             }
             if (blocked == 2 && emu_tiled_radius(R)) {     // k_canny_f32: f32 phases, certified classes, exact resolver
+                uint8_t* cm = mir ? sCm.data() : nullptr;
                 switch (R) {
-                    case 4: emu_tile_c32<4>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin); break;
-                    case 6: emu_tile_c32<6>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin); break;
-                    case 8: emu_tile_c32<8>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin); break;
-                    case 10: emu_tile_c32<10>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin); break;
-                    default: emu_tile_c32<12>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin); break;
+                    case 4: emu_tile_c32<4>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin, cm); break;
+                    case 6: emu_tile_c32<6>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin, cm); break;
+                    case 8: emu_tile_c32<8>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin, cm); break;
+                    case 10: emu_tile_c32<10>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin, cm); break;
+                    default: emu_tile_c32<12>(T, w, gray, gmax, sB.data(), sV.data(), sM.data(), sC.data(), xin, yin, cm); break;
                 }
                 canny_p5(0, 1, T, sC.data(), low, high);
+                if (mir)                                   // the transposed words: rows tx0 .., half word (ty0 / 32) & 1 of word ty0 / 64
+                    for (int xx = 0; xx < CT_X; xx++)
+                        for (int yy = 0; yy < CT_Y; yy++) {
+                            const int row = tx0 + xx, col = ty0 + yy, cls = sCm[xx * CT_Y + yy];
+                            if (row >= S || col >= S || !cls) continue;
+                            low[STP_CLS(row, col >> 6)] |= 1ull << (col & 63);
+                            if (cls == 2) high[STP_CLS(row, col >> 6)] |= 1ull << (col & 63);
+                        }
                 continue;
             }
             if (blocked && emu_tiled_radius(R)) {          // the device path of the tiled radii (k_canny_pipe<R>)
@@ -318,6 +344,13 @@ void emu_canny_f32(const float* gray, int S, int R, const double* w, stp_u64* lo
 {
     g_c32_uncertain = 0; g_c32_candidates = 0;
     emu_canny2(gray, S, R, w, low, high, 2);
+    if (counts) { counts[0] = g_c32_candidates; counts[1] = g_c32_uncertain; }
+}
+// ... with `mirror` (the image must be symmetric): the tiles below the diagonal from the transposes of the tiles above it
+void emu_canny_f32_sym(const float* gray, int S, int R, const double* w, stp_u64* low, stp_u64* high, long long* counts)
+{
+    g_c32_uncertain = 0; g_c32_candidates = 0;
+    emu_canny2(gray, S, R, w, low, high, 3);
     if (counts) { counts[0] = g_c32_candidates; counts[1] = g_c32_uncertain; }
 }
 

@@ -48,6 +48,14 @@ def _canny_f32(emu, full, S, R, gw):
     return _unpack_cls(low, S).astype(np.uint8) + _unpack_cls(high, S), cnt
 
 
+def _canny_f32_sym(emu, full, S, R, gw):
+    """... with `mirror` (round 6): the tiles strictly below the diagonal are not computed; the tiles whose transpose lies there
+    hand their class words over transposed -- the f32 verdicts as they are, the undecidable pixels settled once per position."""
+    low = np.zeros(2800, np.uint64); high = np.zeros(2800, np.uint64); cnt = np.zeros(2, np.int64)
+    emu.emu_canny_f32_sym(_p(np.ascontiguousarray(full)), S, R, _p(gw), _p(low), _p(high), _p(cnt))
+    return _unpack_cls(low, S).astype(np.uint8) + _unpack_cls(high, S), cnt
+
+
 @pytest.mark.parametrize('ci', [0, 2, 4, 5])
 def test_emulated_kernels_match_oracle(emu, golden_stages, chr7, ci):
     g = golden_stages
@@ -80,6 +88,9 @@ def test_emulated_kernels_match_oracle(emu, golden_stages, chr7, ci):
         assert np.array_equal(_unpack_cls(low, S).astype(np.uint8) + _unpack_cls(high, S), dbg['cls'])
         cls32, cnt = _canny_f32(emu, gray[bi], S, 8, gw)       # k_canny_f32's phases: same classes, few exact resolutions
         assert np.array_equal(cls32, dbg['cls']) and cnt[1] < 0.01 * cnt[0] + 50
+        assert np.array_equal(gray[bi, :S, :S], gray[bi, :S, :S].T)          # a frame's image is its own transpose ...
+        cls32s, cnts = _canny_f32_sym(emu, gray[bi], S, 8, gw)               # ... so the tiles below the diagonal need not be computed
+        assert np.array_equal(cls32s, dbg['cls']) and cnts[0] <= cnt[0]
         dbgw = np.zeros(4 * 2800, np.uint64); cols = np.zeros(1200, np.int16); recs = (ER * 128)(); sw = C.c_int(0)
         n = emu.emu_lines(_p(low), _p(high), _p(band), W, hw, C.c_int64(start), _p(nz), S, 10, 8, _p(dbgw), _p(cols), recs,
                           128, C.byref(sw))
@@ -403,3 +414,55 @@ def test_interior_flat_window_threshold(emu, golden_stages, sigma, key):
                 cls32, _ = _canny_f32(emu, img, S, R, gw)
                 assert np.array_equal(cls32, dbg['cls']), 'pattern %d base %.2f amp %.4f: %d pixels differ' % (
                     pi, base, amp, int((cls32 != dbg['cls']).sum()))
+
+
+# ----------------------------------------------------------------------------- image symmetry (k_canny_f32's `mirror`)
+def _symmetric_images(S, seed):
+    """Grey images that equal their transpose bit for bit: noise, steps along and across the diagonal, a square on the diagonal,
+    a staircase of diagonal bands (plateaus and exact ties: the resolver decides, at both positions of a pair)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:S, 0:S]
+    n = 0.25 * rng.standard_normal((S, S))
+    base = 0.5 + 0.35 * np.sin((xx + yy) / 9.0) * np.cos((xx - yy) / 13.0)
+    imgs = [0.299 + 0.701 * np.clip(base + (n + n.T) / 2, 0, 1),
+            np.where(xx + yy < S, 0.2, 0.95),
+            np.where(np.abs(xx - yy) > 7, 0.35, 0.85),
+            0.5 + 0.4 * ((np.abs(xx - S // 2) < S // 5) & (np.abs(yy - S // 2) < S // 5)),
+            0.3 + 0.1 * ((np.abs(xx - yy) // 16) % 5),
+            np.maximum(np.where(xx < S // 2, 0.25, 0.9), np.where(yy < S // 2, 0.25, 0.9))]
+    out = [np.ascontiguousarray(i, dtype=np.float32) for i in imgs]
+    for i in out:
+        assert np.array_equal(i, i.T)
+    return out
+
+
+@pytest.mark.parametrize('sigma,key', [(2.0, 'gw_2p0'), (2.5, 'gw_2p5')])
+@pytest.mark.parametrize('S', [400, 399, 301, 225, 143, 97, 64, 41, 12])
+def test_canny_mirrored_tiles(emu, golden_stages, S, sigma, key):
+    """Class maps with the tiles below the diagonal taken from the transposes of the tiles above it == the oracle's, on symmetric
+    images of sizes that end inside a tile row / column / word half, both default radii."""
+    gw = np.ascontiguousarray(golden_stages[key])
+    R = (len(gw) - 1) // 2
+    for k, img in enumerate(_symmetric_images(S, 5 + S)):
+        full = np.zeros((400, 400), np.float32)
+        full[:S, :S] = img
+        oe, dbg = O.canny(img, gw, R, debug=True)
+        got, cnt = _canny_f32_sym(emu, full, S, R, gw)
+        assert np.array_equal(got, dbg['cls']), 'mirrored tiles, image %d (S=%d, sigma %.1f)' % (k, S, sigma)
+        ref, cnt0 = _canny_f32(emu, full, S, R, gw)
+        assert np.array_equal(ref, got)
+        if S > 128:
+            assert cnt[0] < cnt0[0] or cnt0[0] == 0          # fewer tiles ran
+
+
+@pytest.mark.parametrize('sigma', [1.0, 1.5, 3.0])
+def test_canny_mirrored_tiles_other_radii(emu, sigma):
+    from oracle.oracle import gauss_weights
+    gw, R = gauss_weights(sigma)
+    for S in (400, 210):
+        for k, img in enumerate(_symmetric_images(S, 77)[:3]):
+            full = np.zeros((400, 400), np.float32)
+            full[:S, :S] = img
+            oe, dbg = O.canny(img, gw, R, debug=True)
+            got, _ = _canny_f32_sym(emu, full, S, R, gw)
+            assert np.array_equal(got, dbg['cls']), 'mirrored tiles, image %d (S=%d, sigma %.1f)' % (k, S, sigma)
