@@ -2693,9 +2693,11 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     // it.  Needs a band that is symmetric bit for bit (verified once per band: band_symmetric) and grey images whose every
     // pixel equals its mirror image -- k_gray_c3 reports the images where one does not (the flags behind the tile flags).
     int mirror = 0;
+    bool sym_all = false;
     if (canny_f32 && a == 1 && !gray_exact) {
         const char* sym_env = getenv("STP_SYM");
         if (!(sym_env && sym_env[0] == '0')) { const int rcs = band_symmetric(ctx, band, &mirror); if (rcs) return rcs; }
+        sym_all = sym_env && strcmp(sym_env, "report-all") == 0;
     }
     void* p_x = nullptr;         // k_canny_f32's flags: tile-images for the exact kernel [nimg x tiles], asymmetric images [nimg]
     const size_t nflags = nimg * ctiles;
@@ -2716,6 +2718,9 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         if (a == 1 && !gray_exact)
             hipLaunchKernelGGL(k_gray_c3, dim3(tiles, STP_GRAY_LEVRUNS < nlev ? STP_GRAY_LEVRUNS : nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
                                fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (float2*)p_cells, p_asym);
+        // (test hook: STP_SYM=report-all marks every image as "has a grey pixel that differs from its mirror image", so the
+        //  tests can drive the path such an image takes -- its tiles below the diagonal through the exact kernel -- at will)
+        if (p_asym && sym_all) HIPCHK(hipMemsetAsync(p_asym, 1, nimg, ctx->stream));
         else if (a == 1)
             hipLaunchKernelGGL(k_gray<1>, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
                                fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray, (float2*)p_cells);

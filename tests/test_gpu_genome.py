@@ -114,6 +114,13 @@ def test_mm10_genome_compute_determinism_invariants_and_sampled_frames(tmp_path)
         os.environ.pop('STP_CANNY', None)
         os.environ.pop('STP_GRAY', None)
     assert a == c, 'the certified kernels (k_canny_f32, k_gray_c3) and the exact ones (k_canny_pipe, k_gray<1>) give different tables'
+    # round 6: the shipped kernels with every Canny tile computed (no use of the images' symmetry)
+    os.environ['STP_SYM'] = '0'
+    try:
+        d = _run_compute(table, str(tmp_path / 'd'), '0.95,0.96,0.97,0.98,0.99')
+    finally:
+        os.environ.pop('STP_SYM', None)
+    assert a == d, 'mirrored class words (k_canny_f32 with the images\' symmetry) and computed ones give different tables'
     u, f = _check_tables(a[0], a[1], names, MM10, levels, 0.1)
     assert len(u) > 30000 and len(f) > 2000 and set(u['chr']) == set(names)
     # >= 40 frames across all chromosomes against the oracle: the facade's own quantiles and searches
