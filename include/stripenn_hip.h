@@ -127,6 +127,12 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
                          int32_t nframes, int32_t flags, stp_frames** out);
 int stp_frames_info(stp_ctx* ctx, const stp_frames* fr, int32_t* S_out, int16_t* nz_out /* nframes*400 */,
                     double* medpixel_out /* nframes, may be NULL */);
+/* Frame overlap (round 6).  search_frame's windows advance by 200 bins and are 400 wide (getStripe.py:794-799), so the trailing block
+ * of frame i is the leading block of frame i + 1 and the reference computes the images of that block twice.  shift_out[i] = index
+ * (in frame i's compacted coordinates) where the block shared with frame i + 1 starts when both compacted frames keep exactly
+ * the same bins of it, else -1: the search then takes the class maps of the block's interior (Gaussian radius + 3 pixels from
+ * its border) for frame i from frame i + 1 instead of computing them (STP_REUSE=0 in the environment: always computed). */
+int stp_frames_overlap(stp_ctx* ctx, const stp_frames* fr, int32_t* shift_out /* nframes */);
 void stp_frames_free(stp_ctx* ctx, stp_frames* fr);
 
 /* ---- StripeSearch ------------------------------------------------------------------------

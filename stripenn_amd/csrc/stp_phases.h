@@ -1024,6 +1024,97 @@ STP_HD stp_u64 stp_runfill(stp_u64 mask, stp_u64 seed)
     return stp_brev64(dn);
 }
 
+// ---- frame overlap (round 6) -------------------------------------------------------------------------------------------
+// Frames advance by 200 bins and are 400 wide (getStripe.py:794-799): the trailing 200 x 200 block of frame f is the leading
+// block of frame f + 1.  Blur, Gaussian, Sobel and the local-maximum test are functions of a pixel's neighbourhood alone
+// wherever that neighbourhood lies inside both images and the two compacted frames keep the same bins there: the class of
+// (r, c) in frame f is then the class of (r - shift, c - shift) in frame f + 1 -- the SAME operations on the SAME numbers,
+// bit for bit, whatever the arithmetic.  How far from the block's border: the class of a pixel reads the magnitudes of its 3 x 3
+// neighbourhood (1), a magnitude the smoothed values of its 3 x 3 neighbourhood (1), a smoothed value the grey values R rows
+// and columns away -- all of them inside the image, or the window is cut and renormalised (R) -- and a grey value the contact
+// values one pixel away, inside the image or the 3 x 3 mean reflects (1): R + 3.  (Hysteresis runs per frame, on the whole map.)
+// The host marks a frame whose trailing kept bins are exactly the leading kept bins of its successor (shift = their first
+// index in this frame; -1 otherwise); k_canny_f32 then skips the tiles that lie inside the square [lo, hi)^2 and k_lines' loader
+// takes those class words from the successor's planes.
+#define STP_REUSE_MARGIN(R) ((R) + 3)
+struct stp_reuse { int lo, hi, shift; };           // lo >= hi: nothing is taken from the next frame
+STP_HD stp_reuse stp_reuse_of(int shift, int S, int R, bool next_in_launch)
+{
+    stp_reuse U;
+    U.shift = shift;
+    U.lo = shift + STP_REUSE_MARGIN(R);
+    U.hi = (shift >= 0 && next_in_launch) ? S - STP_REUSE_MARGIN(R) : 0;
+    if (shift < 0) U.lo = 1;
+    return U;
+}
+// is tile (ty, tx) -- CT_Y rows x CT_X columns, the grid of the Canny kernels -- wholly inside the square
+STP_HD bool stp_reuse_tile(stp_reuse U, int ty, int tx)
+{
+    return U.lo < U.hi && ty * 32 >= U.lo && ty * 32 + 32 <= U.hi && tx * 64 >= U.lo && tx * 64 + 64 <= U.hi;
+}
+// the columns of word w of row r that no tile of this frame writes.  With `mirror` (k_canny_f32, image symmetry) a tile
+// strictly below the diagonal (tile row >= 2 x word + 2) receives its two half words from the tiles (2 w + h, r / 64) above
+STP_HD stp_u64 stp_reuse_mask(stp_reuse U, int mirror, int r, int w)
+{
+    if (U.lo >= U.hi) return 0ull;
+    const int ty = r >> 5;
+    if (mirror && ty >= 2 * w + 2)
+        return (stp_reuse_tile(U, 2 * w, r >> 6) ? 0xFFFFFFFFull : 0ull) | (stp_reuse_tile(U, 2 * w + 1, r >> 6) ? 0xFFFFFFFF00000000ull : 0ull);
+    return stp_reuse_tile(U, ty, w) ? ~0ull : 0ull;
+}
+// bits c0 .. c0 + 63 of row r of a class plane (word-column-major); columns outside the plane read as 0
+STP_HD stp_u64 stp_cls_bits(const stp_u64* __restrict__ plane, int r, int c0)
+{
+    const int w0 = c0 >> 6, sh = c0 & 63;           // (arithmetic shift: floor for a negative column)
+    const stp_u64 a = (w0 >= 0 && w0 < STP_NW) ? plane[STP_CLS(r, w0)] : 0ull;
+    if (sh == 0) return a;
+    const stp_u64 b = (w0 + 1 >= 0 && w0 + 1 < STP_NW) ? plane[STP_CLS(r, w0 + 1)] : 0ull;
+    return (a >> sh) | (b << (64 - sh));
+}
+// k_lines' loader with the overlap: a thread first REQUESTS the words it will patch from the next frame's planes (at most
+// STP_REUSE_ITEMS (row, word) items of the square's bounding box), then runs the plain load -- all global loads are in flight
+// together: as a second pass behind the plain load the patch cost every image one more memory round trip (+1.5 ms per genome
+// step) -- and after a barrier writes the requested bits over whatever the skipped tiles' words held.
+#define STP_REUSE_ITEMS 3
+struct stp_reuse_fetch { stp_u64 m[STP_REUSE_ITEMS], lo[STP_REUSE_ITEMS], hi[STP_REUSE_ITEMS]; int k[STP_REUSE_ITEMS]; };
+STP_HD void lines_reuse_request(int tid, int nt, int S, stp_reuse U, int mirror, const stp_u64* __restrict__ low_next,
+                                const stp_u64* __restrict__ high_next, stp_reuse_fetch* F)
+{
+    const int ty0 = (U.lo + 31) >> 5, ty1 = U.hi >> 5;                // tile rows / word columns wholly inside the square
+    const int tx0 = (U.lo + 63) >> 6, tx1 = U.hi >> 6;
+    const int r0 = ty0 << 5, nr = (ty1 - ty0) << 5;
+    // words: the skipped tiles' own (tx0 .. tx1) and, with `mirror`, the words that hold their transposes' half words
+    const int w0 = mirror && (ty0 >> 1) < tx0 ? (ty0 >> 1) : tx0, w1 = mirror && ((ty1 + 1) >> 1) > tx1 ? ((ty1 + 1) >> 1) : tx1;
+    const int nwu = (S + 63) >> 6, wl = w0 < 0 ? 0 : w0, wh = w1 > nwu ? nwu : w1, nw = wh - wl;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int q = 0; q < STP_REUSE_ITEMS; q++) {
+        const int i = tid + q * nt;
+        F->m[q] = 0ull; F->k[q] = 0;
+        if (nr > 0 && nw > 0 && i < nr * nw) {
+            const int w = wl + i / nr, r = r0 + i % nr;
+            const stp_u64 m = stp_reuse_mask(U, mirror, r, w);
+            if (m) {
+                F->m[q] = m; F->k[q] = r * STP_NW + w;
+                F->lo[q] = stp_cls_bits(low_next, r - U.shift, 64 * w - U.shift);
+                F->hi[q] = stp_cls_bits(high_next, r - U.shift, 64 * w - U.shift);
+            }
+        }
+    }
+}
+STP_HD void lines_reuse_patch(const stp_reuse_fetch* F, stp_u64* sLow, stp_u64* sE)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int q = 0; q < STP_REUSE_ITEMS; q++)
+        if (F->m[q]) {
+            const int k = F->k[q];
+            sLow[k] = (sLow[k] & ~F->m[q]) | (F->lo[q] & F->m[q]);
+            sE[k] = (sE[k] & ~F->m[q]) | (F->hi[q] & F->m[q]);
+        }
+}
 STP_HD void lines_load(int tid, int nt, int S, const stp_u64* __restrict__ low_img,
                        const stp_u64* __restrict__ high_img, stp_u64* sLow, stp_u64* sE)
 {

@@ -220,9 +220,6 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
     stp_tile T;
     T.S = S; T.ty0 = (blockIdx.x / tpr) * GT_Y; T.tx0 = (blockIdx.x % tpr) * GT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
-#if defined(STP_ABLATE_REUSE) && STP_ABLATE_REUSE == 2     /* upper bound only: the canny tiles beside the hole need these grey values */
-    if (S >= 395 && T.ty0 >= 224 && T.ty0 < 384 && T.tx0 >= 256 && T.tx0 < 384) return;
-#endif
     const int tid = threadIdx.x;
     if (tid >= 128 && tid < 128 + NCB && tid - 128 < nb) s_cb[tid - 128] = stp_gray_cb(bvals[tid - 128]);   // (read after the barriers below)
     const int16_t* nzf = fnz + (size_t)f * STP_FRAME_MAX;
@@ -899,6 +896,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
                                                     stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_w32 W32,
                                                     const float2* __restrict__ cells, uint8_t* __restrict__ xflags,
                                                     int mirror /* the images are symmetric: see below */, const uint8_t* __restrict__ asym,
+                                                    const int32_t* __restrict__ fshift /* frame overlap, or null */,
                                                     float* __restrict__ dbg = nullptr, int dbg_bi = -1,
                                                     unsigned long long* __restrict__ dbg_cnt = nullptr)
 {
@@ -915,9 +913,6 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     stp_tile T;
     T.S = S; T.ty0 = (tile / tpr) * CT_Y; T.tx0 = (tile % tpr) * CT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
-#if defined(STP_ABLATE_REUSE)            /* timing-only build (never shipped): the tiles inside the block a frame shares with its successor are skipped */
-    if (S >= 395 && T.ty0 >= 224 && T.ty0 < 384 && T.tx0 >= 256 && T.tx0 < 384) return;
-#endif
     // Image symmetry (round 6).  The contact matrix is symmetric and a frame keeps the same bins as rows and as columns, so
     // every image is the transpose of itself up to the ORDER of the reference's roundings (box sum row-major, Gaussian rows
     // before columns).  With `mirror` set (the host has verified the band's symmetry bit for bit and k_gray_c3 reports, per
@@ -928,6 +923,9 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     // (the mirror geometry is re-derived from the block index where it is needed -- c32_mgeo -- so that nothing of it lives
     //  across the image loop: held there it cost radius 8 three spilled registers)
     if (mirror && tile / tpr >= 2 * (tile % tpr) + 2) return;
+    // Frame overlap (stp_phases.h): a tile inside the block this frame shares with the next one is not computed -- k_lines takes
+    // its class words (and the words of the tiles below the diagonal its transpose would have covered) from the next frame's planes
+    if (fshift != nullptr && stp_reuse_tile(stp_reuse_of(fshift[f0 + fl], S, R, fl + 1 < nf), tile / tpr, tile % tpr)) return;
     const stp_c32_layout L = canny32_layout(R);
     double* sW = (double*)smem;
     float* sRB = (float*)(smem + L.sRB);
@@ -1354,7 +1352,8 @@ __global__ __launch_bounds__(512, RCAP == STP_RCAP ? 6 : 4) void k_lines(const s
                                                 int minH, int maxW, stp_drec* __restrict__ recs,
                                                 int32_t* __restrict__ rec_count, stp_u64* __restrict__ escr, int want_dbg,
                                                 stp_u64* __restrict__ dbg /* E,V,T1,T2 */, int16_t* __restrict__ dbg_cols,
-                                                int dbg_stop)
+                                                int dbg_stop, const int32_t* __restrict__ fshift /* frame overlap, or null */,
+                                                int gauss_radius, int nframes, int mirror)
 {
     __shared__ stp_u64 bufA[STP_FRAME_MAX * STP_NW];   // low -> V (vert)
     __shared__ stp_u64 bufB[STP_FRAME_MAX * STP_NW];   // E (edges) -> testmat -> row sums
@@ -1378,7 +1377,19 @@ __global__ __launch_bounds__(512, RCAP == STP_RCAP ? 6 : 4) void k_lines(const s
     const stp_u64* himg = high + (size_t)img * (STP_FRAME_MAX * STP_NW);
     stp_u64* eimg = escr + (size_t)img * (STP_FRAME_MAX * STP_NW);
     for (int i = tid; i < S; i += nt) s_nz[i] = fnz[(size_t)f * STP_FRAME_MAX + i];
-    lines_load(tid, nt, S, limg, himg, bufA, bufB);
+    stp_reuse U;                  // the class words of the tiles k_canny_f32 skipped come from the next frame's planes (stp_phases.h)
+    U.lo = 1; U.hi = 0; U.shift = -1;
+    if (fshift != nullptr) U = stp_reuse_of(fshift[f], S, gauss_radius, img / imgs_per_frame + 1 < nframes);
+    if (U.lo < U.hi) {            // workgroup-uniform
+        static_assert(512 * STP_REUSE_ITEMS >= 192 * STP_NW, "every (row, word) item of the largest square has a thread");
+        const size_t nxt = (size_t)imgs_per_frame * (STP_FRAME_MAX * STP_NW);
+        stp_reuse_fetch F;
+        lines_reuse_request(tid, nt, S, U, mirror, limg + nxt, himg + nxt, &F);
+        lines_load(tid, nt, S, limg, himg, bufA, bufB);
+        __syncthreads();          // (the plain load has stored whatever the skipped tiles' words held)
+        lines_reuse_patch(&F, bufA, bufB);
+    } else
+        lines_load(tid, nt, S, limg, himg, bufA, bufB);
     __syncthreads();
     if (dbg_stop == 1) { if (tid == 0) rec_count[img] = (int)(bufB[3] & 0); return; }      // timing-only ablation
     if (!want_dbg) {   // an image without a single strong pixel has no edges (hysteresis keeps only components that hold
@@ -1846,8 +1857,9 @@ struct stp_frames {
     const stp_band* band = nullptr;
     int n = 0;
     int32_t *d_start = nullptr, *d_n0 = nullptr, *d_S = nullptr;
+    int32_t* d_shift = nullptr;       // frame overlap (stp_phases.h): where the block shared with the next frame starts, or -1
     int16_t* d_nz = nullptr;
-    std::vector<int32_t> h_start, h_n0, h_S;
+    std::vector<int32_t> h_start, h_n0, h_S, h_shift;
     std::vector<int16_t> h_nz;
     std::vector<double> h_med;
 };
@@ -2312,6 +2324,7 @@ void stp_frames_free(stp_ctx* ctx, stp_frames* fr)
         pool_release(ctx, fr->d_start, fr->n * sizeof(int32_t));
         pool_release(ctx, fr->d_n0, fr->n * sizeof(int32_t));
         pool_release(ctx, fr->d_S, fr->n * sizeof(int32_t));
+        pool_release(ctx, fr->d_shift, fr->n * sizeof(int32_t));
         pool_release(ctx, fr->d_nz, (size_t)fr->n * STP_FRAME_MAX * sizeof(int16_t));
     }
     delete fr;
@@ -2347,6 +2360,7 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
     FRCHK(pool_alloc(ctx, n * sizeof(int32_t), (void**)&fr->d_start));
     FRCHK(pool_alloc(ctx, n * sizeof(int32_t), (void**)&fr->d_n0));
     FRCHK(pool_alloc(ctx, n * sizeof(int32_t), (void**)&fr->d_S));
+    FRCHK(pool_alloc(ctx, n * sizeof(int32_t), (void**)&fr->d_shift));
     FRCHK(pool_alloc(ctx, (size_t)n * STP_FRAME_MAX * sizeof(int16_t), (void**)&fr->d_nz));
     stp_xfer x(ctx, ctx->aux);
     FRCHK(x.h2d(fr->d_start, fr->h_start.data(), n * sizeof(int32_t)));
@@ -2383,6 +2397,32 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
         const bool even = (((long long)N) % 2) == 0;
         fr->h_med[i] = even ? (b - (b - a) * (1 - 0.5)) : (a + (b - a) * 0.0);
     }
+    // Frame overlap (stp_phases.h, "frame overlap"): frame i is marked when its trailing kept bins are exactly the leading kept
+    // bins of frame i + 1 -- the same absolute bins, one contiguous run in both compacted frames -- and the block it would
+    // take from frame i + 1 does not reach into the block frame i + 1 takes from frame i + 2.
+    fr->h_shift.assign(n, -1);
+    for (int i = 0; i + 1 < n; i++) {
+        const int s0 = fr->h_start[i], e0 = s0 + fr->h_n0[i] - 1, s1 = fr->h_start[i + 1], e1 = s1 + fr->h_n0[i + 1] - 1;
+        const int S0 = fr->h_S[i], S1 = fr->h_S[i + 1];
+        if (!(s1 > s0 && s1 <= e0 && e1 >= e0) || S0 <= 0 || S1 <= 0) continue;
+        const int16_t* z0 = fr->h_nz.data() + (size_t)i * STP_FRAME_MAX;
+        const int16_t* z1 = fr->h_nz.data() + (size_t)(i + 1) * STP_FRAME_MAX;
+        int p = 0;
+        while (p < S0 && s0 + z0[p] < s1) p++;
+        const int q = S0 - p;
+        if (q < 1 || q > S1) continue;
+        bool same = true;
+        for (int k = 0; k < q && same; k++) same = (s0 + z0[p + k]) == (s1 + z1[k]);
+        if (same && q < S1 && s1 + z1[q] <= e0) same = false;        // frame i + 1 keeps a bin of the block that frame i dropped
+        if (same) fr->h_shift[i] = p;
+    }
+    for (int i = 0; i + 2 < n; i++)                                    // (p of frame i + 1 == q of frame i in the reference's geometry)
+        if (fr->h_shift[i] >= 0 && fr->h_shift[i + 1] >= 0 && fr->h_shift[i + 1] < fr->h_S[i] - fr->h_shift[i]) fr->h_shift[i] = -1;
+    {
+        stp_xfer x2(ctx, ctx->aux);
+        FRCHK(x2.h2d(fr->d_shift, fr->h_shift.data(), n * sizeof(int32_t)));
+        FRCHK(x2.finish());
+    }
 #undef FRCHK
     *out = fr;
     return STP_OK;
@@ -2394,6 +2434,13 @@ int stp_frames_info(stp_ctx* ctx, const stp_frames* fr, int32_t* S_out, int16_t*
     if (S_out) memcpy(S_out, fr->h_S.data(), fr->n * sizeof(int32_t));
     if (nz_out) memcpy(nz_out, fr->h_nz.data(), (size_t)fr->n * STP_FRAME_MAX * sizeof(int16_t));
     if (med_out) memcpy(med_out, fr->h_med.data(), fr->n * sizeof(double));
+    return STP_OK;
+}
+
+int stp_frames_overlap(stp_ctx* ctx, const stp_frames* fr, int32_t* shift_out)
+{
+    if (!ctx || !fr || !shift_out) return STP_E_ARG;
+    memcpy(shift_out, fr->h_shift.data(), fr->n * sizeof(int32_t));
     return STP_OK;
 }
 
@@ -2711,6 +2758,13 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         }
     }
     uint8_t* p_asym = mirror ? (uint8_t*)p_x + nflags : nullptr;
+    // Frame overlap: k_canny_f32 skips the tiles inside the block a frame shares with its successor, k_lines fetches their class
+    // words from the successor's planes (STP_REUSE=0 switches it off)
+    const int32_t* p_shift = nullptr;
+    if (canny_f32 && nf > 1) {
+        const char* reuse_env = getenv("STP_REUSE");
+        if (!(reuse_env && reuse_env[0] == '0')) p_shift = fr->d_shift;
+    }
     prof_scope chain_scope(ctx, "chain_wall", ipx * 26.0);     // gray + canny + lines as one interval
     {
         prof_scope ps(ctx, "gray", ipx * 12.0);          // stage A of SURVEY 8(d): 8 B read + 4 B written per image px
@@ -2718,15 +2772,15 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         if (a == 1 && !gray_exact)
             hipLaunchKernelGGL(k_gray_c3, dim3(tiles, STP_GRAY_LEVRUNS < nlev ? STP_GRAY_LEVRUNS : nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
                                fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (float2*)p_cells, p_asym);
-        // (test hook: STP_SYM=report-all marks every image as "has a grey pixel that differs from its mirror image", so the
-        //  tests can drive the path such an image takes -- its tiles below the diagonal through the exact kernel -- at will)
-        if (p_asym && sym_all) HIPCHK(hipMemsetAsync(p_asym, 1, nimg, ctx->stream));
         else if (a == 1)
             hipLaunchKernelGGL(k_gray<1>, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
                                fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray, (float2*)p_cells);
         else
             hipLaunchKernelGGL(k_gray<GT_AMAX>, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
                                fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray, (float2*)nullptr);
+        // (test hook: STP_SYM=report-all marks every image as "has a grey pixel that differs from its mirror image", so the
+        //  tests can drive the path such an image takes -- its tiles below the diagonal through the exact kernel -- at will)
+        if (p_asym && sym_all) HIPCHK(hipMemsetAsync(p_asym, 1, nimg, ctx->stream));
     }
     HIPCHK(hipGetLastError());
     {
@@ -2745,7 +2799,7 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
             switch (R) {
 #define STP_X(RR) case RR: \
                 hipLaunchKernelGGL(k_canny_f32<RR>, dim3(pgrid), dim3(256), smem, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, d_w, \
-                                   d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x, mirror, (const uint8_t*)p_asym); \
+                                   d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x, mirror, (const uint8_t*)p_asym, p_shift); \
                 hipLaunchKernelGGL(k_canny_pipe_list<RR>, dim3(xgrid), dim3(256), smem_x, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, \
                                    d_w, d_low, d_high, fd, (uint8_t*)p_x, p_asym); \
                 break;
@@ -2785,11 +2839,11 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         if (rcap == STP_RCAP)
             hipLaunchKernelGGL(k_lines<STP_RCAP>, dim3((unsigned)nimg), dim3(512), 0, ctx->stream, d_low, d_high, band->d, band->W,
                                band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, ipf, prm->minH, prm->maxW, d_recs, d_cnt,
-                               (stp_u64*)p_edges, want_dbg, d_dbg, d_dbgc, lines_stop);
+                               (stp_u64*)p_edges, want_dbg, d_dbg, d_dbgc, lines_stop, p_shift, R, nf, mirror);
         else
             hipLaunchKernelGGL(k_lines<STP_RCAP_MAX>, dim3((unsigned)nimg), dim3(512), 0, ctx->stream, d_low, d_high, band->d, band->W,
                                band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, ipf, prm->minH, prm->maxW, d_recs, d_cnt,
-                               (stp_u64*)p_edges, want_dbg, d_dbg, d_dbgc, lines_stop);
+                               (stp_u64*)p_edges, want_dbg, d_dbg, d_dbgc, lines_stop, p_shift, R, nf, mirror);
     }
     HIPCHK(hipGetLastError());
     return STP_OK;
@@ -3168,7 +3222,7 @@ int stp_dbg_canny_f32(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
 #define STP_X(RR) case RR: \
         hipLaunchKernelGGL((k_canny_f32<RR, true>), dim3(pgrid), dim3(256), smem, ctx->stream, (const float*)dGray, fr->d_S, f, 1, 1, nb, \
                            (const double*)bW.p, (stp_u64*)bLow.p, (stp_u64*)bHigh.p, W32, (const float2*)p_cells, (uint8_t*)bX.p, \
-                           0, (const uint8_t*)nullptr /* every tile computed: the dump covers the whole image */, \
+                           0, (const uint8_t*)nullptr, (const int32_t*)nullptr /* every tile computed: the dump covers the whole image */, \
                            (float*)bPl.p, (int)bi, (unsigned long long*)bC.p); \
         break;
         STP_CANNY_RADII(STP_X)

@@ -20,7 +20,7 @@ _ERRNAMES = {-1: 'STP_E_ARG', -2: 'STP_E_CAPACITY', -3: 'STP_E_HIP', -4: 'STP_E_
 EXPORTS = [
     'stp_version', 'stp_ctx_create', 'stp_ctx_destroy', 'stp_last_error', 'stp_ctx_set_stream',
     'stp_ctx_synchronize', 'stp_band_upload', 'stp_band_pack', 'stp_band_pack_select', 'stp_band_nearest', 'stp_band_download', 'stp_band_wrap_device', 'stp_band_free',
-    'stp_frames_create', 'stp_frames_create_ex', 'stp_frames_info', 'stp_frames_free', 'stp_stripe_search', 'stp_stripe_search_begin', 'stp_stripe_search_count', 'stp_stripe_search_fetch',
+    'stp_frames_create', 'stp_frames_create_ex', 'stp_frames_info', 'stp_frames_overlap', 'stp_frames_free', 'stp_stripe_search', 'stp_stripe_search_begin', 'stp_stripe_search_count', 'stp_stripe_search_fetch',
     'stp_stripe_search_cancel', 'stp_dbg_stages', 'stp_dbg_canny_f32', 'stp_dbg_set_sweep_slots',
     'stp_set_profiling', 'stp_get_stats', 'stp_reset_stats',
 ]
@@ -82,6 +82,8 @@ def load():
     L.stp_frames_create.argtypes = [vp, vp, vp, vp, C.c_int32, C.POINTER(vp)]
     L.stp_frames_create_ex.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.stp_frames_info.argtypes = [vp, vp, vp, vp, vp]
+    if hasattr(L, 'stp_frames_overlap'):      # (absent from an older profiling build named by STP_LIB: only Frames.overlap() needs it)
+        L.stp_frames_overlap.argtypes = [vp, vp, vp]
     L.stp_frames_free.argtypes = [vp, vp]
     L.stp_frames_free.restype = None
     L.stp_stripe_search.argtypes = [vp, vp, C.POINTER(SearchParams), vp, C.c_int32, vp, C.c_int64, C.POINTER(C.c_int64)]
@@ -353,6 +355,12 @@ class Frames:
         self.nz = np.zeros((self.n, STP_FRAME_MAX), np.int16)
         self.medpixel = np.zeros(self.n, np.float64)
         self.ctx._chk(self.ctx.L.stp_frames_info(self.ctx.h, self.h, _ptr(self.S), _ptr(self.nz), _ptr(self.medpixel)))
+
+    def overlap(self):
+        """shift[i] >= 0: the class maps of the block frame i shares with frame i + 1 are taken from frame i + 1 (stp_frames_overlap)"""
+        sh = np.zeros(self.n, np.int32)
+        self.ctx._chk(self.ctx.L.stp_frames_overlap(self.ctx.h, self.h, _ptr(sh)))
+        return sh
 
     def close(self):
         if getattr(self, 'h', None) and self.ctx.h:
