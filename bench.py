@@ -47,7 +47,7 @@ CHR16_BINS = 19642     # mm10 chr16 (98,207,768 bp) at 5 kb
 RESOL = 5000
 MAXPIXEL = [0.95, 0.96, 0.97, 0.98, 0.99]
 BYTES_PER_IMAGE_PX = {'gray': 12.0, 'canny': 5.0, 'lines': 9.0}  # SURVEY.md 8(d) stages A, B, C-F
-SCORE_KERNELS = ('pvalue', 'stripiness', 'score')
+SCORE_KERNELS = ('pvalue', 'stripiness', 'score', 'pvalue_block', 'stripiness_block')
 PMC_FILE = os.path.join(ROOT, 'profiles', 'pmc_current.json')    # written by tools/summarize_profile.py
 
 

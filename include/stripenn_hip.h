@@ -106,7 +106,11 @@ int stp_band_pack_csr(stp_ctx* ctx, const int64_t* bin1_offset, const void* bin2
 int stp_band_nearest(stp_ctx* ctx, const stp_band* band, int32_t* right_out /* nrows */, int32_t* left_out /* nrows */);
 /* Copy a band back to the host (nrows x 2*halfwidth doubles; parity tests, debugging). */
 int stp_band_download(stp_ctx* ctx, const stp_band* band, double* out_host);
-/* Adopt a band that already lives in device memory (caller keeps ownership of dptr). */
+/* Adopt a band that already lives in device memory (caller keeps ownership of dptr).  The memory must stay UNCHANGED for the life
+ * of the handle: the library establishes once per handle whether the band is symmetric bit for bit (k_band_symcheck) and then
+ * reads stripe patches through the symmetry (stp_score, stp_pvalue, stp_stripiness) and takes the Canny class maps of the
+ * tiles below an image's diagonal from the tiles above it (stp_stripe_search); a band rewritten behind the handle would be read
+ * under a stale verdict.  To search other data, free the handle and wrap again. */
 int stp_band_wrap_device(stp_ctx* ctx, const void* dptr, int64_t nrows, int32_t halfwidth, stp_band** out);
 void stp_band_free(stp_ctx* ctx, stp_band* band);
 

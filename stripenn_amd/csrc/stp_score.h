@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void k_stripiness(stp_bandref B, const double*
 // sum is a tolerance statistic in both and is reduced in another order here).  Stripes the wave form does not take --
 // more than SW_MAXH rows, a block wider than SW_MAXW columns, row sums of more than 128 terms -- go to the block kernels
 // through an index list; STP_SCORE=block sends everything there (tests compare the two).
-#define SW_KR_SHORT 3      /* rows per lane of the two instances: stripes of up to 128 rows (95 % of the candidates; 28 waves per CU) ... */
+#define SW_KR_SHORT 3      /* rows per lane of the two instances: stripes of up to 64 x 3 = 192 rows (95 % of the candidates; 28 waves per CU) ... */
 #define SW_KR_TALL 4       /* ... and of up to 256 rows (the rest of what a 400-bin frame yields; 16 waves per CU) */
 #define SW_MAXH (64 * SW_KR_TALL)
 #define SW_MAXW 64

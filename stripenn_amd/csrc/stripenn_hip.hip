@@ -2888,7 +2888,13 @@ static int search_enqueue(stp_ctx* ctx, stp_search* s)
     //  Round 5, on the faster kernels: 6 144 images per launch -- a whole chromosome of up to 204 frames at 5 levels x 6 images -- instead
     //  of 3 072: 72.0 -> 70.0 ms per genome step (20 instead of 36 launches of each chain kernel: fewer tails, fewer small stream
     //  operations between units); 4 608: 70.3, 9 216: 69.9.  3.9 GB of grey workspace.  STP_CHUNK_IMAGES: measurement hook.)
-    static const int chunk_images = getenv("STP_CHUNK_IMAGES") ? std::max(64, atoi(getenv("STP_CHUNK_IMAGES"))) : 6144;
+    static const int chunk_images = [] {            // (read once per process; anything that is not a number in 64 .. 65 536 keeps the default)
+        const char* e = getenv("STP_CHUNK_IMAGES");
+        if (!e || !*e) return 6144;
+        char* end = nullptr;
+        const long v = strtol(e, &end, 10);
+        return (end && *end == 0 && v >= 64 && v <= 65536) ? (int)v : 6144;
+    }();
     int chunk = chunk_images / ipf;
     if (chunk < 1) chunk = 1;
     if (chunk > fr->n) chunk = fr->n;
@@ -3414,7 +3420,7 @@ static int run_score(stp_ctx* ctx, const stp_band* band, const stp_background* b
     // which stripes the wave form takes (STP_SCORE=block: none -- the tests compare the two forms)
     const char* env = getenv("STP_SCORE");
     const bool all_block = env && strcmp(env, "block") == 0;
-    std::vector<int> small, tall, big;                                    // wave form (<= 128 rows), wave form (<= 256 rows), block kernels
+    std::vector<int> small, tall, big;                                    // wave form (<= 64 SW_KR_SHORT = 192 rows), wave form (<= 256 rows), block kernels
     double bytes_pv = 0, bytes_sc = 0;
     for (int64_t i = 0; i < n; i++) {
         bool ok = !all_block;

@@ -141,7 +141,11 @@ class PixelTable:
         """CSR index of chrom_pixels(chrom)'s rows (position of the first pixel of every bin of the chromosome, + the
         pixel count), or None when the chromosome's rows hold trans pixels (the filtered columns have no stored index)."""
         lo, hi = self.chrom_bins(chrom)
-        if self._trans.get(str(chrom), True) and len(self.chrom_pixels(chrom)[0]) != int(self.bin1_offset[hi] - self.bin1_offset[lo]):
+        trans = self._trans.get(chrom)                  # (the key chrom_pixels stores its verdict under)
+        if trans is None:                               # not asked yet: chrom_pixels establishes the verdict (one look-up per bin)
+            self.chrom_pixels(chrom)
+            trans = self._trans.get(chrom, False)       # (a chromosome without pixels leaves no verdict: nothing was dropped)
+        if trans:                                       # at least one pixel was dropped: the stored index does not describe the kept rows
             return None
         return self.bin1_offset[lo:hi + 1] - self.bin1_offset[lo]
 
