@@ -40,7 +40,11 @@ class SynthChrom:
     """
 
     def __init__(self, nbins, seed, balanced=True, stripe_every=170, stripe_gain=2.5,
-                 nan_frac=0.005):
+                 nan_frac=0.005, depth=1.0, count_div=1):
+        # data regimes (round 6): depth scales lam (sequencing depth: relative noise ~ 1 / sqrt(depth)), count_div > 1 keeps
+        # floor(count / count_div) (a shallow library: mostly 0 / 1 / 2 away from the diagonal); balanced=False gives raw
+        # integer counts (`--norm None`).  The defaults leave every matrix of rounds 1-5 bit for bit what it was.
+        self.depth, self.count_div = float(depth), int(count_div)
         self.nbins = int(nbins)
         self.seed = int(seed)
         self.balanced = bool(balanced)
@@ -96,8 +100,12 @@ class SynthChrom:
         x2, y2 = r, c
         in2 = (y2 >= self._s_lo[np.clip(x2, 0, self.nbins - 1)]) & (y2 <= self._s_hi[np.clip(x2, 0, self.nbins - 1)])
         lam = np.where(in1 | in2, lam * self.stripe_gain, lam)
+        if self.depth != 1.0:
+            lam = lam * self.depth
         cnt = np.floor(lam + np.sqrt(lam) * z + 0.5)
         cnt = np.where(cnt < 0.0, 0.0, cnt)
+        if self.count_div > 1:
+            cnt = np.floor(cnt / float(self.count_div))
         return np.where(d > BAND_LIMIT, 0.0, cnt)
 
     def block(self, r0, r1, c0, c1):

@@ -68,8 +68,12 @@ class DeviceChrom:
         in1 = (r >= self.s_lo[c]) & (r <= self.s_hi[c])
         in2 = (c >= self.s_lo[r]) & (c <= self.s_hi[r])
         lam = torch.where(in1 | in2, lam * self.host.stripe_gain, lam)
+        if self.host.depth != 1.0:
+            lam = lam * self.host.depth
         cnt = torch.floor(lam + torch.sqrt(lam) * z + 0.5)
         cnt = torch.where(cnt < 0.0, torch.zeros_like(cnt), cnt)
+        if self.host.count_div > 1:
+            cnt = torch.floor(cnt / float(self.host.count_div))
         return torch.where(d > synth.BAND_LIMIT, torch.zeros_like(cnt), cnt)
 
     def band(self, halfwidth=512, chunk=8192):
