@@ -441,6 +441,15 @@ def main():
                         os.environ.pop(k, None)
                     else:
                         os.environ[k] = v
+        if world == 1 and not args.no_extras and not exact_env and not args.emulate_rank:
+            out['ab_round6'] = ab_round6(W, barrier)
+            if not args.bins and args.workload == 'genome':
+                out['emulated_shares_ms'] = emulated_shares(W, barrier, 8)
+        if world == 1 and not args.no_extras and not exact_env and not args.emulate_rank and not args.bins and args.workload == 'genome':
+            try:
+                out['regimes'] = regimes_extra(hb, dev, args.canny, barrier)
+            except Exception as e:      # noqa: BLE001 -- an extra line must not cost the metric line
+                out['regimes'] = {'error': str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             ci = min({u[0] for u in W.my_units}, key=lambda c: nbins[c])        # the smallest chromosome held here
             band_h = W.bands[names[ci]].download()
@@ -482,8 +491,119 @@ def main():
     if world > 1:
         dist.barrier()                    # gloo control group
         if comm == 'gloo' and not rehearse:
-            os._exit(0)                   # a failed / hung RCCL probe must not hold the exit
+            # The RCCL probe failed or timed out on some rank: its outcome is `config.comm_note`, nothing else.  A probe thread
+            # that is still alive (joined for 90 s above, daemon) may hold a half-built RCCL communicator whose destructor -- or
+            # destroy_process_group() walking over that group -- could block this rank's exit for good, after the JSON line is
+            # out and the gloo barrier above has passed on every rank: so the process ends here, with status 0, without
+            # running any further teardown.  (The path has never met a second device on the build boxes; the two-rank
+            # rehearsal -- STP_BENCH_REHEARSE=1, tests/test_shard_gloo.py -- covers everything around it.)
+            os._exit(0)
         dist.destroy_process_group()
+
+
+def _timed_steps(W, barrier, n):
+    W.reset_stats(); barrier()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        W.step()
+    barrier()
+    return (time.perf_counter() - t0) / n * 1e3, W.stats()
+
+
+def ab_round6(W, barrier, steps=5):
+    """Same-process A/B of the two round-6 measures on the metric's workload: the images' symmetry (STP_SYM: the Canny tiles below
+    an image's diagonal take their class words from the transposes of the tiles above) and the frame overlap (STP_REUSE: the
+    block a frame shares with its successor is computed once).  ms per step and the Canny kernel's share with both, with one,
+    with neither; records_equal: sha256 of every unit's record buffer of one step, each selection against `neither`."""
+    import hashlib
+    saved = {k: os.environ.get(k) for k in ('STP_SYM', 'STP_REUSE')}
+    res, sha = {}, {}
+    try:
+        for name, sym, reuse in (('shipped', None, None), ('no_overlap', None, '0'), ('no_symmetry', '0', None), ('neither', '0', '0')):
+            for k, v in (('STP_SYM', sym), ('STP_REUSE', reuse)):
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            h = hashlib.sha256()
+            W.step(digest=h)                          # (also the selection's warm-up)
+            sha[name] = h.hexdigest()[:16]
+            ms, st = _timed_steps(W, barrier, steps)
+            res[name] = {'ms_per_step': round(ms, 3), 'canny_ms_per_step': round(st['canny']['ms'] / steps, 3),
+                         'lines_ms_per_step': round(st['lines']['ms'] / steps, 3)}
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return {'what': 'STP_SYM / STP_REUSE switched off one at a time and together, %d steps each, same process and box; '
+                    'records_equal: every unit\'s record buffer of one step under each selection == under `neither`' % steps,
+            'runs': res, 'records_equal': all(v == sha['neither'] for v in sha.values()), 'records_sha256': sha}
+
+
+def emulated_shares(W, barrier, n, steps=5):
+    """ms per step of each of the n shares an n-rank run would cut the genome into, one after the other ALONE on this GPU
+    (diagonal: per-rank fixed costs -- pipeline fill and drain, launch tails -- without an n-GPU node).  NOT a multi-GPU
+    measurement and no scaling claim: eight real ranks share host cores, PCIe and power."""
+    saved = W.my_units
+    out = []
+    try:
+        for r in range(n):
+            W.my_units = W.units_for(n, r)
+            W.step()
+            ms, _ = _timed_steps(W, barrier, steps)
+            out.append(round(ms, 2))
+    finally:
+        W.my_units = saved
+    return out
+
+
+REGIMES = (('balanced', {}), ('raw_counts', {'balanced': False}), ('counts_div8', {'balanced': False, 'count_div': 8}),
+           ('counts_div32', {'balanced': False, 'count_div': 32}), ('depth_x10', {'depth': 10.0}))
+
+
+def regimes_extra(hb, dev, sigma, barrier, steps=5):
+    """Other data regimes on the device (not the metric): one chr16-size chromosome (19 642 bins, 99 frames x 5 levels x 6 images) of
+    balanced floats (the metric's family), raw integer counts (`--norm None`), shallow libraries (counts // 8, // 32: few-level
+    images full of exact ties) and a 10 x deeper matrix; frame preparation + StripeSearch chain, shipped kernels.  Per regime:
+    contact-Mpx/s, and k_canny_f32's own counters on 8 sampled frames x 2 brightness images at the first level: fraction of
+    the image in tiles skipped as flat, candidates, pixels settled by the f64 resolver and tile-images handed to the exact
+    kernel, per image.  tests/test_gpu_regimes.py checks every record of such chromosomes against the oracle."""
+    res = {}
+    for name, kw in REGIMES:
+        spec = dict(names=['chr16'], nbins=[CHR16_BINS], seeds=[16], wl='regime ' + name, kw=kw)
+        Wr = _Workload(hb, dev, spec, 1, 0, '', score=False, sigma=sigma)
+        try:
+            Wr.step(); Wr.step()
+            Wr.reset_stats(); barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                nrec, px = Wr.step()
+            barrier()
+            dt = (time.perf_counter() - t0) / steps
+            st = Wr.stats()
+            fst, fen = Wr.tabs[0]
+            fr = Wr.bands['chr16'].frames(fst, fen)
+            flat, cand, reso, flag, nimg = 0.0, 0, 0, 0, 0
+            for f in range(5, len(fst), 12):
+                if fr.S[f] == 0:
+                    continue
+                for bi in (0, 5):
+                    c = fr.dbg_canny_f32(f, float(Wr.Ms[0][0]), bi, sigma=sigma)
+                    flat += float(np.isnan(c['g']).mean()); cand += c['candidates']; reso += c['resolved']; flag += c['flagged']
+                    nimg += 1
+            fr.close()
+            res[name] = {'value': round(px / dt / 1e6, 1), 'unit': 'contact-Mpx/s', 'ms_per_step': round(dt * 1e3, 3),
+                         'stripe_records': int(nrec), 'maxpixel_levels': [round(float(m), 4) for m in Wr.Ms[0]],
+                         'canny_ms_per_step': round(st['canny']['ms'] / steps, 3), 'gray_ms_per_step': round(st['gray']['ms'] / steps, 3),
+                         'lines_ms_per_step': round(st['lines']['ms'] / steps, 3),
+                         'sampled_images': nimg, 'flat_tile_fraction': round(flat / max(nimg, 1), 3),
+                         'candidates_per_image': round(cand / max(nimg, 1), 1), 'resolver_pixels_per_image': round(reso / max(nimg, 1), 1),
+                         'exact_tile_images_per_image': round(flag / max(nimg, 1), 2)}
+        finally:
+            Wr.release()
+    return res
 
 
 class _Workload:
@@ -500,29 +620,18 @@ class _Workload:
         self.bs = int(50000 / RESOL)
         sizes = np.array([n * RESOL for n in nbins], dtype=np.int64)
         self.nframes = [-(-n // 200) for n in nbins]
-        my_units = shard.frame_spans(self.nframes, world)[rank]       # (chromosome index, first frame, end frame)
         if emulate_rank:
             er, en_ = (int(v) for v in emulate_rank.split('/'))
-            my_units = shard.frame_spans(self.nframes, en_)[er]
-        # pipeline stages: pieces of at most one device chunk (6 144 images = 204 frames at 5 levels x 6 brightness: round 5), so that
-        # filling and draining the two-deep pipeline costs a chunk's latency, not a chromosome's
-        # (a rank's span is cut into at least four stages -- a 1/8 share of the genome, 330 frames, into pieces of 83 -- so that
-        #  filling and draining the pipeline stays a small part of a short step; the whole genome runs in chromosome-size pieces)
-        nfr_rank = sum(f1 - f0 for _, f0, f1 in my_units)
-        piece = max(1, int(os.environ.get('STP_BENCH_PIECE', str(min(204, max(64, -(-nfr_rank // 4)))))))
-        self.my_units = [(ci, a, min(a + piece, f1)) for ci, f0, f1 in my_units for a in range(f0, f1, piece)]
-        # issue order: largest unit first, smallest last -- a step that drains ends with the scoring of its LAST unit (nothing left on
-        # the device to hide it behind), so that unit should be the short one (round 5: 66.8 -> 65.7 and 67.8 -> 67.1 ms per genome step in two same-box A/B pairs).  The units
-        # are independent; STP_BENCH_ORDER=file keeps the chromosome order
-        if os.environ.get('STP_BENCH_ORDER', 'size') != 'file':
-            self.my_units.sort(key=lambda u: -(u[2] - u[1]))
+            self.my_units = self.units_for(en_, er)
+        else:
+            self.my_units = self.units_for(world, rank)
         # ---- untimed set-up: every band in HBM, maxpixel quantiles, expected values, background tables
         self.chroms, self.tens, self.bands = {}, {}, {}
         need_all = score                      # the background tables sample every chromosome of the genome
         for ci, nm in enumerate(names):
             if not need_all and not any(u[0] == ci for u in self.my_units):
                 continue
-            self.chroms[nm] = synth_device.DeviceChrom(nbins[ci], seeds[ci], dev)
+            self.chroms[nm] = synth_device.DeviceChrom(nbins[ci], seeds[ci], dev, **spec.get('kw', {}))
             self.tens[nm] = self.chroms[nm].band(hw)
             torch.cuda.synchronize()
             self.bands[nm] = self.ctx.band_wrap(self.tens[nm].data_ptr(), nbins[ci], hw, keepalive=self.tens[nm])
@@ -584,6 +693,23 @@ class _Workload:
             self._q = queue.Queue()
             self._thr = threading.Thread(target=self._score_loop, daemon=True)
             self._thr.start()
+
+    def units_for(self, world, rank):
+        """The units rank `rank` of `world` works through in a step: its span of the (chromosome x frame) grid
+        (shard.frame_spans) cut into pipeline stages -- pieces of at most one device chunk (6 144 images = 204 frames at 5 levels
+        x 6 brightness), so that filling and draining the two-deep pipeline costs a chunk's latency, not a chromosome's; a rank's
+        span is cut into at least four stages (a 1/8 share of the genome, 330 frames, into pieces of 83).  Issue order: largest
+        unit first, smallest last -- a step that drains ends with the scoring of its LAST unit (nothing left on the device to
+        hide it behind), so that unit should be the short one (round 5: 66.8 -> 65.7 ms per genome step).  The units are
+        independent; STP_BENCH_ORDER=file keeps the chromosome order."""
+        from stripenn_amd import shard
+        spans = shard.frame_spans(self.nframes, world)[rank]          # (chromosome index, first frame, end frame)
+        nfr_rank = sum(f1 - f0 for _, f0, f1 in spans)
+        piece = max(1, int(os.environ.get('STP_BENCH_PIECE', str(min(204, max(64, -(-nfr_rank // 4)))))))
+        units = [(ci, a, min(a + piece, f1)) for ci, f0, f1 in spans for a in range(f0, f1, piece)]
+        if os.environ.get('STP_BENCH_ORDER', 'size') != 'file':
+            units.sort(key=lambda u: -(u[2] - u[1]))
+        return units
 
     def _score_loop(self):
         while True:
