@@ -696,17 +696,24 @@ class _Workload:
 
     def units_for(self, world, rank):
         """The units rank `rank` of `world` works through in a step: its span of the (chromosome x frame) grid
-        (shard.frame_spans) cut into pipeline stages -- pieces of at most one device chunk (6 144 images = 204 frames at 5 levels
-        x 6 brightness), so that filling and draining the two-deep pipeline costs a chunk's latency, not a chromosome's; a rank's
-        span is cut into at least four stages (a 1/8 share of the genome, 330 frames, into pieces of 83).  Issue order: largest
-        unit first, smallest last -- a step that drains ends with the scoring of its LAST unit (nothing left on the device to
-        hide it behind), so that unit should be the short one (round 5: 66.8 -> 65.7 ms per genome step).  The units are
-        independent; STP_BENCH_ORDER=file keeps the chromosome order."""
+        (shard.frame_spans) cut into pipeline stages of at most one device chunk (6 144 images = 204 frames at 5 levels x 6
+        brightness).  The whole genome (world 1) runs in chromosome-size units, largest first, smallest last -- a step that drains
+        ends with the scoring of its LAST unit (nothing left on the device to hide it behind), so that unit should be the short
+        one (round 5: 66.8 -> 65.7 ms per genome step); a share of it in equal parts of at most 128 frames (below).  The units
+        are independent; STP_BENCH_PIECE / STP_BENCH_ORDER=file override."""
         from stripenn_amd import shard
         spans = shard.frame_spans(self.nframes, world)[rank]          # (chromosome index, first frame, end frame)
-        nfr_rank = sum(f1 - f0 for _, f0, f1 in spans)
-        piece = max(1, int(os.environ.get('STP_BENCH_PIECE', str(min(204, max(64, -(-nfr_rank // 4)))))))
-        units = [(ci, a, min(a + piece, f1)) for ci, f0, f1 in spans for a in range(f0, f1, piece)]
+        # Round 6 (tools/emulated_shares_matrix.sh, profiles/r06_shares_matrix*.txt): a 1/8 share holds 3-4 chromosome pieces.  Cut into
+        # pieces of 83 frames + remainders they made 5-7 units, some of a few frames only, each of which costs the host its full
+        # per-unit work (frame preparation, record fetch, score inputs, one blocking score call) for microseconds of device time:
+        # 8.8 / 9.0 ms for shares 5 / 7 of 8.  Now: shard.frame_spans leaves no slivers (cuts snap onto chromosome boundaries), and
+        # a chromosome piece is cut into the fewest EQUAL parts of at most 128 frames: 3-5 units per share, 7.2-7.6 ms.
+        whole = world == 1
+        piece = max(1, int(os.environ.get('STP_BENCH_PIECE', '204' if whole else '128')))
+        units = []
+        for ci, f0, f1 in spans:
+            n, k = f1 - f0, -(-(f1 - f0) // piece)
+            units += [(ci, f0 + (n * j) // k, f0 + (n * (j + 1)) // k) for j in range(k)]
         if os.environ.get('STP_BENCH_ORDER', 'size') != 'file':
             units.sort(key=lambda u: -(u[2] - u[1]))
         return units

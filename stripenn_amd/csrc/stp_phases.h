@@ -1036,6 +1036,20 @@ STP_HD stp_u64 stp_runfill(stp_u64 mask, stp_u64 seed)
 // The host marks a frame whose trailing kept bins are exactly the leading kept bins of its successor (shift = their first
 // index in this frame; -1 otherwise); k_canny_f32 then skips the tiles that lie inside the square [lo, hi)^2 and k_lines' loader
 // takes those class words from the successor's planes.
+// the mark of frame i (host and device run the same code): z0 / z1 = the kept local indices of frames i and i + 1
+STP_HD int stp_overlap_shift(int s0, int n0, int S0, const int16_t* z0, int s1, int n1, int S1, const int16_t* z1)
+{
+    const int e0 = s0 + n0 - 1, e1 = s1 + n1 - 1;
+    if (!(s1 > s0 && s1 <= e0 && e1 >= e0) || S0 <= 0 || S1 <= 0) return -1;
+    int p = 0;
+    while (p < S0 && s0 + z0[p] < s1) p++;
+    const int q = S0 - p;
+    if (q < 1 || q > S1) return -1;
+    for (int k = 0; k < q; k++)
+        if (s0 + z0[p + k] != s1 + z1[k]) return -1;
+    if (q < S1 && s1 + z1[q] <= e0) return -1;                 // frame i + 1 keeps a bin of the block that frame i dropped
+    return p;
+}
 #define STP_REUSE_MARGIN(R) ((R) + 3)
 struct stp_reuse { int lo, hi, shift; };           // lo >= hi: nothing is taken from the next frame
 STP_HD stp_reuse stp_reuse_of(int shift, int S, int R, bool next_in_launch)

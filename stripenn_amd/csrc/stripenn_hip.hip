@@ -2316,6 +2316,28 @@ void stp_band_free(stp_ctx* ctx, stp_band* b)
     delete b;
 }
 
+// Frame overlap (stp_phases.h): the mark of every frame, one lane per frame, from the compaction k_frame_prep has just written
+// (same stream).  Second rule (the block frame i takes from frame i + 1 must not reach into the block frame i + 1 takes from
+// frame i + 2): both marks are formed by the lane that needs them.
+__global__ __launch_bounds__(64) void k_overlap_shift(const int32_t* __restrict__ fstart, const int32_t* __restrict__ fn0,
+                                                      const int32_t* __restrict__ fS, const int16_t* __restrict__ fnz, int n,
+                                                      int32_t* __restrict__ shift)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    int p = -1;
+    if (i + 1 < n) {
+        p = stp_overlap_shift(fstart[i], fn0[i], fS[i], fnz + (size_t)i * STP_FRAME_MAX, fstart[i + 1], fn0[i + 1], fS[i + 1],
+                              fnz + (size_t)(i + 1) * STP_FRAME_MAX);
+        if (p >= 0 && i + 2 < n) {
+            const int p1 = stp_overlap_shift(fstart[i + 1], fn0[i + 1], fS[i + 1], fnz + (size_t)(i + 1) * STP_FRAME_MAX, fstart[i + 2],
+                                             fn0[i + 2], fS[i + 2], fnz + (size_t)(i + 2) * STP_FRAME_MAX);
+            if (p1 >= 0 && p1 < fS[i] - p) p = -1;
+        }
+    }
+    shift[i] = p;
+}
+
 void stp_frames_free(stp_ctx* ctx, stp_frames* fr)
 {
     if (!fr) return;
@@ -2377,6 +2399,7 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
         stp_bandref B{band->d, band->nrows, band->W, band->hw};
         hipLaunchKernelGGL(k_frame_prep, dim3(n), dim3(STP_PREP_NT), 0, ctx->aux, B, fr->d_start, fr->d_n0, fr->d_S, fr->d_nz, d_med,
                            (flags & STP_FRAMES_KEEP_ALL) ? 1 : 0);
+        hipLaunchKernelGGL(k_overlap_shift, dim3((n + 63) / 64), dim3(64), 0, ctx->aux, fr->d_start, fr->d_n0, fr->d_S, fr->d_nz, n, fr->d_shift);
     }
     {
         hipError_t el = hipGetLastError();
@@ -2400,29 +2423,13 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
     // Frame overlap (stp_phases.h, "frame overlap"): frame i is marked when its trailing kept bins are exactly the leading kept
     // bins of frame i + 1 -- the same absolute bins, one contiguous run in both compacted frames -- and the block it would
     // take from frame i + 1 does not reach into the block frame i + 1 takes from frame i + 2.
+    // (the device marks its copy itself -- k_overlap_shift behind k_frame_prep, same code -- so the marks cost no second round trip)
     fr->h_shift.assign(n, -1);
-    for (int i = 0; i + 1 < n; i++) {
-        const int s0 = fr->h_start[i], e0 = s0 + fr->h_n0[i] - 1, s1 = fr->h_start[i + 1], e1 = s1 + fr->h_n0[i + 1] - 1;
-        const int S0 = fr->h_S[i], S1 = fr->h_S[i + 1];
-        if (!(s1 > s0 && s1 <= e0 && e1 >= e0) || S0 <= 0 || S1 <= 0) continue;
-        const int16_t* z0 = fr->h_nz.data() + (size_t)i * STP_FRAME_MAX;
-        const int16_t* z1 = fr->h_nz.data() + (size_t)(i + 1) * STP_FRAME_MAX;
-        int p = 0;
-        while (p < S0 && s0 + z0[p] < s1) p++;
-        const int q = S0 - p;
-        if (q < 1 || q > S1) continue;
-        bool same = true;
-        for (int k = 0; k < q && same; k++) same = (s0 + z0[p + k]) == (s1 + z1[k]);
-        if (same && q < S1 && s1 + z1[q] <= e0) same = false;        // frame i + 1 keeps a bin of the block that frame i dropped
-        if (same) fr->h_shift[i] = p;
-    }
+    for (int i = 0; i + 1 < n; i++)
+        fr->h_shift[i] = stp_overlap_shift(fr->h_start[i], fr->h_n0[i], fr->h_S[i], fr->h_nz.data() + (size_t)i * STP_FRAME_MAX,
+                                           fr->h_start[i + 1], fr->h_n0[i + 1], fr->h_S[i + 1], fr->h_nz.data() + (size_t)(i + 1) * STP_FRAME_MAX);
     for (int i = 0; i + 2 < n; i++)                                    // (p of frame i + 1 == q of frame i in the reference's geometry)
         if (fr->h_shift[i] >= 0 && fr->h_shift[i + 1] >= 0 && fr->h_shift[i + 1] < fr->h_S[i] - fr->h_shift[i]) fr->h_shift[i] = -1;
-    {
-        stp_xfer x2(ctx, ctx->aux);
-        FRCHK(x2.h2d(fr->d_shift, fr->h_shift.data(), n * sizeof(int32_t)));
-        FRCHK(x2.finish());
-    }
 #undef FRCHK
     *out = fr;
     return STP_OK;

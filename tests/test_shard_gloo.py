@@ -27,7 +27,8 @@ def test_lpt_balance_mm10():
 
 
 def test_frame_spans_balance_mm10():
-    """(chromosome x frame) work queue: contiguous spans, every frame exactly once, imbalance of one frame."""
+    """(chromosome x frame) work queue: contiguous spans, every frame exactly once, imbalance of one frame -- or, with cuts
+    snapped onto a chromosome boundary <= 8 frames away (round 6: no slivers), of at most 2 x 8 frames."""
     mm10 = [195471971, 182113224, 160039680, 156508116, 151834684, 149736546, 145441459, 129401213, 124595110,
             130694993, 122082543, 120129022, 120421639, 124902244, 104043685, 98207768, 94987271, 90702639, 61431566,
             171031299]
@@ -43,7 +44,11 @@ def test_frame_spans_balance_mm10():
                     seen[ci][f] += 1
         assert all(v == 1 for row in seen for v in row)
         loads = [sum(hi - lo for _, lo, hi in sp) for sp in spans]
-        assert max(loads) - min(loads) <= 1 and max(loads) / (sum(loads) / n) < 1.03
+        assert max(loads) - min(loads) <= 2 * shard.SNAP_FRAMES + 1 and max(loads) / (sum(loads) / n) < 1.03
+        assert all(hi - lo > shard.SNAP_FRAMES or (lo == 0 and hi == nfr[ci]) for sp in spans for ci, lo, hi in sp)     # no slivers
+        plain = shard.frame_spans(nfr, n, snap=0)
+        loads0 = [sum(hi - lo for _, lo, hi in sp) for sp in plain]
+        assert max(loads0) - min(loads0) <= 1
 
 
 def _spawn(world, out, numcores):
