@@ -773,7 +773,16 @@ class _Workload:
         StripeSearch chain enqueued on the main stream of context k; returns without waiting for the chain"""
         ci, f0, f1 = unit
         st, en = self.tabs[ci]
-        fr = (self.bands2 if k else self.bands)[self.names[ci]].frames(st[f0:f1], en[f0:f1])
+        if os.environ.get('STP_BENCH_CACHE_FRAMES') == '1':
+            # (diagnostic, VERDICT r05 #4: what frame preparation costs THE STEP -- the frames of a unit prepared once and served
+            #  from the previous step's results; the step then runs without k_frame_prep and its blocking round trip.  Not the metric.)
+            cache = self.__dict__.setdefault('_frames_cache', {})
+            fr = cache.get((unit, k))
+            if fr is None:
+                fr = cache[(unit, k)] = (self.bands2 if k else self.bands)[self.names[ci]].frames(st[f0:f1], en[f0:f1])
+                fr.close = lambda: None                 # kept for the next step (released with the workload's bands)
+        else:
+            fr = (self.bands2 if k else self.bands)[self.names[ci]].frames(st[f0:f1], en[f0:f1])
         return unit, fr, fr.stripe_search_begin(self.Ms[ci], sigma=self.sigma)
 
     def step(self, digest=None):

@@ -147,6 +147,7 @@ def sharded_compute(rank, world, cool, out, norm, chrom, canny, minL, maxW, maxp
     sel = Lib.matrix(balance=normv)
     backend = backend_factory(rank) if backend_factory is not None else None
     t0 = time.time()
+    phase = {}                                   # seconds per phase of this rank (written to stripenn.log by rank 0)
 
     # ---- A: whole-chromosome steps
     mineA = lpt_assign(chrom_costs(sizes, resol), world)[rank]
@@ -187,6 +188,7 @@ def sharded_compute(rank, world, cool, out, norm, chrom, canny, minL, maxW, maxp
     for part in comm.allgather(parts):
         allparts.update(part)
     bg = objA.null_concat([allparts[c] for c in cand2])
+    phase['A quantile + expected + background'] = time.time() - t0
 
     # ---- B: candidate stripes, p-values, redundancy filters, Stripiness of this rank's frame span
     nfr = chrom_nframes(sizes, resol)
@@ -218,10 +220,15 @@ def sharded_compute(rank, world, cool, out, norm, chrom, canny, minL, maxW, maxp
             num = np.asarray(table['num'], dtype=np.int64)
             table = table.iloc[np.nonzero((num >= lo) & (num < hi))[0]]          # drop the halo frames
             s = objB.scoringstripes(table, EV, mask)[0]
-    table = table.copy()
+    # (the nine helper columns have done their work -- the filters and Stripiness above -- and would only be pickled, sent and
+    #  concatenated to be dropped by finish_tables: 21 -> 12 columns through the gather)
+    from .stripenn import HELPER_COLUMNS
+    table = table.drop(columns=[c for c in HELPER_COLUMNS if c in table.columns])
     table.insert(table.shape[1], '_stripiness', list(s), True)
     elapsed = time.time() - t0
-    gathered = comm.allgather((rank, table, elapsed))
+    phase['B search + p-values + filters + Stripiness'] = elapsed - phase['A quantile + expected + background']
+    gathered = comm.allgather((rank, table, elapsed, phase))
+    t_merge = time.time()
     result = (None, None)
     if rank == 0:
         merged = pd.concat([g[1] for g in sorted(gathered, key=lambda g: g[0]) if len(g[1])] or [gathered[0][1]])
@@ -238,7 +245,11 @@ def sharded_compute(rank, world, cool, out, norm, chrom, canny, minL, maxW, maxp
             with open(out + 'stripenn.log', 'a') as f:
                 f.write('gpus: %d\n' % world)
                 for g in sorted(gathered, key=lambda g: g[0]):
-                    f.write('rank %d: %.2f s\n' % (g[0], g[2]))
+                    f.write('rank %d: %.2f s (%s)\n' % (g[0], g[2], '; '.join('%s %.3f' % kv for kv in g[3].items())))
+                # what stays serial on rank 0 behind the ranks' work: gathering the tables, merge into the reference's row
+                # order, final columns / filter / sort, both TSVs (stripenn.py:149-159)
+                f.write('rank 0 serial tail (gather wait + merge + TSVs): %.3f s\n' % (time.time() - t0 - elapsed))
+                f.write('rank 0 merge + TSVs alone: %.3f s\n' % (time.time() - t_merge))
         result = (result_table, res_filter)
     if backend is None:
         objB.backend.close()

@@ -165,7 +165,7 @@ def write_tsv(df, path):
 
 def finish_tables(result_table, stripiness, pcut):
     """stripenn.py:149-152"""
-    result_table = result_table.drop(columns=HELPER_COLUMNS)
+    result_table = result_table.drop(columns=[c for c in HELPER_COLUMNS if c in result_table.columns])   # (the sharded driver's ranks have dropped them already)
     result_table.insert(result_table.shape[1], 'Stripiness', stripiness, True)
     res_filter = result_table[result_table['pvalue'] < pcut]
     res_filter = res_filter.sort_values(by=['Stripiness'], ascending=False)
