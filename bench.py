@@ -357,7 +357,7 @@ def main():
                 'traffic_source': (pmc.get('tag') if traffic is not None else
                                    ('stale: %s was collected on other kernel sources' % pmc.get('tag')) if pmc and not pmc_fresh else None),
                 # what the dominant kernel runs into: its issue rate or HBM when one of them is above half its peak, else
-                # neither (latency / synchronisation: DESIGN.md section 5)
+                # neither (latency / synchronisation: DESIGN.md section 3)
                 'limiter': ('valu_issue' if valu and valu['frac'] >= 0.5 and valu['frac'] > ach / HBM_PEAK_GBS else
                             'hbm' if ach / HBM_PEAK_GBS >= 0.5 or not valu else 'latency'),
                 'avg_launch_ms': round(d['ms'] / d['launches'], 4), 'launches_per_step': d['launches'] / args.steps,

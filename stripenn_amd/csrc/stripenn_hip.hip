@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     const stp_cwin CW = canny_cand_window(T);
     const int et = c32_budget_of(xin && yin, S, R);  // tile-wide budget: full windows everywhere, or the worst cut
     // (measured and dropped in round 3, on the dword-load form: prefetching the next image's inputs into registers, 18-row
-    //  items, two packed columns per lane, the resolver in a kernel of its own, 6 waves per SIMD -- DESIGN.md section 3)
+    //  items, two packed columns per lane, the resolver in a kernel of its own, 6 waves per SIMD -- docs/history/DESIGN_r01-r05.md section 3)
     int prev = -1;                                   // the image whose class test has just run (overflow check below)
     while (live) {                                   // workgroup-uniform
         const int bi = __builtin_ctz(live);

@@ -74,7 +74,7 @@ def test_block_mean_is_numpy_order():
 def test_block_mean_is_numpys_mean():
     """so_block_mean (the window mean of the background step) against np.mean of the same 2-D slices with THIS
     numpy -- also above 8192 elements, where numpy's buffered reduction adds up one pairwise sum per 8192-element
-    buffer (the 1.26.4 build of the harness interpreter gives the same bits: tools note in DESIGN.md)."""
+    buffer (the 1.26.4 build of the harness interpreter gives the same bits: docs/history/DESIGN_r01-r05.md, exactness rules)."""
     import ctypes as C
     L = O._lib_score()
     rng = np.random.default_rng(5)
