@@ -566,7 +566,12 @@ STP_HD float c32_gauss_exact(const float* centre, int stride, const double* w, i
 // x-2-R .. x+2+R of the vertical pass (0 outside the image: constant mode), element l = r * (2R+5) + c.
 // c32_res_V_taps requests the taps of element l (nothing for an element outside the image: all taps 0),
 // c32_gauss_sum turns them into the value.
-template <int R>
+// TR (the mirrored resolver, image symmetry): the grey value of image position (a, b) is READ at (b, a).  The resolver settles
+// pixels of tiles below the diagonal, whose grey windows may lie in tiles k_gray_c3 no longer writes (stp_gray_dead_tile); in
+// an image that equals its transpose -- any other is reported by k_gray_c3 and its tiles below the diagonal are recomputed
+// from grey values filled in for them (k_gray_fill) -- the transposed position holds the same float.  Taps beyond the
+// image are read (the neighbouring row, image or guard region: valid memory) and masked, as in the plain form.
+template <int R, bool TR = false>
 STP_HD void c32_res_V_taps(stp_tile T, int y, int x, int l, const float* __restrict__ gimg, float* v)
 {
     constexpr int NC = 2 * R + 5;
@@ -576,9 +581,10 @@ STP_HD void c32_res_V_taps(stp_tile T, int y, int x, int l, const float* __restr
     const int xx = x - 2 - R + c;
     const bool in = xx >= 0 && xx < T.S;
     const int lo = !in ? 1 : (yy - R < 0 ? R - yy : 0), hi = !in ? 0 : (yy + R >= T.S ? R + (T.S - 1 - yy) : 2 * R);
-    c32_gauss_taps<R>(gimg + yy * STP_PITCH + (in ? xx : 0), STP_PITCH, lo, hi, v);
+    if (TR) c32_gauss_taps<R>(gimg + (in ? xx : 0) * STP_PITCH + yy, 1, lo, hi, v);
+    else c32_gauss_taps<R>(gimg + yy * STP_PITCH + (in ? xx : 0), STP_PITCH, lo, hi, v);
 }
-template <int R>
+template <int R, bool TR = false>
 STP_HD float c32_res_V(stp_tile T, int y, int x, int l, const double* w, const float* __restrict__ gimg)
 {
     if (R > 8) {                                   // (as c32_gauss_exact: one tap pair at a time)
@@ -589,10 +595,11 @@ STP_HD float c32_res_V(stp_tile T, int y, int x, int l, const double* w, const f
         const int xx = x - 2 - R + c;
         const bool in = xx >= 0 && xx < T.S;
         const int lo = !in ? 1 : (yy - R < 0 ? R - yy : 0), hi = !in ? 0 : (yy + R >= T.S ? R + (T.S - 1 - yy) : 2 * R);
+        if (TR) return c32_gauss_exact<R>(gimg + (in ? xx : 0) * STP_PITCH + yy, 1, w, lo, hi);
         return c32_gauss_exact<R>(gimg + yy * STP_PITCH + (in ? xx : 0), STP_PITCH, w, lo, hi);
     }
     float v[2 * R + 1];
-    c32_res_V_taps<R>(T, y, x, l, gimg, v);
+    c32_res_V_taps<R, TR>(T, y, x, l, gimg, v);
     return c32_gauss_sum<R>(v, w);
 }
 // S patch: element l = r * 5 + c is the smoothed value at (clamp(y-2+r), clamp(x-2+c)), the reference's operations

@@ -1036,6 +1036,17 @@ STP_HD stp_u64 stp_runfill(stp_u64 mask, stp_u64 seed)
 // The host marks a frame whose trailing kept bins are exactly the leading kept bins of its successor (shift = their first
 // index in this frame; -1 otherwise); k_canny_f32 then skips the tiles that lie inside the square [lo, hi)^2 and k_lines' loader
 // takes those class words from the successor's planes.
+// ---- grey tiles nobody reads (round 6, with the image symmetry) ----------------------------------------------------------------
+// k_canny_f32 with `mirror` computes the tiles (ty, tx) with ty <= 2 tx + 1 only.  A computed tile reads grey values at most
+// R + 2 <= 14 pixels from its border and grey cells (8 x 16) that overlap that window: inside the tile grown by 16 rows and 16
+// columns, i.e. inside the 3 x 3 tile neighbourhood.  A grey tile (gy, gx) therefore has a reader among the computed tiles iff
+// gy - 1 <= 2 (gx + 1) + 1: the 20 tiles with gy >= 2 gx + 5 (a quarter of the image, its far corner below the diagonal) are
+// written for nobody -- k_gray_c3 skips them.  The two consumers that may look there anyway: the mirrored resolver reads
+// its grey values at the transposed position (c32_res_V_taps<R, true>), and a (frame, level) whose tiles below the diagonal go to
+// the exact kernel (list overflow, or an image that differs from its transpose) is marked by k_canny_f32 and gets these tiles
+// filled in by k_gray_fill -- every operation of the reference, at the position itself -- before k_canny_pipe_list runs.
+STP_HD bool stp_gray_dead_tile(int gy, int gx) { return gy >= 2 * gx + 5; }
+
 // the mark of frame i (host and device run the same code): z0 / z1 = the kept local indices of frames i and i + 1
 STP_HD int stp_overlap_shift(int s0, int n0, int S0, const int16_t* z0, int s1, int n1, int S1, const int16_t* z1)
 {

@@ -48,25 +48,26 @@ __device__ __forceinline__ unsigned wt_dpp_xor4(unsigned w)
 __device__ __forceinline__ unsigned wt_dpp_xor2(unsigned w) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x4E, 0xF, 0xF, false); }    // quad_perm:[2,3,0,1]
 __device__ __forceinline__ unsigned wt_dpp_xor1(unsigned w) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xB1, 0xF, 0xF, false); }    // quad_perm:[1,0,3,2]
 
+// one tile of one (frame, level): every brightness image, every operation of the reference (k_gray, k_gray_fill)
 template <int AMAX>
-__global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, int W, int hw,
+__device__ __forceinline__ void gray_tile_exact(const double* __restrict__ band, int W, int hw,
                                                const int32_t* __restrict__ fstart, const int32_t* __restrict__ fS,
                                                const int16_t* __restrict__ fnz, int f0,
                                                const double* __restrict__ Mlev, int nlev,
                                                const double* __restrict__ bvals, int nb, int a,
-                                               float* __restrict__ gray, float2* __restrict__ cells)
+                                               float* __restrict__ gray, float2* __restrict__ cells, int tile, int lev, int fl)
 {
     // AMAX = 1 (bfilter 3): 20 KB of LDS -> 7 workgroups per CU; the generic instance is sized for bfilter <= 7
     constexpr int SG_N = (GT_Y + 2 * AMAX) * (GT_X + 2 * AMAX);
     constexpr int SADJ_W = 4 * (GT_X + 2);               // bfilter 3: one product row per wave
     __shared__ double sg[SG_N];
     __shared__ double sadj[AMAX == 1 ? SADJ_W : SG_N];
-    const int fl = blockIdx.z, lev = blockIdx.y, f = f0 + fl;
+    const int f = f0 + fl;
     const int S = fS[f];
     if (S == 0) return;
     const int tpr = (STP_FRAME_MAX + GT_X - 1) / GT_X;
     stp_tile T;
-    T.S = S; T.ty0 = (blockIdx.x / tpr) * GT_Y; T.tx0 = (blockIdx.x % tpr) * GT_X;
+    T.S = S; T.ty0 = (tile / tpr) * GT_Y; T.tx0 = (tile % tpr) * GT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
     const int tid = threadIdx.x, nt = blockDim.x;
     if (AMAX == 1) {
@@ -146,6 +147,36 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
         __syncthreads();
     }
 }
+template <int AMAX>
+__global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, int W, int hw,
+                                               const int32_t* __restrict__ fstart, const int32_t* __restrict__ fS,
+                                               const int16_t* __restrict__ fnz, int f0,
+                                               const double* __restrict__ Mlev, int nlev,
+                                               const double* __restrict__ bvals, int nb, int a,
+                                               float* __restrict__ gray, float2* __restrict__ cells)
+{
+    gray_tile_exact<AMAX>(band, W, hw, fstart, fS, fnz, f0, Mlev, nlev, bvals, nb, a, gray, cells, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// The grey tiles k_gray_c3 skipped (stp_gray_dead_tile), for the (frame, level) pairs k_canny_f32 has marked: their tiles below the
+// diagonal go to the exact kernel, which reads its grey windows wherever they lie.  Grid (20 dead tiles, pairs); a pair without
+// a mark -- every pair of ordinary data -- costs its workgroups one byte load.
+__global__ __launch_bounds__(256) void k_gray_fill(const double* __restrict__ band, int W, int hw,
+                                                    const int32_t* __restrict__ fstart, const int32_t* __restrict__ fS,
+                                                    const int16_t* __restrict__ fnz, int f0,
+                                                    const double* __restrict__ Mlev, int nlev,
+                                                    const double* __restrict__ bvals, int nb,
+                                                    float* __restrict__ gray, const uint8_t* __restrict__ need)
+{
+    const int pair = blockIdx.y;
+    if (!need[pair]) return;
+    constexpr int tpr = (STP_FRAME_MAX + GT_X - 1) / GT_X, tpc = (STP_FRAME_MAX + GT_Y - 1) / GT_Y;
+    int k = blockIdx.x, tile = -1;                    // the k-th dead tile, row by row
+    for (int t = 0; t < tpr * tpc; t++)
+        if (stp_gray_dead_tile(t / tpr, t % tpr) && k-- == 0) { tile = t; break; }
+    if (tile < 0) return;
+    gray_tile_exact<1>(band, W, hw, fstart, fS, fnz, f0, Mlev, nlev, bvals, nb, 1, gray, nullptr, tile, pair % nlev, pair / nlev);
+}
+#define STP_GRAY_DEAD_TILES 20      /* tiles with stp_gray_dead_tile in the 13 x 7 grid (checked by a static_assert on the host side) */
 
 // K-A for the 3 x 3 mean filter, certified (stp_phases.h, "certified grey"): the same tile / strip geometry as k_gray<1> -- one
 // workgroup per (tile, level, frame), the g~ plane of the tile in LDS, each wave an 8-row strip with lane = column and no
@@ -204,7 +235,7 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
                                                   const double* __restrict__ Mlev, int nlev,
                                                   const double* __restrict__ bvals, int nb,
                                                   float* __restrict__ gray, float2* __restrict__ cells,
-                                                  uint8_t* __restrict__ asym /* per image, or null: see gray_c3_redo */)
+                                                  uint8_t* __restrict__ asym /* per image, or null: see gray_c3_redo */, int skip_dead)
 {
     constexpr int HH = GT_Y + 2, WW = GT_X + 2, N = HH * WW, IT = (N + 255) / 256;
     __shared__ double sg[N], sd[N];
@@ -220,6 +251,7 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
     stp_tile T;
     T.S = S; T.ty0 = (blockIdx.x / tpr) * GT_Y; T.tx0 = (blockIdx.x % tpr) * GT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
+    if (skip_dead && stp_gray_dead_tile(blockIdx.x / tpr, blockIdx.x % tpr)) return;       // no reader (stp_phases.h, "grey tiles nobody reads")
     const int tid = threadIdx.x;
     if (tid >= 128 && tid < 128 + NCB && tid - 128 < nb) s_cb[tid - 128] = stp_gray_cb(bvals[tid - 128]);   // (read after the barriers below)
     const int16_t* nzf = fnz + (size_t)f * STP_FRAME_MAX;
@@ -693,8 +725,8 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe_list(const
     const int n = nf * nlev * nb * TPI;
     // k_gray_c3's per-image asymmetry reports have been read by k_canny_f32: cleared here, like the flags served below, so
     // that both buffers are all zero between launches
-    if (asym != nullptr)
-        for (int i = blockIdx.x * 256 + (int)threadIdx.x; i < nf * nlev * nb; i += gridDim.x * 256) asym[i] = 0;
+    if (asym != nullptr)          // (the marks of k_gray_fill's pairs lie behind them: nf x nlev more bytes)
+        for (int i = blockIdx.x * 256 + (int)threadIdx.x; i < nf * nlev * nb + nf * nlev; i += gridDim.x * 256) asym[i] = 0;
     __shared__ stp_u64 sAny[4];
     for (int k0 = blockIdx.x * 256; k0 < n; k0 += gridDim.x * 256) {     // 256 flags at a time
         const int kk = k0 + (int)threadIdx.x;
@@ -817,7 +849,7 @@ __device__ __forceinline__ void canny32_resolve(stp_tile T, int e, int lane, con
         if (hb) Vp[lane + 64] = c32_gauss_sum<R>(vb, sW);
     } else {                  // (two windows of 21 / 25 taps would not fit the registers of five waves per SIMD)
 #pragma unroll 1
-        for (int l = lane; l < NV; l += 64) Vp[l] = c32_res_V<R>(T, y, x, l, sW, gimg);
+        for (int l = lane; l < NV; l += 64) Vp[l] = c32_res_V<R, MIR>(T, y, x, l, sW, gimg);     // (MIR: grey values read at the transposed position)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -872,7 +904,7 @@ static __host__ __device__ stp_c32_layout canny32_layout(int R)
 }
 
 // mirror geometry of a tile (k_canny_f32, image symmetry): does its transpose cover tiles below the diagonal, and which
-struct stp_c32mgeo { bool mir, t1_in; int t0, tyi; };
+struct stp_c32mgeo { bool mir, t1_in; int t0, tyi, pair; };
 __device__ __forceinline__ stp_c32mgeo c32_mgeo(int mirror, int S)
 {
     constexpr int TPI = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
@@ -885,6 +917,7 @@ __device__ __forceinline__ stp_c32mgeo c32_mgeo(int mirror, int S)
     g.t0 = (2 * txi) * tpr + (tyi >> 1);             // the two tiles the transpose covers (t0, t0 + tpr), one word half each
     g.t1_in = (2 * txi + 1) * CT_Y < S;
     g.tyi = tyi;
+    g.pair = (b & 7) + 8 * ((b >> 3) / TPI);         // the (frame, level) pair of this workgroup (the XCD-aware numbering)
     return g;
 }
 // DBG (stp_dbg_canny_f32 only; the product launches <RT, false>): after the magnitudes of image dbg_bi the tile's own pixels
@@ -897,6 +930,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
                                                     const float2* __restrict__ cells, uint8_t* __restrict__ xflags,
                                                     int mirror /* the images are symmetric: see below */, const uint8_t* __restrict__ asym,
                                                     const int32_t* __restrict__ fshift /* frame overlap, or null */,
+                                                    uint8_t* __restrict__ need /* per (frame, level): tiles below the diagonal go to the exact kernel (k_gray_fill), or null */,
                                                     float* __restrict__ dbg = nullptr, int dbg_bi = -1,
                                                     unsigned long long* __restrict__ dbg_cnt = nullptr)
 {
@@ -1035,6 +1069,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
             if (mg.mir) {                             // ... and the tiles below the diagonal that would have received its transpose
                 xflags[(img0 + prev) * TPI + mg.t0] = 1;
                 if (mg.t1_in) xflags[(img0 + prev) * TPI + mg.t0 + tpr] = 1;
+                if (need != nullptr) need[mg.pair] = 1;
             }
         }
         prev = bi;
@@ -1116,6 +1151,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         if (mir) {
             xflags[(img0 + prev) * TPI + mtile0] = 1;
             if (mtile1_in) xflags[(img0 + prev) * TPI + mtile0 + tpr] = 1;
+            if (need != nullptr) need[mg.pair] = 1;
         }
     }
     uint32_t* sT = (uint32_t*)sV;                    // transposed class words [image][low | high][tile column] (the pass buffers are dead)
@@ -1125,6 +1161,7 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         if (tid >= 128 && tid < 128 + nb && asym != nullptr && asym[img0 + (tid - 128)]) {
             xflags[(img0 + (tid - 128)) * TPI + mtile0] = 1;
             if (mtile1_in) xflags[(img0 + (tid - 128)) * TPI + mtile0 + tpr] = 1;
+            if (need != nullptr) need[mg.pair] = 1;
         }
         // the verdicts of the f32 test, transposed: 32 rows x 64 columns -> 64 half words (the undecidable pixels are still
         // 0 in both forms; the resolver below sets them per position)
@@ -2713,7 +2750,7 @@ static int band_symmetric(stp_ctx* ctx, const stp_band* b, int* out);
 static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, int f0, int nf,
                      const double* h_M /* the levels on the host */, const double* d_M, int nlev, const double* d_b, const double* d_w, float* d_gray, stp_u64* d_low,
                      stp_u64* d_high, stp_drec* d_recs, int32_t* d_cnt, int want_dbg, stp_u64* d_dbg, int16_t* d_dbgc,
-                     int rcap = STP_RCAP)
+                     int rcap = STP_RCAP, bool whole_gray = false /* stp_dbg_canny_f32 reads every grey tile afterwards */)
 {
     void* p_edges = nullptr;     // parked edge maps of k_lines (one bit matrix per image)
     HIPCHK(ws_get(ctx, WS_EDGES, (size_t)nf * nlev * prm->n_bright * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), &p_edges));
@@ -2756,7 +2793,7 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     void* p_x = nullptr;         // k_canny_f32's flags: tile-images for the exact kernel [nimg x tiles], asymmetric images [nimg]
     const size_t nflags = nimg * ctiles;
     if (canny_f32) {
-        HIPCHK(ws_get(ctx, WS_C32Q, nflags + nimg, &p_x));
+        HIPCHK(ws_get(ctx, WS_C32Q, nflags + nimg + (size_t)nf * nlev, &p_x));
         // the flags are zero between launches: k_canny_pipe_list clears every flag it has served, so the buffer is
         // cleared here only when it is new (no fill kernel -- two launch gaps -- between k_gray and the Canny kernel)
         if (ctx->c32q_zero != p_x || ctx->c32q_zero_bytes < ctx->ws_bytes[WS_C32Q]) {
@@ -2765,6 +2802,12 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         }
     }
     uint8_t* p_asym = mirror ? (uint8_t*)p_x + nflags : nullptr;
+    // with the symmetry in use the 20 grey tiles no computed Canny tile reads are not written (stp_gray_dead_tile); the debug entry
+    // points return whole grey images and keep them
+    const int skip_dead = mirror && !want_dbg && !whole_gray;
+    uint8_t* p_need = skip_dead ? p_asym + nimg : nullptr;
+    static_assert([] { int n = 0; for (int t = 0; t < 91; t++) n += (t / 7 >= 2 * (t % 7) + 5); return n; }() == STP_GRAY_DEAD_TILES    /* stp_gray_dead_tile */
+                  && ((STP_FRAME_MAX + GT_X - 1) / GT_X) == 7 && ((STP_FRAME_MAX + GT_Y - 1) / GT_Y) == 13, "k_gray_fill's grid");
     // Frame overlap: k_canny_f32 skips the tiles inside the block a frame shares with its successor, k_lines fetches their class
     // words from the successor's planes (STP_REUSE=0 switches it off)
     const int32_t* p_shift = nullptr;
@@ -2772,13 +2815,22 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         const char* reuse_env = getenv("STP_REUSE");
         if (!(reuse_env && reuse_env[0] == '0')) p_shift = fr->d_shift;
     }
+    {   // (test hook: STP_TEST_POISON_GRAY=1 fills the grey images and their cell table with NaN patterns before the grey kernel runs,
+        //  so that a read of anything this launch did not write -- a skipped tile -- reaches the class maps instead of finding the
+        //  previous launch's values there)
+        const char* pz = getenv("STP_TEST_POISON_GRAY");
+        if (pz && pz[0] == '1') {
+            HIPCHK(hipMemsetAsync(d_gray, 0xFF, nimg * (size_t)STP_PITCH * STP_PITCH * sizeof(float), ctx->stream));
+            if (p_cells) HIPCHK(hipMemsetAsync(p_cells, 0xFF, nimg * GC_ROWS * GC_COLS * sizeof(float2), ctx->stream));
+        }
+    }
     prof_scope chain_scope(ctx, "chain_wall", ipx * 26.0);     // gray + canny + lines as one interval
     {
         prof_scope ps(ctx, "gray", ipx * 12.0);          // stage A of SURVEY 8(d): 8 B read + 4 B written per image px
         const int tiles = ((STP_FRAME_MAX + GT_X - 1) / GT_X) * ((STP_FRAME_MAX + GT_Y - 1) / GT_Y);
         if (a == 1 && !gray_exact)
             hipLaunchKernelGGL(k_gray_c3, dim3(tiles, STP_GRAY_LEVRUNS < nlev ? STP_GRAY_LEVRUNS : nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
-                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (float2*)p_cells, p_asym);
+                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (float2*)p_cells, p_asym, skip_dead);
         else if (a == 1)
             hipLaunchKernelGGL(k_gray<1>, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
                                fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray, (float2*)p_cells);
@@ -2806,7 +2858,9 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
             switch (R) {
 #define STP_X(RR) case RR: \
                 hipLaunchKernelGGL(k_canny_f32<RR>, dim3(pgrid), dim3(256), smem, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, d_w, \
-                                   d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x, mirror, (const uint8_t*)p_asym, p_shift); \
+                                   d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x, mirror, (const uint8_t*)p_asym, p_shift, p_need); \
+                if (p_need) hipLaunchKernelGGL(k_gray_fill, dim3(STP_GRAY_DEAD_TILES, (unsigned)(nf * nlev)), dim3(256), 0, ctx->stream, band->d, band->W, \
+                                               band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (const uint8_t*)p_need); \
                 hipLaunchKernelGGL(k_canny_pipe_list<RR>, dim3(xgrid), dim3(256), smem_x, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, \
                                    d_w, d_low, d_high, fd, (uint8_t*)p_x, p_asym); \
                 break;
@@ -3219,7 +3273,7 @@ int stp_dbg_canny_f32(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
     HIPCHK(x.h2d(bB.p, prm->bright, nb * sizeof(double)));
     HIPCHK(x.h2d(bW.p, prm->gauss_w, (2 * R + 1) * sizeof(double)));
     rc = run_chain(ctx, fr, prm, f, 1, &M, (const double*)bM.p, 1, (const double*)bB.p, (const double*)bW.p, dGray,
-                   (stp_u64*)bLow.p, (stp_u64*)bHigh.p, (stp_drec*)bRecs.p, (int32_t*)bCnt.p, 0, nullptr, nullptr, STP_RCAP_MAX);
+                   (stp_u64*)bLow.p, (stp_u64*)bHigh.p, (stp_drec*)bRecs.p, (int32_t*)bCnt.p, 0, nullptr, nullptr, STP_RCAP_MAX, true);
     if (rc) return rc;
     void* p_cells = nullptr;                         // the table run_chain has just filled (same workspace slot, same size)
     HIPCHK(ws_get(ctx, WS_CELLS, nimg * GC_ROWS * GC_COLS * sizeof(float2), &p_cells));
@@ -3235,7 +3289,7 @@ int stp_dbg_canny_f32(stp_ctx* ctx, const stp_frames* fr, const stp_search_param
 #define STP_X(RR) case RR: \
         hipLaunchKernelGGL((k_canny_f32<RR, true>), dim3(pgrid), dim3(256), smem, ctx->stream, (const float*)dGray, fr->d_S, f, 1, 1, nb, \
                            (const double*)bW.p, (stp_u64*)bLow.p, (stp_u64*)bHigh.p, W32, (const float2*)p_cells, (uint8_t*)bX.p, \
-                           0, (const uint8_t*)nullptr, (const int32_t*)nullptr /* every tile computed: the dump covers the whole image */, \
+                           0, (const uint8_t*)nullptr, (const int32_t*)nullptr, (uint8_t*)nullptr /* every tile computed: the dump covers the whole image */, \
                            (float*)bPl.p, (int)bi, (unsigned long long*)bC.p); \
         break;
         STP_CANNY_RADII(STP_X)

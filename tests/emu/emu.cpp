@@ -66,7 +66,7 @@ static void emu_tile_c32(stp_tile T, const double* w, const float* gray, float g
                 for (int l = 0; l < 9; l++) M9[l] = c32_res_mag(Sp, l);
                 cls = c32_res_class(Sp, M9);
                 if (sCm) {                              // the mirror pixel (x, y): canny32_resolve<R, true>
-                    for (int l = 0; l < NV; l++) Vp[l] = c32_res_V<R>(T, x, y, l, w, gray);
+                    for (int l = 0; l < NV; l++) Vp[l] = c32_res_V<R, true>(T, x, y, l, w, gray);      // (grey values read at the transposed position)
                     for (int l = 0; l < 25; l++) Sp[l] = c32_res_S_any<R>(T.S, x, y, l, w, Vp);
                     for (int l = 0; l < 9; l++) M9[l] = c32_res_mag(Sp, l);
                     sCm[xx * CT_Y + yy] = (uint8_t)c32_res_class(Sp, M9);

@@ -129,6 +129,27 @@ def test_plateaus_on_and_across_the_diagonal(hip_ctx):
                     _, dbg = O.canny(O.gray(gp, O.brightness_levels()[bi], 3), gw, gr, debug=True)
                     assert np.array_equal(a['cls'], dbg['cls']), (name, f, M, bi)
                     assert np.array_equal(b['cls'], dbg['cls']), (name, f, M, bi, 'every tile computed')
+        # the search itself (the debug entry point above keeps whole grey images; the search does not write the grey tiles no
+        # computed Canny tile reads, and fills them in for the (frame, level) pairs whose tiles below the diagonal go to the
+        # exact kernel: k_gray_fill): records with the measures on, off, and the oracle's
+        Ms = np.array([float(np.quantile(dense[dense > 0], 0.9)), float(dense.max())])
+        with _sym(None):
+            ra = fr.stripe_search(Ms)
+        os.environ['STP_REUSE'] = '0'
+        try:
+            with _sym('0'):
+                rb = fr.stripe_search(Ms)
+        finally:
+            os.environ.pop('STP_REUSE', None)
+        assert ra.tobytes() == rb.tobytes(), name
+        exp = []
+        for f, (s, e) in enumerate(((0, 399), (250, 649))):
+            D = np.ascontiguousarray(dense[s:e + 1, s:e + 1])
+            for li, M in enumerate(Ms):
+                r, t = O.stripe_search(D, float(M), gw=gw)
+                exp += [(f, li) + tuple(int(v) for v in q) for q in r]
+        got = [tuple(int(r[k]) for k in ('frame', 'level', 'b_index', 'ud', 'x', 'y', 'w', 'h')) for r in ra]
+        assert got == exp, name
         fr.close(); band.close()
 
 
@@ -170,3 +191,40 @@ def test_a_band_that_is_not_symmetric_is_never_mirrored(hip_ctx):
     gotl = [tuple(int(r[k]) for k in ('frame', 'level', 'b_index', 'ud', 'x', 'y', 'w', 'h')) for r in got]
     assert sorted(gotl) == sorted(exp) and len(exp) > 0
     fr.close(); band.close()
+
+
+def test_skipped_grey_tiles_are_never_read(hip_ctx):
+    """With the symmetry in use k_gray_c3 does not write the 20 grey tiles no computed Canny tile reads (the far corner below the
+    diagonal).  STP_TEST_POISON_GRAY=1 fills the grey images and the cell table with NaN patterns before every launch: a read of
+    an unwritten value would reach the class maps.  Ordinary data (the resolver's transposed reads), plateaus (list overflow ->
+    the tiles below the diagonal through the exact kernel, their grey tiles filled in by k_gray_fill) and report-all (every pair
+    filled in) give the records of the plain search."""
+    from stripenn_amd import synth
+    ch = synth.SynthChrom(3100, 53, stripe_every=70, stripe_gain=3.0, nan_frac=0.008)
+    band_h = ch.band(512)
+    n = 800
+    rr, cc = np.mgrid[0:n, 0:n].astype(np.float64)
+    blocks = np.where(((cc // 37) + (rr // 37)) % 2 == 0, 12.0, 3.0) + np.where(np.abs(cc - rr) < 25, 20.0, 0.0)
+    blocks = np.where(np.abs(cc - rr) <= 500, blocks, 0.0)
+    for name, bh in (('noisy', band_h), ('blocks', _band_of(blocks))):
+        nb = bh.shape[0]
+        band = hip_ctx.band_upload(bh)
+        nfr = -(-nb // 200)
+        st = np.array([max(0, i * 200 - 100) for i in range(nfr)]); en = np.minimum((np.arange(nfr) + 1) * 200 + 99, nb - 1)
+        fr = band.frames(st, en)
+        Ms = np.quantile(bh[bh > 0], [0.9, 0.99])
+        os.environ['STP_REUSE'] = '0'; os.environ['STP_SYM'] = '0'
+        try:
+            ref = fr.stripe_search(Ms)
+        finally:
+            os.environ.pop('STP_REUSE', None); os.environ.pop('STP_SYM', None)
+        assert len(ref) > 20
+        os.environ['STP_TEST_POISON_GRAY'] = '1'
+        try:
+            for mode in (None, 'report-all'):
+                with _sym(mode):
+                    got = fr.stripe_search(Ms)
+                assert got.tobytes() == ref.tobytes(), (name, mode)
+        finally:
+            os.environ.pop('STP_TEST_POISON_GRAY', None)
+        fr.close(); band.close()
