@@ -297,6 +297,10 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
             }
         }
         __syncthreads();
+        // (round 6, measured and dropped -- profiles/r06_ab_saturated_strips.txt: a wave whose whole 10 x 66 window holds g~ >= b writes
+        //  ONE number, ((3 b) + (3 b) + (3 b)) c_b, into its 512 outputs; 15 % of the strip-images of the benchmark data qualify -- the
+        //  darker brightness levels away from the diagonal -- but the kernel's time did not move (12.5-12.8 ms per step either way):
+        //  those strips still store their 2 KB, and the 29 minima per level that find them cost what the skipped arithmetic saved)
         for (int bi = 0; bi < nb; bi++) {
             const size_t img = ((size_t)fl * nlev + lev) * nb + bi;
             float* gimg = gray + img * (size_t)(STP_PITCH * STP_PITCH) + (size_t)y0 * STP_PITCH + x;
@@ -1370,10 +1374,36 @@ __device__ int lines_group_pairs_wave(int lane, int S, int ud, int maxW, int nro
     }
     const stp_u64 em = __ballot(emit);
     if (emit) {
-        const int pos = nrec + __popcll(em & ((1ull << lane) - 1ull));
+        // (lanes below this one that emit: mbcnt, not a popcount under a per-lane mask -- the mask, hoisted out of the direction
+        //  loop, was what k_lines spilled once the wave-cooperative paint had joined the loop)
+        const int pos = nrec + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(em >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)em, 0u));
         if (pos < cap) recs[pos] = r;
     }
     return nrec + __popcll(em);
+}
+
+// lines_paint (stp_phases.h: getStripe.py:948-955) by waves (round 6): a wave takes 64 columns; the columns to paint (a ballot)
+// are walked one after the other and each one's rows are painted by all 64 lanes side by side -- 64 rows per step on different LDS
+// words -- instead of every lane walking its own column alone, one atomic after the other, while the wave waits for its longest
+// column (a stripe is up to 400 rows long; an image paints ~20 columns).  Same words, same bits: OR commutes.
+__device__ __forceinline__ void lines_paint_wave(int tid, int nt, int S, int ud, const int16_t* colEnd, const int16_t* colUd, stp_u64* sT)
+{
+    const int lane = tid & 63;
+    for (int c0 = (tid >> 6) << 6; c0 < S; c0 += nt) {            // wave-uniform
+        const int c = c0 + lane;
+        stp_u64 m = __ballot(c < S && colUd[c] == ud);
+        while (m) {                                                // wave-uniform
+            const int col = c0 + __builtin_ctzll(m);
+            m &= m - 1;
+            // (the column's bounds again from LDS, one broadcast read: no per-lane copies live across the loop)
+            int cs = col, ce = __builtin_amdgcn_readfirstlane((int)colEnd[col]);
+            if (ud == 1) { const int t = cs; cs = ce; ce = t; }
+            if (cs < 0) cs = 0;
+            if (ce > S) ce = S;
+            const stp_u64 bit = 1ull << (col & 63);
+            for (int y = cs + lane; y < ce; y += 64) atomicOr(&sT[y * STP_NW + (col >> 6)], bit);
+        }
+    }
 }
 
 // K-C: hysteresis + verticalLine + block + line joining + totals, one workgroup per image, every mask
@@ -1493,7 +1523,11 @@ __global__ __launch_bounds__(512, RCAP == STP_RCAP ? 6 : 4) void k_lines(const s
     for (int ud = 1; ud <= 2; ud++) {
         lines_zero(tid, nt, S * STP_NW, bufB);
         __syncthreads();
+#if defined(STP_EXP_OLDPAINT)           /* A/B build: a lane per column, as in rounds 1-5 */
         lines_paint(tid, nt, S, ud, colEnd, colUd, bufB);
+#else
+        lines_paint_wave(tid, nt, S, ud, colEnd, colUd, bufB);
+#endif
         __syncthreads();
         if (dbg_stop == 7) { if (tid == 0) rec_count[img] = (int)(bufB[3] & 0); return; }
         lines_refine(tid, nt, S, eimg, bufA, bufB);
