@@ -2387,26 +2387,47 @@ void stp_band_free(stp_ctx* ctx, stp_band* b)
     delete b;
 }
 
-// Frame overlap (stp_phases.h): the mark of every frame, one lane per frame, from the compaction k_frame_prep has just written
-// (same stream).  Second rule (the block frame i takes from frame i + 1 must not reach into the block frame i + 1 takes from
-// frame i + 2): both marks are formed by the lane that needs them.
+// Frame overlap (stp_phases.h): the mark of every frame from the compaction k_frame_prep has just written (same stream), one WAVE
+// per frame: stp_overlap_shift's tests with the lanes side by side (a lane per frame walked its 400-entry lists alone: 0.25 ms
+// per launch, in front of the blocking copy every frame preparation ends with).  Second rule (the block frame i takes from frame
+// i + 1 must not reach into the block frame i + 1 takes from frame i + 2): both marks are formed by the wave that needs them.
+__device__ __forceinline__ int overlap_shift_wave(int s0, int n0, int S0, const int16_t* __restrict__ z0, int s1, int n1, int S1,
+                                                  const int16_t* __restrict__ z1, int lane)
+{
+    const int e0 = s0 + n0 - 1, e1 = s1 + n1 - 1;
+    if (!(s1 > s0 && s1 <= e0 && e1 >= e0) || S0 <= 0 || S1 <= 0) return -1;          // (wave-uniform throughout)
+    int p = 0;                                                                          // kept bins of frame i before frame i + 1 starts (z0 ascends)
+    for (int k0 = 0; k0 < S0; k0 += 64) {
+        const int k = k0 + lane;
+        p += __popcll(__ballot(k < S0 && s0 + z0[k] < s1));
+    }
+    const int q = S0 - p;
+    if (q < 1 || q > S1) return -1;
+    bool diff = false;
+    for (int k0 = 0; k0 < q; k0 += 64) {
+        const int k = k0 + lane;
+        diff = diff || (k < q && s0 + z0[p + k] != s1 + z1[k]);
+    }
+    if (__any(diff)) return -1;
+    if (q < S1 && s1 + z1[q] <= e0) return -1;
+    return p;
+}
 __global__ __launch_bounds__(64) void k_overlap_shift(const int32_t* __restrict__ fstart, const int32_t* __restrict__ fn0,
                                                       const int32_t* __restrict__ fS, const int16_t* __restrict__ fnz, int n,
                                                       int32_t* __restrict__ shift)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
+    const int i = blockIdx.x, lane = threadIdx.x;
     int p = -1;
     if (i + 1 < n) {
-        p = stp_overlap_shift(fstart[i], fn0[i], fS[i], fnz + (size_t)i * STP_FRAME_MAX, fstart[i + 1], fn0[i + 1], fS[i + 1],
-                              fnz + (size_t)(i + 1) * STP_FRAME_MAX);
+        p = overlap_shift_wave(fstart[i], fn0[i], fS[i], fnz + (size_t)i * STP_FRAME_MAX, fstart[i + 1], fn0[i + 1], fS[i + 1],
+                               fnz + (size_t)(i + 1) * STP_FRAME_MAX, lane);
         if (p >= 0 && i + 2 < n) {
-            const int p1 = stp_overlap_shift(fstart[i + 1], fn0[i + 1], fS[i + 1], fnz + (size_t)(i + 1) * STP_FRAME_MAX, fstart[i + 2],
-                                             fn0[i + 2], fS[i + 2], fnz + (size_t)(i + 2) * STP_FRAME_MAX);
+            const int p1 = overlap_shift_wave(fstart[i + 1], fn0[i + 1], fS[i + 1], fnz + (size_t)(i + 1) * STP_FRAME_MAX, fstart[i + 2],
+                                              fn0[i + 2], fS[i + 2], fnz + (size_t)(i + 2) * STP_FRAME_MAX, lane);
             if (p1 >= 0 && p1 < fS[i] - p) p = -1;
         }
     }
-    shift[i] = p;
+    if (lane == 0) shift[i] = p;
 }
 
 void stp_frames_free(stp_ctx* ctx, stp_frames* fr)
@@ -2470,7 +2491,7 @@ int stp_frames_create_ex(stp_ctx* ctx, const stp_band* band, const int32_t* star
         stp_bandref B{band->d, band->nrows, band->W, band->hw};
         hipLaunchKernelGGL(k_frame_prep, dim3(n), dim3(STP_PREP_NT), 0, ctx->aux, B, fr->d_start, fr->d_n0, fr->d_S, fr->d_nz, d_med,
                            (flags & STP_FRAMES_KEEP_ALL) ? 1 : 0);
-        hipLaunchKernelGGL(k_overlap_shift, dim3((n + 63) / 64), dim3(64), 0, ctx->aux, fr->d_start, fr->d_n0, fr->d_S, fr->d_nz, n, fr->d_shift);
+        hipLaunchKernelGGL(k_overlap_shift, dim3(n), dim3(64), 0, ctx->aux, fr->d_start, fr->d_n0, fr->d_S, fr->d_nz, n, fr->d_shift);
     }
     {
         hipError_t el = hipGetLastError();
@@ -2518,7 +2539,20 @@ int stp_frames_info(stp_ctx* ctx, const stp_frames* fr, int32_t* S_out, int16_t*
 int stp_frames_overlap(stp_ctx* ctx, const stp_frames* fr, int32_t* shift_out)
 {
     if (!ctx || !fr || !shift_out) return STP_E_ARG;
-    memcpy(shift_out, fr->h_shift.data(), fr->n * sizeof(int32_t));
+    // the marks the kernels use are the DEVICE's (k_overlap_shift); the host forms its own from the same rule: they are compared
+    // here, so that a caller of this (test / diagnostic) entry point sees a disagreement instead of the host's opinion
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<int32_t> dev(fr->n);
+    {
+        stp_xfer x(ctx, ctx->aux);
+        HIPCHK(x.d2h(dev.data(), fr->d_shift, fr->n * sizeof(int32_t)));
+        HIPCHK(x.finish());
+    }
+    for (int i = 0; i < fr->n; i++)
+        if (dev[i] != fr->h_shift[i])
+            return set_err(ctx, STP_E_HIP, "frame overlap: device mark of frame " + std::to_string(i) + " = " + std::to_string(dev[i]) +
+                                           ", host " + std::to_string(fr->h_shift[i]));
+    memcpy(shift_out, dev.data(), fr->n * sizeof(int32_t));
     return STP_OK;
 }
 
