@@ -1880,6 +1880,7 @@ struct stp_pending {
     hipEvent_t e0, e1;
     const char* name;
     double bytes;
+    bool own = true;          // false: the events are shared marks of a chain (prof_marks), destroyed once through stp_ctx::shared_events
 };
 
 enum { WS_GRAY = 0, WS_LOW, WS_HIGH, WS_RECS, WS_CNT, WS_OUT, WS_TOTAL, WS_PARAMS, WS_EDGES, WS_CELLS, WS_C32Q, WS_NSLOTS };
@@ -1887,6 +1888,7 @@ enum { WS_GRAY = 0, WS_LOW, WS_HIGH, WS_RECS, WS_CNT, WS_OUT, WS_TOTAL, WS_PARAM
 struct stp_ctx {
     int device = 0;
     std::vector<stp_pending> pending;
+    std::vector<hipEvent_t> shared_events;      // chain marks several pending intervals refer to (destroyed after they are resolved)
     void* ws[WS_NSLOTS] = {nullptr};       // grow-only device workspace, reused across calls
     size_t ws_bytes[WS_NSLOTS] = {0};
     void* pin = nullptr;                   // pinned host staging buffer (records)
@@ -2054,11 +2056,43 @@ static void resolve_pending(stp_ctx* ctx)
             stp_kstat& s = stat_for(ctx, p.name);
             s.launches++; s.ms += ms; s.bytes += p.bytes;
         }
-        (void)hipEventDestroy(p.e0);
-        (void)hipEventDestroy(p.e1);
+        if (p.own) {
+            (void)hipEventDestroy(p.e0);
+            (void)hipEventDestroy(p.e1);
+        }
     }
     ctx->pending.clear();
+    for (hipEvent_t e : ctx->shared_events) (void)hipEventDestroy(e);
+    ctx->shared_events.clear();
 }
+
+// The chain's timers as MARKS between its kernels (round 6): grey = [m0, m1], Canny = [m1, m2], line joining = [m2, m3], the chain =
+// [m0, m3], the record compaction behind it = [m3, m4] -- five event records per unit instead of the ten that five separate scopes
+// put into the stream (every record is a packet the kernels behind it wait for: the timers cost a genome step 0.8-1.6 ms,
+// tools/ab_profiling.py).
+struct prof_marks {
+    stp_ctx* ctx;
+    hipEvent_t m[8] = {};
+    int n = 0;
+    explicit prof_marks(stp_ctx* c) : ctx(c) {}
+    int mark()                                      // returns the mark's index, or -1 (not profiling / no event)
+    {
+        if (!ctx->profiling || n >= 8) return -1;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        (void)hipEventRecord(e, ctx->stream);
+        ctx->shared_events.push_back(e);
+        m[n] = e;
+        return n++;
+    }
+    void interval(int a, int b, const char* name, double bytes)
+    {
+        if (a < 0 || b < 0) return;
+        stp_pending p;
+        p.e0 = m[a]; p.e1 = m[b]; p.name = name; p.bytes = bytes; p.own = false;
+        ctx->pending.push_back(p);
+    }
+};
 
 extern "C" {
 #pragma GCC visibility push(default)
@@ -2818,7 +2852,8 @@ static int band_symmetric(stp_ctx* ctx, const stp_band* b, int* out);
 static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params* prm, int f0, int nf,
                      const double* h_M /* the levels on the host */, const double* d_M, int nlev, const double* d_b, const double* d_w, float* d_gray, stp_u64* d_low,
                      stp_u64* d_high, stp_drec* d_recs, int32_t* d_cnt, int want_dbg, stp_u64* d_dbg, int16_t* d_dbgc,
-                     int rcap = STP_RCAP, bool whole_gray = false /* stp_dbg_canny_f32 reads every grey tile afterwards */)
+                     int rcap = STP_RCAP, bool whole_gray = false /* stp_dbg_canny_f32 reads every grey tile afterwards */,
+                     prof_marks* marks_out = nullptr /* the chain's timer marks, for the caller's own interval behind them */)
 {
     void* p_edges = nullptr;     // parked edge maps of k_lines (one bit matrix per image)
     HIPCHK(ws_get(ctx, WS_EDGES, (size_t)nf * nlev * prm->n_bright * STP_FRAME_MAX * STP_NW * sizeof(stp_u64), &p_edges));
@@ -2892,9 +2927,12 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
             if (p_cells) HIPCHK(hipMemsetAsync(p_cells, 0xFF, nimg * GC_ROWS * GC_COLS * sizeof(float2), ctx->stream));
         }
     }
-    prof_scope chain_scope(ctx, "chain_wall", ipx * 26.0);     // gray + canny + lines as one interval
+    // timers (prof_marks): grey = [m0, m1] (stage A of SURVEY 8(d): 8 B read + 4 B written per image px), Canny = [m1, m2] (stage B: 4 B
+    // read + 1 B written), line joining = [m2, m3] (stages C-F: 2 + 2 + 1 + 4 B), the chain as one interval = [m0, m3]
+    prof_marks local_marks(ctx);
+    prof_marks& PM = marks_out ? *marks_out : local_marks;
+    const int m0 = PM.mark();
     {
-        prof_scope ps(ctx, "gray", ipx * 12.0);          // stage A of SURVEY 8(d): 8 B read + 4 B written per image px
         const int tiles = ((STP_FRAME_MAX + GT_X - 1) / GT_X) * ((STP_FRAME_MAX + GT_Y - 1) / GT_Y);
         if (a == 1 && !gray_exact)
             hipLaunchKernelGGL(k_gray_c3, dim3(tiles, STP_GRAY_LEVRUNS < nlev ? STP_GRAY_LEVRUNS : nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
@@ -2910,8 +2948,9 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         if (p_asym && sym_all) HIPCHK(hipMemsetAsync(p_asym, 1, nimg, ctx->stream));
     }
     HIPCHK(hipGetLastError());
+    const int m1 = PM.mark();
+    PM.interval(m0, m1, "gray", ipx * 12.0);
     {
-        prof_scope ps(ctx, "canny", ipx * 5.0);          // stage B: 4 B read + 1 B written
         const int tiles = ((STP_FRAME_MAX + CT_X - 1) / CT_X) * ((STP_FRAME_MAX + CT_Y - 1) / CT_Y);
         const dim3 cg(tiles, (unsigned)nimg);
         const unsigned pgrid = (unsigned)(((nf * nlev + 7) / 8) * 8 * tiles);
@@ -2958,13 +2997,14 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         }
     }
     HIPCHK(hipGetLastError());
+    const int m2 = PM.mark();
+    PM.interval(m1, m2, "canny", ipx * 5.0);
     {
 #if defined(STP_ABLATE_LINES_STOPS)   /* timing-only build (make ablate): truncate k_lines after phase N */
         static const int lines_stop = getenv("STP_LINES_STOP") ? atoi(getenv("STP_LINES_STOP")) : 0;
 #else
         const int lines_stop = 0;          // the product library has no such switch
 #endif
-        prof_scope ps(ctx, "lines", ipx * 9.0);          // stages C-F: 2 + 2 + 1 + 4 B per image px
         if (rcap == STP_RCAP)
             hipLaunchKernelGGL(k_lines<STP_RCAP>, dim3((unsigned)nimg), dim3(512), 0, ctx->stream, d_low, d_high, band->d, band->W,
                                band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, ipf, prm->minH, prm->maxW, d_recs, d_cnt,
@@ -2975,6 +3015,9 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
                                (stp_u64*)p_edges, want_dbg, d_dbg, d_dbgc, lines_stop, p_shift, R, nf, mirror);
     }
     HIPCHK(hipGetLastError());
+    const int m3 = PM.mark();
+    PM.interval(m2, m3, "lines", ipx * 9.0);
+    PM.interval(m0, m3, "chain_wall", ipx * 26.0);
     return STP_OK;
 }
 
@@ -3093,15 +3136,17 @@ static int search_enqueue(stp_ctx* ctx, stp_search* s)
         const int f0 = c * chunk;
         const int nf = (fr->n - f0 < chunk) ? fr->n - f0 : chunk;
         const size_t nimg = (size_t)nf * ipf;
+        prof_marks PM(ctx);
         int rc = run_chain(ctx, fr, prm, f0, nf, s->M.data(), dM, n_levels, dB, dW, (float*)pGray, (stp_u64*)pLow, (stp_u64*)pHigh,
-                           (stp_drec*)pRecs, (int32_t*)pCnt, 0, nullptr, nullptr, rcap);
+                           (stp_drec*)pRecs, (int32_t*)pCnt, 0, nullptr, nullptr, rcap, false, &PM);
         if (rc) return rc;
         {
-            prof_scope ps(ctx, "compact_recs", (double)nimg * 4.0);
             hipLaunchKernelGGL(k_compact_recs, dim3((unsigned)((nimg + CR_IPB - 1) / CR_IPB)), dim3(1024), 0, ctx->stream, (const stp_drec*)pRecs,
                                (const int32_t*)pCnt, (int)nimg, f0, n_levels, nb, (stp_stripe_rec*)s->d_out, (long long)ocap,
                                (const long long*)(s->d_tot + 2 * c), s->d_tot + 2 * (c + 1), rcap,
                                rcap == STP_RCAP ? std::min(rcap, ctx->sweep_slots) : rcap);
+            const int m4 = PM.mark();
+            PM.interval(PM.n >= 2 ? PM.n - 2 : -1, m4, "compact_recs", (double)nimg * 4.0);      // from the chain's last mark
         }
         HIPCHK(hipGetLastError());
     }
