@@ -354,6 +354,43 @@ void emu_canny_f32_sym(const float* gray, int S, int R, const double* w, stp_u64
     if (counts) { counts[0] = g_c32_candidates; counts[1] = g_c32_uncertain; }
 }
 
+// Round 6 invariant: every class half word k_lines reads (rows < S, words < ceil(S / 64)) is written by exactly one source -- a
+// computed tile of k_canny_f32 (directly, or as the transpose of a tile above the diagonal) or the loader's patch from the next
+// frame (stp_reuse_mask).  The writers are restated here from the kernel's rules; returns the number of (row, half word) cells that
+// are written by nobody or claimed twice.
+long long emu_class_word_cover(int S, int shift, int R, int mirror, int next_in_launch)
+{
+    const stp_reuse U = stp_reuse_of(shift, S, R, next_in_launch != 0);
+    const int nwu = (S + 63) >> 6;
+    std::vector<int> cnt((size_t)STP_FRAME_MAX * STP_NW * 2, 0);
+    auto put = [&](int r, int w, int h) { if (r < S) cnt[((size_t)r * STP_NW + w) * 2 + h]++; };
+    for (int ty = 0; ty * CT_Y < S; ty++)
+        for (int tx = 0; tx * CT_X < S; tx++) {
+            if (mirror && ty >= 2 * tx + 2) continue;                       // strictly below the diagonal: never computed
+            if (stp_reuse_tile(U, ty, tx)) continue;                         // inside the block shared with the next frame
+            for (int r = ty * CT_Y; r < ty * CT_Y + CT_Y; r++) { put(r, tx, 0); put(r, tx, 1); }
+            if (mirror && tx > (ty >> 1)) {                                  // its transpose: rows tx0 .., word ty / 2, half ty & 1
+                const bool solo = (ty & 1) == 0 && ty * CT_Y + CT_Y >= S;
+                for (int r = tx * CT_X; r < tx * CT_X + CT_X; r++) {
+                    put(r, ty >> 1, ty & 1);
+                    if (solo) put(r, ty >> 1, 1);
+                }
+            }
+        }
+    long long bad = 0;
+    for (int r = 0; r < S; r++)
+        for (int w = 0; w < nwu; w++) {
+            const stp_u64 m = stp_reuse_mask(U, mirror, r, w);
+            for (int h = 0; h < 2; h++) {
+                const bool patched = ((m >> (32 * h)) & 0xFFFFFFFFull) != 0;
+                if (patched && ((m >> (32 * h)) & 0xFFFFFFFFull) != 0xFFFFFFFFull) bad++;        // a half word is patched whole or not at all
+                if (cnt[((size_t)r * STP_NW + w) * 2 + h] + (patched ? 1 : 0) != 1) bad++;
+                if (patched && !(r - shift >= STP_REUSE_MARGIN(R) && r - shift < S - shift - STP_REUSE_MARGIN(R))) bad++;   // source rows inside the shared block's interior
+            }
+        }
+    return bad;
+}
+
 struct emu_rec { int32_t ud, x, y, w, h; double total; };
 
 // mirror of k_lines; dbg: E, V, T1, T2 bit matrices (each 400*7 words); cols: t, end, ud (3 x 400)

@@ -466,3 +466,23 @@ def test_canny_mirrored_tiles_other_radii(emu, sigma):
             oe, dbg = O.canny(img, gw, R, debug=True)
             got, _ = _canny_f32_sym(emu, full, S, R, gw)
             assert np.array_equal(got, dbg['cls']), 'mirrored tiles, image %d (S=%d, sigma %.1f)' % (k, S, sigma)
+
+
+def test_every_class_word_has_exactly_one_writer(emu):
+    """Round 6 invariant (image symmetry + frame overlap): for every image size, shared-block position, radius and both settings
+    of `mirror`, every (row, half word) of the class planes k_lines reads is written by exactly one computed tile of
+    k_canny_f32 -- directly or as a transpose -- or patched from the next frame by the loader (stp_reuse_mask); never by nobody,
+    never twice; patched rows lie inside the shared block's interior."""
+    emu.emu_class_word_cover.restype = C.c_longlong
+    n = 0
+    for S in list(range(11, 80, 7)) + list(range(80, 401, 3)):
+        for R in (4, 8, 12):
+            for mirror in (0, 1):
+                assert emu.emu_class_word_cover(S, -1, R, mirror, 1) == 0, (S, R, mirror, 'no shared block')
+                for shift in {0, 1, S // 3, S // 2 - 1, S // 2, S // 2 + 3, S - 150, S - 64, S - 40} - {s for s in range(-400, 0)}:
+                    if shift >= S:
+                        continue
+                    assert emu.emu_class_word_cover(S, shift, R, mirror, 1) == 0, (S, shift, R, mirror)
+                    assert emu.emu_class_word_cover(S, shift, R, mirror, 0) == 0, (S, shift, R, mirror, 'next frame in another launch')
+                    n += 1
+    assert n > 4000
