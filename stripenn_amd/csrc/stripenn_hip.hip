@@ -338,7 +338,10 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
 #if defined(STP_ABLATE_GRAY) && STP_ABLATE_GRAY == 1      /* timing-only builds (never shipped): no pixel stores ... */
                         if (out[j] == 12345.0f)
 #endif
-                        gimg[j * STP_PITCH] = out[j];
+                        // (non-temporal, round 6: a launch writes 1.9 GB of grey values that the Canny kernel reads one launch later,
+                        //  from HBM either way -- kept out of the caches they no longer evict what the other kernels share: 12.5 ->
+                        //  10.5 ms per step, and 2.5 ms off the step: profiles/r06_ab_nt_stores.txt)
+                        __builtin_nontemporal_store(out[j], &gimg[j * STP_PITCH]);
                         const unsigned bits = __float_as_uint(out[j]);       // grey values are >= +0: their bit patterns order like the values
 #if !(defined(STP_ABLATE_GRAY) && STP_ABLATE_GRAY == 3)   /* ... no cell minima / maxima ... */
                         vmn = min(vmn, bits); vmx = max(vmx, bits);
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
 #pragma unroll
                     for (int j = 0; j < GS_ROWS; j++)
                         if (j < nrows) {
-                            gimg[j * STP_PITCH] = out[j];
+                            __builtin_nontemporal_store(out[j], &gimg[j * STP_PITCH]);
                             const unsigned bits = __float_as_uint(out[j]);
                             vmn = min(vmn, bits); vmx = max(vmx, bits);
                         }
@@ -1199,8 +1202,8 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
         const int bi = i / CT_Y, row = i - bi * CT_Y, y = T.ty0 + row;
         if (y < S) {
             const size_t o = (img0 + bi) * (STP_FRAME_MAX * STP_NW) + STP_CLS(y, T.tx0 >> 6);   // 32 rows = 256 contiguous bytes per plane
-            low[o] = sBits[bi * 2 * CT_Y + row];
-            high[o] = sBits[bi * 2 * CT_Y + CT_Y + row];
+            low[o] = sBits[bi * 2 * CT_Y + row];                     // (plain stores: non-temporal ones for the class words, or non-temporal
+            high[o] = sBits[bi * 2 * CT_Y + CT_Y + row];            //  loads in k_lines' loader, changed nothing -- measured in round 6)
         }
     }
     if (mir) {
