@@ -482,6 +482,10 @@ def main():
                                    'value': round(px4 * 5 / dt4 / 1e6, 2), 'unit': 'contact-Mpx/s', 'ms_per_step': round(dt4 / 5 * 1e3, 3),
                                    'contact_px_per_step': px4,
                                    'chain_frac_of_hbm_peak': round(26.0 * px4 * 6 * 5 / (cw * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   # (SURVEY 8(d)'s 26 B per image-px count every pixel of every image; with the tiles below the diagonal,
+                                   #  the shared blocks and the unread grey tiles not computed the contract figure can exceed what any
+                                   #  hardware could move: then it is marked, as in roofline.kernels, and is not roofline evidence)
+                                   'model_exceeds_work': bool(26.0 * px4 * 6 * 5 / (cw * 1e-3) / 1e9 / HBM_PEAK_GBS > 1.0),
                                    'kernels_ms_per_step': {k: round(v['ms'] / 5, 3) for k, v in s4.items()}}
                 W4.release()
             except Exception as e:      # noqa: BLE001 -- an extra line must not cost the metric line
@@ -551,9 +555,9 @@ def emulated_shares(W, barrier, n, steps=5):
     try:
         for r in range(n):
             W.my_units = W.units_for(n, r)
-            W.step()
-            ms, _ = _timed_steps(W, barrier, steps)
-            out.append(round(ms, 2))
+            W.step(); W.step()
+            ms = min(_timed_steps(W, barrier, steps)[0] for _ in range(2))      # (the lower of two runs: a share is 7 ms, one stray
+            out.append(round(ms, 2))                                            #  host hiccup is a fifth of it)
     finally:
         W.my_units = saved
     return out
