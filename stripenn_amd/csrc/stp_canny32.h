@@ -260,6 +260,7 @@ STP_HD void c32_p1_item(stp_tile T, int xx, int yy0, const stp_w32& W, const flo
                                          kernel would gain from fewer load instructions at unchanged arithmetic) */
             if (k % STP_ABLATE_TD) raw[k] = raw[k - k % STP_ABLATE_TD] * 1.0001f; else
 #endif
+            // (plain loads: neighbouring tiles share their halos through L2 -- read non-temporally the kernel lost 1 ms per step, round 6)
             raw[k] = *(const __attribute__((address_space(1))) float*)((stp_gp)bk + (size_t)boff + (k - k0) * (STP_PITCH * 4));
     }
 #else
