@@ -186,3 +186,42 @@ def test_symmetric_reads_are_used_only_for_symmetric_bands():
         assert _same(g[idx], eg, True) and _same(m[idx], em, False) and _same(t[idx], et, False), name + ': Stripiness vs oracle'
         gb.close()
     hb.close()
+
+
+def test_identical_stripes_are_scored_once_with_the_same_results():
+    """stp_score scores byte-identical rows once and copies the results (round 6: 59 % of a search's candidates repeat another row).
+    A list in which every stripe occurs 1-5 times in random order gives, row by row, what the separate calls give -- which never
+    merge rows -- and the repeats of a row are equal among themselves; a list without repeats takes the plain path."""
+    from stripenn_amd import backend as BK, synth
+    rng = np.random.default_rng(77)
+    nb, bs = 1800, 10
+    ch = synth.SynthChrom(nb, 901, nan_frac=0.01)
+    band_h = ch.band(512)
+    hb = BK.HipBackend(0)
+    gb = hb.open_chrom(band_h)
+    bg = [np.sort(rng.normal(0, 3, (400, 700)), axis=1) for _ in range(4)]
+    hb.set_background(*bg)
+    EV = 240.0 / (1.0 + np.arange(400)) + 1.0 + rng.random(400)
+    pv0, sc0 = _stripes(rng, nb, bs, 300, 190)
+    ok = np.ones(len(pv0), bool)
+    try:
+        hb.stripiness(gb, EV, sc0)
+    except IndexError:                      # (keep only stripes the reference would not raise on: one by one)
+        for i in range(len(pv0)):
+            try:
+                hb.stripiness(gb, EV, sc0[i:i + 1])
+            except IndexError:
+                ok[i] = False
+    pv0, sc0 = pv0[ok], sc0[ok]
+    reps = rng.integers(1, 6, len(pv0))
+    idx = np.repeat(np.arange(len(pv0)), reps)
+    rng.shuffle(idx)
+    pv, sc = pv0[idx], sc0[idx]
+    assert len(pv) > 600
+    p, g, m, t = hb.score(gb, bs, EV, pv, sc)
+    p1 = hb.pvalue(gb, bs, pv)
+    g1, m1, t1 = hb.stripiness(gb, EV, sc)
+    assert _same(p, p1, True) and _same(g, g1, True) and _same(m, m1, True) and _same(t, t1, True)
+    pu, gu, mu, tu = hb.score(gb, bs, EV, pv0, sc0)              # (no repeats)
+    assert _same(p, pu[idx], True) and _same(g, gu[idx], True) and _same(m, mu[idx], True) and _same(t, tu[idx], True)
+    hb.close()
