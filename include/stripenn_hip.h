@@ -145,7 +145,12 @@ void stp_frames_free(stp_ctx* ctx, stp_frames* fr);
  * mean blur + cv.cvtColor grey (:907-913), skimage.feature.canny (:917), ImageProcessing.verticalLine
  * (ImageProcessing.py:61-83), ImageProcessing.block per column (:924-940, ImageProcessing.py:100-195),
  * line joining (:942-1078) and the x/y/w/h/total of each candidate (:1081-1104).
- * Records come out in the reference's row order: frame, level, brightness, ud (1 then 2), X order. */
+ * Records come out in the reference's row order: frame, level, brightness, ud (1 then 2), X order.
+ * What the reference computes twice is computed once, with its results: in a band that is symmetric bit for
+ * bit the Canny class maps of the tiles below an image's diagonal are the transposes of the tiles above it (proved for the f32
+ * verdicts, settled per position for the undecidable pixels); the block of bins two consecutive frames of the batch share is
+ * taken from the later frame where both keep the same bins of it (stp_frames_overlap).  Environment: STP_SYM=0 / STP_REUSE=0
+ * switch these off, STP_CANNY=exact / STP_GRAY=exact select the kernels that perform every operation of the reference. */
 typedef struct {
     int32_t minH;        /* --minL  (getStripe.py:933) */
     int32_t maxW;        /* --maxW  (getStripe.py:1055) */
@@ -270,7 +275,9 @@ int stp_stripiness(stp_ctx* ctx, const stp_band* band, const double* exval400, c
 
 /* ---- p-value AND Stripiness of the same stripes in one call (one upload, one launch, one download): what
  * score.getScore (score.py:52-55) and a driver that scores candidates straight from the search do back to back.
- * pv_stripes[i] / sc_stripes[i] describe stripe i as stp_pvalue / stp_stripiness take it; outputs as theirs. */
+ * pv_stripes[i] / sc_stripes[i] describe stripe i as stp_pvalue / stp_stripiness take it; outputs as theirs.  Rows whose two
+ * descriptors are byte-identical to an earlier row's are not scored again: they receive that row's results (the outputs are a
+ * function of the descriptors alone; a search returns the same rectangle for several brightness images, levels and frames). */
 int stp_score(stp_ctx* ctx, const stp_band* band, const stp_background* bg, int32_t bs, const double* exval400,
               const stp_pv_stripe* pv_stripes, const stp_score_stripe* sc_stripes, int64_t n, double* out_p, double* out_g,
               double* out_oe_mean, double* out_oe_total, int32_t* out_status);
