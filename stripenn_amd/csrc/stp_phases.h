@@ -1046,6 +1046,9 @@ STP_HD stp_u64 stp_runfill(stp_u64 mask, stp_u64 seed)
 // the exact kernel (list overflow, or an image that differs from its transpose) is marked by k_canny_f32 and gets these tiles
 // filled in by k_gray_fill -- every operation of the reference, at the position itself -- before k_canny_pipe_list runs.
 STP_HD bool stp_gray_dead_tile(int gy, int gx) { return gy >= 2 * gx + 5; }
+// (with the frame overlap the rule is applied tile by tile -- stp_gray_tile_unread below, behind the overlap's definitions: the
+//  Canny tiles inside the block shared with the next frame are not computed either, which leaves six more grey tiles without a
+//  reader in an ordinary frame)
 
 // the mark of frame i (host and device run the same code): z0 / z1 = the kept local indices of frames i and i + 1
 STP_HD int stp_overlap_shift(int s0, int n0, int S0, const int16_t* z0, int s1, int n1, int S1, const int16_t* z1)
@@ -1076,6 +1079,25 @@ STP_HD stp_reuse stp_reuse_of(int shift, int S, int R, bool next_in_launch)
 STP_HD bool stp_reuse_tile(stp_reuse U, int ty, int tx)
 {
     return U.lo < U.hi && ty * 32 >= U.lo && ty * 32 + 32 <= U.hi && tx * 64 >= U.lo && tx * 64 + 64 <= U.hi;
+}
+// is Canny tile (ty, tx) of an S x S image computed by k_canny_f32 (not below the diagonal with `mirror`, not inside the shared block)
+STP_HD bool stp_canny_tile_computed(int ty, int tx, int S, int mirror, stp_reuse U)
+{
+    return ty >= 0 && tx >= 0 && ty * 32 < S && tx * 64 < S && !(mirror && ty >= 2 * tx + 2) && !stp_reuse_tile(U, ty, tx);
+}
+// grey tile (gy, gx) has no reader among the computed Canny tiles: none in its 3 x 3 tile neighbourhood (see "grey tiles nobody
+// reads": a Canny tile reads grey values and cells at most 16 pixels beyond its border).  Without the overlap this is
+// stp_gray_dead_tile (gy >= 2 gx + 5); k_gray_c3 does not write such a tile, k_gray_fill fills it in on demand.
+// Only tiles on or below the line gy = 2 gx + 1 are ever skipped (42 of the 91): that is where every unread tile of the
+// reference's frame geometry lies -- the 20 of the symmetry rule and those around the shared block -- and it is the set
+// k_gray_fill's grid walks, so "skipped by k_gray_c3" and "filled in on demand" are the same predicate by construction.
+STP_HD bool stp_gray_tile_unread(int gy, int gx, int S, int mirror, stp_reuse U)
+{
+    if (gy < 2 * gx + 1) return false;
+    for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++)
+            if (stp_canny_tile_computed(gy + dy, gx + dx, S, mirror, U)) return false;
+    return true;
 }
 // the columns of word w of row r that no tile of this frame writes.  With `mirror` (k_canny_f32, image symmetry) a tile
 // strictly below the diagonal (tile row >= 2 x word + 2) receives its two half words from the tiles (2 w + h, r / 64) above

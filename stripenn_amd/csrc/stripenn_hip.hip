@@ -157,26 +157,32 @@ __global__ __launch_bounds__(256) void k_gray(const double* __restrict__ band, i
 {
     gray_tile_exact<AMAX>(band, W, hw, fstart, fS, fnz, f0, Mlev, nlev, bvals, nb, a, gray, cells, blockIdx.x, blockIdx.y, blockIdx.z);
 }
-// The grey tiles k_gray_c3 skipped (stp_gray_dead_tile), for the (frame, level) pairs k_canny_f32 has marked: their tiles below the
-// diagonal go to the exact kernel, which reads its grey windows wherever they lie.  Grid (20 dead tiles, pairs); a pair without
-// a mark -- every pair of ordinary data -- costs its workgroups one byte load.
+// The grey tiles k_gray_c3 skipped (stp_gray_tile_unread), for the (frame, level) pairs k_canny_f32 has marked: their tiles below the
+// diagonal go to the exact kernel, which reads its grey windows wherever they lie.  Grid (the 42 tiles on or below the line
+// gy = 2 gx + 1, where every unread tile lies, pairs); a pair without a mark -- every pair of ordinary data -- costs its
+// workgroups one byte load.
 __global__ __launch_bounds__(256) void k_gray_fill(const double* __restrict__ band, int W, int hw,
                                                     const int32_t* __restrict__ fstart, const int32_t* __restrict__ fS,
                                                     const int16_t* __restrict__ fnz, int f0,
                                                     const double* __restrict__ Mlev, int nlev,
                                                     const double* __restrict__ bvals, int nb,
-                                                    float* __restrict__ gray, const uint8_t* __restrict__ need)
+                                                    float* __restrict__ gray, const uint8_t* __restrict__ need,
+                                                    const int32_t* __restrict__ fshift, int gauss_radius, int nframes)
 {
     const int pair = blockIdx.y;
     if (!need[pair]) return;
     constexpr int tpr = (STP_FRAME_MAX + GT_X - 1) / GT_X, tpc = (STP_FRAME_MAX + GT_Y - 1) / GT_Y;
-    int k = blockIdx.x, tile = -1;                    // the k-th dead tile, row by row
+    int k = blockIdx.x, tile = -1;                    // the k-th tile with gy >= 2 gx + 1, row by row
     for (int t = 0; t < tpr * tpc; t++)
-        if (stp_gray_dead_tile(t / tpr, t % tpr) && k-- == 0) { tile = t; break; }
+        if (t / tpr >= 2 * (t % tpr) + 1 && k-- == 0) { tile = t; break; }
     if (tile < 0) return;
-    gray_tile_exact<1>(band, W, hw, fstart, fS, fnz, f0, Mlev, nlev, bvals, nb, 1, gray, nullptr, tile, pair % nlev, pair / nlev);
+    const int fl = pair / nlev, S = fS[f0 + fl];
+    stp_reuse U; U.lo = 1; U.hi = 0; U.shift = -1;
+    if (fshift != nullptr) U = stp_reuse_of(fshift[f0 + fl], S, gauss_radius, fl + 1 < nframes);
+    if (!stp_gray_tile_unread(tile / tpr, tile % tpr, S, 1, U)) return;               // k_gray_c3 has written it
+    gray_tile_exact<1>(band, W, hw, fstart, fS, fnz, f0, Mlev, nlev, bvals, nb, 1, gray, nullptr, tile, pair % nlev, fl);
 }
-#define STP_GRAY_DEAD_TILES 20      /* tiles with stp_gray_dead_tile in the 13 x 7 grid (checked by a static_assert on the host side) */
+#define STP_GRAY_FILL_TILES 42      /* tiles with gy >= 2 gx + 1 in the 13 x 7 grid (checked by a static_assert on the host side) */
 
 // K-A for the 3 x 3 mean filter, certified (stp_phases.h, "certified grey"): the same tile / strip geometry as k_gray<1> -- one
 // workgroup per (tile, level, frame), the g~ plane of the tile in LDS, each wave an 8-row strip with lane = column and no
@@ -235,7 +241,8 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
                                                   const double* __restrict__ Mlev, int nlev,
                                                   const double* __restrict__ bvals, int nb,
                                                   float* __restrict__ gray, float2* __restrict__ cells,
-                                                  uint8_t* __restrict__ asym /* per image, or null: see gray_c3_redo */, int skip_dead)
+                                                  uint8_t* __restrict__ asym /* per image, or null: see gray_c3_redo */, int skip_dead,
+                                                  const int32_t* __restrict__ fshift /* frame overlap, or null */, int gauss_radius, int nframes)
 {
     constexpr int HH = GT_Y + 2, WW = GT_X + 2, N = HH * WW, IT = (N + 255) / 256;
     __shared__ double sg[N], sd[N];
@@ -251,7 +258,11 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
     stp_tile T;
     T.S = S; T.ty0 = (blockIdx.x / tpr) * GT_Y; T.tx0 = (blockIdx.x % tpr) * GT_X;
     if (T.ty0 >= S || T.tx0 >= S) return;
-    if (skip_dead && stp_gray_dead_tile(blockIdx.x / tpr, blockIdx.x % tpr)) return;       // no reader (stp_phases.h, "grey tiles nobody reads")
+    if (skip_dead) {                                 // no reader among the computed Canny tiles (stp_phases.h, "grey tiles nobody reads")
+        stp_reuse U; U.lo = 1; U.hi = 0; U.shift = -1;
+        if (fshift != nullptr) U = stp_reuse_of(fshift[f], S, gauss_radius, fl + 1 < nframes);
+        if (stp_gray_tile_unread(blockIdx.x / tpr, blockIdx.x % tpr, S, 1, U)) return;
+    }
     const int tid = threadIdx.x;
     if (tid >= 128 && tid < 128 + NCB && tid - 128 < nb) s_cb[tid - 128] = stp_gray_cb(bvals[tid - 128]);   // (read after the barriers below)
     const int16_t* nzf = fnz + (size_t)f * STP_FRAME_MAX;
@@ -2912,7 +2923,7 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
     // points return whole grey images and keep them
     const int skip_dead = mirror && !want_dbg && !whole_gray;
     uint8_t* p_need = skip_dead ? p_asym + nimg : nullptr;
-    static_assert([] { int n = 0; for (int t = 0; t < 91; t++) n += (t / 7 >= 2 * (t % 7) + 5); return n; }() == STP_GRAY_DEAD_TILES    /* stp_gray_dead_tile */
+    static_assert([] { int n = 0; for (int t = 0; t < 91; t++) n += (t / 7 >= 2 * (t % 7) + 1); return n; }() == STP_GRAY_FILL_TILES
                   && ((STP_FRAME_MAX + GT_X - 1) / GT_X) == 7 && ((STP_FRAME_MAX + GT_Y - 1) / GT_Y) == 13, "k_gray_fill's grid");
     // Frame overlap: k_canny_f32 skips the tiles inside the block a frame shares with its successor, k_lines fetches their class
     // words from the successor's planes (STP_REUSE=0 switches it off)
@@ -2939,7 +2950,7 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
         const int tiles = ((STP_FRAME_MAX + GT_X - 1) / GT_X) * ((STP_FRAME_MAX + GT_Y - 1) / GT_Y);
         if (a == 1 && !gray_exact)
             hipLaunchKernelGGL(k_gray_c3, dim3(tiles, STP_GRAY_LEVRUNS < nlev ? STP_GRAY_LEVRUNS : nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
-                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (float2*)p_cells, p_asym, skip_dead);
+                               fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (float2*)p_cells, p_asym, skip_dead, p_shift, R, nf);
         else if (a == 1)
             hipLaunchKernelGGL(k_gray<1>, dim3(tiles, nlev, nf), dim3(256), 0, ctx->stream, band->d, band->W, band->hw,
                                fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, a, d_gray, (float2*)p_cells);
@@ -2969,8 +2980,8 @@ static int run_chain(stp_ctx* ctx, const stp_frames* fr, const stp_search_params
 #define STP_X(RR) case RR: \
                 hipLaunchKernelGGL(k_canny_f32<RR>, dim3(pgrid), dim3(256), smem, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, d_w, \
                                    d_low, d_high, W32, (const float2*)p_cells, (uint8_t*)p_x, mirror, (const uint8_t*)p_asym, p_shift, p_need); \
-                if (p_need) hipLaunchKernelGGL(k_gray_fill, dim3(STP_GRAY_DEAD_TILES, (unsigned)(nf * nlev)), dim3(256), 0, ctx->stream, band->d, band->W, \
-                                               band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (const uint8_t*)p_need); \
+                if (p_need) hipLaunchKernelGGL(k_gray_fill, dim3(STP_GRAY_FILL_TILES, (unsigned)(nf * nlev)), dim3(256), 0, ctx->stream, band->d, band->W, \
+                                               band->hw, fr->d_start, fr->d_S, fr->d_nz, f0, d_M, nlev, d_b, nb, d_gray, (const uint8_t*)p_need, p_shift, R, nf); \
                 hipLaunchKernelGGL(k_canny_pipe_list<RR>, dim3(xgrid), dim3(256), smem_x, ctx->stream, d_gray, fr->d_S, f0, nf, nlev, nb, \
                                    d_w, d_low, d_high, fd, (uint8_t*)p_x, p_asym); \
                 break;

@@ -391,6 +391,31 @@ long long emu_class_word_cover(int S, int shift, int R, int mirror, int next_in_
     return bad;
 }
 
+// Round 6 invariant: every grey value and every grey cell a COMPUTED Canny tile reads -- its window grown by R + 2 pixels, the
+// 8 x 16 cells overlapping it -- lies in a grey tile k_gray_c3 writes (not stp_gray_tile_unread).  Returns the number of
+// (Canny tile, grey tile) pairs that violate it; *skipped = grey tiles inside the image that are not written.
+long long emu_gray_reader_cover(int S, int shift, int R, int next_in_launch, int* skipped)
+{
+    const stp_reuse U = stp_reuse_of(shift, S, R, next_in_launch != 0);
+    long long bad = 0;
+    int nskip = 0;
+    for (int gy = 0; gy * GT_Y < S; gy++)
+        for (int gx = 0; gx * GT_X < S; gx++) nskip += stp_gray_tile_unread(gy, gx, S, 1, U) ? 1 : 0;
+    for (int ty = 0; ty * CT_Y < S; ty++)
+        for (int tx = 0; tx * CT_X < S; tx++) {
+            if (!stp_canny_tile_computed(ty, tx, S, 1, U)) continue;
+            const int wy0 = std::max(ty * CT_Y - R - 2, 0), wy1 = std::min(ty * CT_Y + CT_Y + R + 2, S);
+            const int wx0 = std::max(tx * CT_X - R - 2, 0), wx1 = std::min(tx * CT_X + CT_X + R + 2, S);
+            const int y0 = wy0 / GC_CY * GC_CY, y1 = std::min(((wy1 - 1) / GC_CY + 1) * GC_CY, S);       // the cells' extent
+            const int x0 = wx0 / GC_CX * GC_CX, x1 = std::min(((wx1 - 1) / GC_CX + 1) * GC_CX, S);
+            for (int gy = y0 / GT_Y; gy * GT_Y < y1; gy++)
+                for (int gx = x0 / GT_X; gx * GT_X < x1; gx++)
+                    if (stp_gray_tile_unread(gy, gx, S, 1, U)) bad++;
+        }
+    if (skipped) *skipped = nskip;
+    return bad;
+}
+
 struct emu_rec { int32_t ud, x, y, w, h; double total; };
 
 // mirror of k_lines; dbg: E, V, T1, T2 bit matrices (each 400*7 words); cols: t, end, ud (3 x 400)

@@ -486,3 +486,19 @@ def test_every_class_word_has_exactly_one_writer(emu):
                     assert emu.emu_class_word_cover(S, shift, R, mirror, 0) == 0, (S, shift, R, mirror, 'next frame in another launch')
                     n += 1
     assert n > 4000
+
+
+def test_every_grey_value_a_computed_canny_tile_reads_is_written(emu):
+    """Round 6 invariant ("grey tiles nobody reads"): for every image size, shared-block position and radius, the grey tiles
+    k_gray_c3 skips (stp_gray_tile_unread) are disjoint from the windows and cells of the Canny tiles k_canny_f32 computes; a full
+    frame without a shared block skips the 20 tiles of the symmetry rule, an ordinary frame six more."""
+    emu.emu_gray_reader_cover.restype = C.c_longlong
+    sk = C.c_int(0)
+    for S in list(range(11, 80, 7)) + list(range(80, 401, 3)):
+        for R in (4, 8, 12):
+            assert emu.emu_gray_reader_cover(S, -1, R, 1, C.byref(sk)) == 0, (S, R)
+            for shift in (0, 1, S // 3, S // 2 - 1, S // 2, S // 2 + 3, max(S - 150, 0), max(S - 64, 0)):
+                assert emu.emu_gray_reader_cover(S, shift, R, 1, C.byref(sk)) == 0, (S, shift, R)
+                assert emu.emu_gray_reader_cover(S, shift, R, 0, C.byref(sk)) == 0, (S, shift, R)
+    assert emu.emu_gray_reader_cover(400, -1, 8, 1, C.byref(sk)) == 0 and sk.value == 20
+    assert emu.emu_gray_reader_cover(398, 198, 8, 1, C.byref(sk)) == 0 and sk.value == 26
