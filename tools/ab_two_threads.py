@@ -73,7 +73,8 @@ def timed(fn, n=10):
 
 
 W.reset_stats(profiling=True); hb2.ctx.set_profiling(True)
+only2 = 'only2' in sys.argv            # (for a kernel trace of the two-thread steps alone: tools/overlap_analysis.py)
 for rep in range(2):
-    ms1, r1 = timed(lambda: W.step()[0])
+    ms1, r1 = (0.0, 0) if only2 else timed(lambda: W.step()[0])
     ms2, r2 = timed(step_two_threads)
     print('one thread: %.2f ms per step (%d records); two threads, two contexts: %.2f ms per step (%d records)' % (ms1, r1, ms2, r2), flush=True)
