@@ -9,8 +9,10 @@ the timed region.
 
 A "step" = one pass of the GPU hot path over the rank's share of the genome: per chromosome (or frame span
 of one) frame compaction + medpixel -> image build / Canny / line joining for every (frame, level,
-brightness) -> candidate records on the host -> p-value + Stripiness kernels for every candidate.  Every step drains (its last
-candidate is scored) before the next one starts.
+brightness) -> candidate records on the host -> p-value + Stripiness kernels for every candidate.  The K timed steps run as
+ONE pipeline between the two barriers (the first units of step s + 1 are launched while the last units of step s are collected
+and scored; every record of every step is collected, every candidate scored inside the timed region); the line also carries the
+figure with every step drained before the next one starts (config.drained_ms_per_step; STP_BENCH_PIPELINE_STEPS=0 times that).
 
 N > 1 (`--gpus N`): STRONG scaling of the same genome.  The (chromosome x frame) grid is cut into N
 contiguous spans of equal frame count (stripenn_amd.shard.frame_spans; all maxpixel levels of a frame stay
@@ -274,8 +276,15 @@ def main():
     W.reset_stats()
     barrier()
     t0 = time.perf_counter()
-    if os.environ.get('STP_BENCH_PIPELINE_STEPS') == '1':        # (diagnostic: the K steps as ONE pipeline, no drain between two steps --
-        nrec, contact_px = W.run(args.steps)                     #  71.0 against 71.8 ms per step in round 5: fill and drain are 1 % of a step)
+    # The K timed steps are ONE pipeline (bracketed by the barriers, as the contract says): the first units of step s + 1 are
+    # launched while the last units of step s are collected and scored -- what a training loop's asynchronous launches do, and
+    # what a study of several samples through one process does.  Every record of every step is collected and every candidate
+    # scored inside the timed region.  STP_BENCH_PIPELINE_STEPS=0 drains every step before the next one starts (rounds 1-5 and
+    # the first half of round 6 reported that; the N = 1 line still carries it: config.drained_ms_per_step): 43.7 against 42.5 ms
+    # for the whole genome, 6.2-6.6 against 5.3-5.75 ms for a 1/8 share (profiles/r06_ab_pipelined_steps.txt).
+    pipelined = os.environ.get('STP_BENCH_PIPELINE_STEPS', '1') != '0'
+    if pipelined:
+        nrec, contact_px = W.run(args.steps)
     else:
         for _ in range(args.steps):                              # every step drains before the next one starts
             nrec, contact_px = W.step()
@@ -284,6 +293,9 @@ def main():
     stats = W.stats()
     host_wait_ms = W.host_wait_s / (args.steps + args.warmup) * 1e3      # (the warm-up steps count too: same work)
     host_call_ms = W.host_call_s / (args.steps + args.warmup) * 1e3
+    drained_ms = None
+    if world == 1 and pipelined:                    # the same steps, each drained before the next one starts (what earlier rounds reported)
+        drained_ms = round(_timed_steps(W, barrier, min(args.steps, 10))[0], 3)
     dt, total_px, total_rec, rank_ms = dt_rank, contact_px, nrec, [dt_rank / args.steps * 1e3]
     if world > 1:
         tmax = torch.tensor([dt_rank], dtype=torch.float64, device=rdev)
@@ -400,8 +412,8 @@ def main():
                           'host_blocked_ms_per_step': round(host_wait_ms + host_call_ms, 2),   # ... and inside every blocking device call (searches, frame preparation, p-value, Stripiness); the rest is Python / numpy work (score inputs, bookkeeping)
                           'score_thread': W._thr is not None,                    # p-value / Stripiness calls on a host thread and context of their own
                           'search_contexts': 2 if W.two_ctx else 1,              # contexts (streams, workspaces) taking alternate units
-                          'steps_pipelined': os.environ.get('STP_BENCH_PIPELINE_STEPS') == '1',
-
+                          'steps_pipelined': pipelined,                          # the K timed steps run as one pipeline (no drain between two steps)
+                          'drained_ms_per_step': drained_ms,                     # ... and the same steps with every step drained
                           'comm': comm, 'comm_note': comm_note, 'devices': devnames,
                           'library': hip.LIB_PATH,
                           'arithmetic': ('line joining, scoring: f64 as the reference; grey images: '
@@ -448,7 +460,9 @@ def main():
         if world == 1 and not args.no_extras and not exact_env and not args.emulate_rank:
             out['ab_round6'] = ab_round6(W, barrier)
             if not args.bins and args.workload == 'genome':
-                out['emulated_shares_ms'] = emulated_shares(W, barrier, 8)
+                out['emulated_shares_ms'] = emulated_shares(W, barrier, 8, pipelined=pipelined)
+                if pipelined:
+                    out['emulated_shares_drained_ms'] = emulated_shares(W, barrier, 8, steps=5, pipelined=False)
         if world == 1 and not args.no_extras and not exact_env and not args.emulate_rank and not args.bins and args.workload == 'genome':
             try:
                 out['regimes'] = regimes_extra(hb, dev, args.canny, barrier)
@@ -509,11 +523,14 @@ def main():
         dist.destroy_process_group()
 
 
-def _timed_steps(W, barrier, n):
+def _timed_steps(W, barrier, n, pipelined=False):
     W.reset_stats(); barrier()
     t0 = time.perf_counter()
-    for _ in range(n):
-        W.step()
+    if pipelined:
+        W.run(n)
+    else:
+        for _ in range(n):
+            W.step()
     barrier()
     return (time.perf_counter() - t0) / n * 1e3, W.stats()
 
@@ -550,18 +567,19 @@ def ab_round6(W, barrier, steps=5):
             'runs': res, 'records_equal': all(v == sha['neither'] for v in sha.values()), 'records_sha256': sha}
 
 
-def emulated_shares(W, barrier, n, steps=5):
+def emulated_shares(W, barrier, n, steps=10, pipelined=True):
     """ms per step of each of the n shares an n-rank run would cut the genome into, one after the other ALONE on this GPU
-    (diagonal: per-rank fixed costs -- pipeline fill and drain, launch tails -- without an n-GPU node).  NOT a multi-GPU
-    measurement and no scaling claim: eight real ranks share host cores, PCIe and power."""
+    (diagnostic: per-rank fixed costs -- pipeline fill and drain, launch tails -- without an n-GPU node), timed as the metric is
+    (`pipelined`: the steps as one pipeline) or with every step drained.  NOT a multi-GPU measurement and no scaling claim:
+    eight real ranks share host cores, PCIe and power."""
     saved = W.my_units
     out = []
     try:
         for r in range(n):
             W.my_units = W.units_for(n, r)
             W.step(); W.step()
-            ms = min(_timed_steps(W, barrier, steps)[0] for _ in range(2))      # (the lower of two runs: a share is 7 ms, one stray
-            out.append(round(ms, 2))                                            #  host hiccup is a fifth of it)
+            ms = min(_timed_steps(W, barrier, steps, pipelined)[0] for _ in range(2))   # (the lower of two runs: a share is 6 ms, one stray
+            out.append(round(ms, 2))                                                    #  host hiccup is a fifth of it)
     finally:
         W.my_units = saved
     return out
@@ -799,9 +817,9 @@ class _Workload:
     def run(self, nsteps, digest=None):
         """`nsteps` steps (each: every unit of this rank once).  Two searches are kept in flight: while the device runs the
         chain of unit u+1 (and u+2 is queued behind it), the host collects the records of unit u, builds the score inputs and
-        enqueues its p-value / Stripiness kernel -- the single in-order stream never runs dry.  The benchmark calls run(1) per
-        step (the pipeline drains at every step's end); with nsteps > 1 (STP_BENCH_PIPELINE_STEPS=1, a diagnostic) the first
-        units of step s + 1 are launched while the last units of step s are collected and scored.  All work is finished when
+        enqueues its p-value / Stripiness kernel -- the single in-order stream never runs dry.  run(1) = one step that drains at
+        its end; with nsteps > 1 (the benchmark's timed region) the first units of step s + 1 are launched while the last units
+        of step s are collected and scored.  All work is finished when
         run() returns.  Returns the records and contact pixels of ONE step (every step does the same work)."""
         nrec, px = 0, 0.0
         nu = len(self.my_units)
