@@ -740,8 +740,11 @@ class _Workload:
         for ci, f0, f1 in spans:
             n, k = f1 - f0, -(-(f1 - f0) // piece)
             units += [(ci, f0 + (n * j) // k, f0 + (n * (j + 1)) // k) for j in range(k)]
-        if os.environ.get('STP_BENCH_ORDER', 'size') != 'file':
+        order = os.environ.get('STP_BENCH_ORDER', 'size')
+        if order != 'file':
             units.sort(key=lambda u: -(u[2] - u[1]))
+        if order == 'interleave':              # (A/B hook: large and small units alternate -- the host's per-unit work of a small unit hides behind a large one's chain)
+            units = [units[i // 2] if i % 2 == 0 else units[len(units) - 1 - i // 2] for i in range(len(units))]
         return units
 
     def _score_loop(self):

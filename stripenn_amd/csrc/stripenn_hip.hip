@@ -562,6 +562,9 @@ __global__ __launch_bounds__(256) void k_canny(const float* __restrict__ gray, c
 #ifndef STP_CANNY_MINBLK
 #define STP_CANNY_MINBLK 4
 #endif
+// (radius 12 -- sigma 3.0, reached under STP_CANNY=exact or through the redo list only -- needs more than the 128 registers four
+//  workgroups per CU leave a lane: three workgroups, no scratch)
+#define STP_CANNY_MINBLK_OF(RT) ((RT) >= 12 ? 3 : STP_CANNY_MINBLK)
 static __host__ __device__ size_t canny_pipe_smem_bytes(int R)
 {
     const int GW = CT_X + 2 * R + 4, VH = CT_Y + 4;
@@ -721,7 +724,7 @@ __device__ __forceinline__ void canny_pipe_tile(const float* __restrict__ gray, 
 
 
 template <int RT>
-__global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
+__global__ __launch_bounds__(256, STP_CANNY_MINBLK_OF(RT)) void k_canny_pipe(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
                                                      int nf, int nlev, int nb, const double* __restrict__ gw,
                                                      stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_fastdiv fd,
                                                      const float2* __restrict__ cells)
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe(const floa
 // pixels were undecidable in f32 than its lists take (plateaus, exact ties).  xflags[image * 91 + tile] != 0 (image
 // counted within the launch); a fixed grid scans the flags.
 template <int RT>
-__global__ __launch_bounds__(256, STP_CANNY_MINBLK) void k_canny_pipe_list(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
+__global__ __launch_bounds__(256, STP_CANNY_MINBLK_OF(RT)) void k_canny_pipe_list(const float* __restrict__ gray, const int32_t* __restrict__ fS, int f0,
                                                      int nf, int nlev, int nb, const double* __restrict__ gw,
                                                      stp_u64* __restrict__ low, stp_u64* __restrict__ high, stp_fastdiv fd,
                                                      uint8_t* __restrict__ xflags, uint8_t* __restrict__ asym)
@@ -3167,6 +3170,8 @@ static int search_enqueue(stp_ctx* ctx, stp_search* s)
     // the count travels with as many records as the previous search of this context produced (+25 %): one round trip
     // in the common case
     s->guess = std::min(s->guess, (s->pin_bytes - s->rec_off) / sizeof(stp_stripe_rec));
+    // (measured and dropped in round 6: the two copies on the transfer stream behind an event, so that they do not stand between this
+    //  search's last kernel and the next search's first -- 42.2 ms per genome step either way, profiles/r06_ab_pipeline.txt)
     HIPCHK(hipMemcpyAsync(s->pin, s->d_tot + 2 * s->nchunks, 2 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
     if (s->guess)
         HIPCHK(hipMemcpyAsync((char*)s->pin + s->rec_off, s->d_out, s->guess * sizeof(stp_stripe_rec), hipMemcpyDeviceToHost, ctx->stream));
