@@ -262,6 +262,9 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
         stp_reuse U; U.lo = 1; U.hi = 0; U.shift = -1;
         if (fshift != nullptr) U = stp_reuse_of(fshift[f], S, gauss_radius, fl + 1 < nframes);
         if (stp_gray_tile_unread(blockIdx.x / tpr, blockIdx.x % tpr, S, 1, U)) return;
+#if defined(STP_ABLATE_GRAY_LOWER)      /* timing-only build: what not writing ANY grey tile below the diagonal would save (results wrong) */
+        if ((int)(blockIdx.x / tpr) >= 2 * (int)(blockIdx.x % tpr) + 2) return;
+#endif
     }
     const int tid = threadIdx.x;
     if (tid >= 128 && tid < 128 + NCB && tid - 128 < nb) s_cb[tid - 128] = stp_gray_cb(bvals[tid - 128]);   // (read after the barriers below)
