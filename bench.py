@@ -734,8 +734,12 @@ class _Workload:
         # per-unit work (frame preparation, record fetch, score inputs, one blocking score call) for microseconds of device time:
         # 8.8 / 9.0 ms for shares 5 / 7 of 8.  Now: shard.frame_spans leaves no slivers (cuts snap onto chromosome boundaries), and
         # a chromosome piece is cut into the fewest EQUAL parts of at most 128 frames: 3-5 units per share, 7.2-7.6 ms.
+        # With the timed steps pipelined (the default since the second half of round 6) nothing drains between two steps and a share is
+        # HOST-bound (the search thread waits for the device 0.15 of 5.5 ms): fewer, larger units win -- one device chunk (204 frames)
+        # per unit: 5.2-5.65 ms for the eight shares against 5.3-6.1 with <= 128 frames (profiles/r06_shares_matrix_pipelined.txt).
         whole = world == 1
-        piece = max(1, int(os.environ.get('STP_BENCH_PIECE', '204' if whole else '128')))
+        pipelined = os.environ.get('STP_BENCH_PIPELINE_STEPS', '1') != '0'
+        piece = max(1, int(os.environ.get('STP_BENCH_PIECE', '204' if whole or pipelined else '128')))
         units = []
         for ci, f0, f1 in spans:
             n, k = f1 - f0, -(-(f1 - f0) // piece)
