@@ -981,6 +981,9 @@ __global__ __launch_bounds__(256, STP_C32_MINBLK) void k_canny_f32(const float* 
     // (the mirror geometry is re-derived from the block index where it is needed -- c32_mgeo -- so that nothing of it lives
     //  across the image loop: held there it cost radius 8 three spilled registers)
     if (mirror && tile / tpr >= 2 * (tile % tpr) + 2) return;
+#if defined(STP_ABLATE_C32_TX6)        /* timing-only build: what the 13 tiles of the last tile column (16 of their 64 columns inside a 400-pixel image) cost */
+    if (tile % tpr == 6) return;
+#endif
     // Frame overlap (stp_phases.h): a tile inside the block this frame shares with the next one is not computed -- k_lines takes
     // its class words (and the words of the tiles below the diagonal its transpose would have covered) from the next frame's planes
     if (fshift != nullptr && stp_reuse_tile(stp_reuse_of(fshift[f0 + fl], S, R, fl + 1 < nf), tile / tpr, tile % tpr)) return;
