@@ -266,6 +266,9 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
         if ((int)(blockIdx.x / tpr) >= 2 * (int)(blockIdx.x % tpr) + 2) return;
 #endif
     }
+#if defined(STP_ABLATE_GRAY_TX6)            /* timing-only build: what the tiles of the last tile column (16 of 64 columns in the image) cost */
+    if ((int)(blockIdx.x % tpr) == 6) return;
+#endif
     const int tid = threadIdx.x;
     if (tid >= 128 && tid < 128 + NCB && tid - 128 < nb) s_cb[tid - 128] = stp_gray_cb(bvals[tid - 128]);   // (read after the barriers below)
     const int16_t* nzf = fnz + (size_t)f * STP_FRAME_MAX;
@@ -291,6 +294,10 @@ __global__ __launch_bounds__(256) void k_gray_c3(const double* __restrict__ band
             if (i < N) sd[i] = (v[k] != v[k]) ? 0.0 : v[k];                  // nantozero (getStripe.py:809)
         }
     }
+    // (round 6, measured and dropped: in the last tile column -- 16 image columns, one cell's width -- the first wave taking all four
+    //  strips with 16 lanes each, the other waves idle in the image loop: bit-identical images, 10.7 ms per step against 10.5.  The 13
+    //  tiles of that column cost 1.07 ms per step for 4 % of the pixels (timing-only build, profiles/r06_ablate_gray_last_column.txt),
+    //  but not through the image loop's issue slots.)
     const int lane = tid & 63, strip = tid >> 6;
     const int x = T.tx0 + lane, y0 = T.ty0 + strip * GS_ROWS;
     const bool xin = x < S;
