@@ -334,6 +334,21 @@ int stp_remove_redundant(stp_ctx* ctx, int64_t n, const int64_t* pos1, const int
                          const int32_t* order, const int32_t* b0, const int32_t* b1, const int32_t* b2,
                          uint8_t* keep);
 
+/* ---- result tables as text: `df.to_csv(path, sep='\t', header=True, index=False)` (stripenn.py:156-157, score.py:60) ----
+ * Formats nrows rows of ncols columns as tab-separated lines ('\n' behind every row; no header) into out[0 .. cap).
+ * kind[c] = STP_COL_I64: data[c] is const int64_t[nrows], written in decimal;
+ *           STP_COL_F64: const double[nrows], written as pandas writes a float64 column -- Python's repr(float): the shortest
+ *                        digits that round-trip, exponent form below 1e-4 and from 1e16 on, ".0" behind an integral value --
+ *                        NaN as the empty field;
+ *           STP_COL_STR: const int32_t[nrows] codes 0 .. nstr[c]-1 into the column's string table: string k is the bytes
+ *                        strtab[c][stroff[c][k] .. stroff[c][k+1]) (the caller has checked that none needs quoting).
+ * strtab / stroff / nstr are read for STP_COL_STR columns only.  *out_len = bytes written, or, with STP_E_CAPACITY, nothing
+ * usable.  Host code only (no context, no device): `stripenn_amd.stripenn.write_tsv` calls it and keeps a Python writer for
+ * tables it does not describe (mixed cells, fields that need quoting). */
+enum { STP_COL_I64 = 0, STP_COL_F64 = 1, STP_COL_STR = 2 };
+int stp_format_tsv(int32_t ncols, const int32_t* kind, const void* const* data, const char* const* strtab,
+                   const int64_t* const* stroff, const int32_t* nstr, int64_t nrows, char* out, int64_t cap, int64_t* out_len);
+
 /* ---- statistics / profiling ---------------------------------------------------------------
  * When profiling is on, every kernel launch is bracketed by HIP events on the ctx stream. */
 typedef struct {

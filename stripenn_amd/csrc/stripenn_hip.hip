@@ -29,6 +29,7 @@
 #endif
 #include "stp_score.h"
 #include "stp_select.h"
+#include "stp_tsv.h"
 
 // ============================================================================================
 // device kernels
@@ -4126,6 +4127,51 @@ int stp_reset_stats(stp_ctx* ctx)
     if (!ctx) return STP_E_ARG;
     resolve_pending(ctx);
     ctx->stats.clear();
+    return STP_OK;
+}
+
+// Result tables as text (stp_tsv.h): host code only.
+int stp_format_tsv(int32_t ncols, const int32_t* kind, const void* const* data, const char* const* strtab,
+                   const int64_t* const* stroff, const int32_t* nstr, int64_t nrows, char* out, int64_t cap, int64_t* out_len)
+{
+    if (ncols < 0 || nrows < 0 || cap < 0 || !out_len || (ncols > 0 && (!kind || !data)) || (cap > 0 && !out)) return STP_E_ARG;
+    *out_len = 0;
+    // widest a row can get: decides once whether the buffer is large enough (no test per field)
+    int64_t roww = 1;
+    for (int c = 0; c < ncols; c++) {
+        if (!data[c] && nrows > 0) return STP_E_ARG;
+        if (kind[c] == STP_COL_I64) roww += 21;
+        else if (kind[c] == STP_COL_F64) roww += 26;
+        else if (kind[c] == STP_COL_STR) {
+            if (!strtab || !stroff || !nstr || !strtab[c] || !stroff[c] || nstr[c] < 0) return STP_E_ARG;
+            int64_t w = 0;
+            for (int k = 0; k < nstr[c]; k++) {
+                const int64_t l = stroff[c][k + 1] - stroff[c][k];
+                if (l < 0) return STP_E_ARG;
+                w = l > w ? l : w;
+            }
+            roww += w + 1;
+        } else return STP_E_ARG;
+    }
+    if (ncols == 0) return STP_OK;                       // (pandas writes one empty line per row of a table without columns: left to it)
+    if (nrows > 0 && roww > cap / nrows) return STP_E_CAPACITY;
+    char* p = out;
+    for (int64_t r = 0; r < nrows; r++) {
+        for (int c = 0; c < ncols; c++) {
+            if (c) *p++ = '\t';
+            if (kind[c] == STP_COL_I64) p = stp_tsv_i64(p, ((const int64_t*)data[c])[r]);
+            else if (kind[c] == STP_COL_F64) p = stp_tsv_repr(p, ((const double*)data[c])[r]);
+            else {
+                const int32_t k = ((const int32_t*)data[c])[r];
+                if (k < 0 || k >= nstr[c]) return STP_E_ARG;
+                const int64_t o = stroff[c][k], l = stroff[c][k + 1] - o;
+                memcpy(p, strtab[c] + o, (size_t)l);
+                p += l;
+            }
+        }
+        *p++ = '\n';
+    }
+    *out_len = (int64_t)(p - out);
     return STP_OK;
 }
 
