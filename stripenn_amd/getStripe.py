@@ -846,9 +846,20 @@ class getStripe:
         key = code * span + (num - num.min())
         order = np.argsort(key, kind='stable').astype(np.int32)
         skey = key[order]
-        b0 = np.searchsorted(skey, key, 'left').astype(np.int32)
-        b1 = np.searchsorted(skey, key, 'right').astype(np.int32)
-        b2 = b1 if same_frame_only else np.searchsorted(skey, key + 1, 'right').astype(np.int32)
+        # bucket bounds of every row in the sorted order -- searchsorted(skey, key, 'left' / 'right') and, for the next frame number,
+        # searchsorted(skey, key + 1, 'right') -- from the runs of equal keys (one pass instead of three binary searches per row)
+        first = np.flatnonzero(np.concatenate(([True], skey[1:] != skey[:-1])))          # start of every run
+        ends = np.append(first[1:], n)
+        run = np.repeat(np.arange(len(first)), ends - first)                             # run of every sorted position
+        ukey = skey[first]
+        nxt = np.append(ukey[1:] == ukey[:-1] + 1, False)                                # the next run holds key + 1
+        ends2 = np.where(nxt, np.append(ends[1:], n), ends)
+        b0 = np.empty(n, dtype=np.int32); b1 = np.empty(n, dtype=np.int32)
+        b0[order] = first[run]; b1[order] = ends[run]
+        if same_frame_only:
+            b2 = b1
+        else:
+            b2 = np.empty(n, dtype=np.int32); b2[order] = ends2[run]
         p = [np.asarray(df[c], dtype=np.int64) for c in ('pos1', 'pos2', 'pos3', 'pos4')]
         if np.any(p[1] == p[0]) or np.any(p[3] == p[2]):
             raise ZeroDivisionError('division by zero')                  # as the reference (:1142-1143)
