@@ -127,6 +127,8 @@ def _write_tsv_native(df, path):
         if any(ch in str(name) for ch in '\t"\n\r'):
             return False
         a = df[name].to_numpy()
+        if a.ndim != 1:                          # (duplicate column names: pandas)
+            return False
         if a.dtype.kind == 'O':
             kind = pd.api.types.infer_dtype(a, skipna=False)
             if kind == 'integer':
