@@ -190,6 +190,9 @@ def write_tsv(df, path):
     produces -- NaN / None as the empty field; anything this writer is not sure about goes through pandas itself.
     Tables of int / float / plain string columns -- every table the drivers write -- are formatted by the library
     (stp_format_tsv, round 6: 0.060 -> 0.012 s for the two tables of a genome); the Python writer below stays for the rest."""
+    if not df.columns.is_unique:                  # (never from the drivers; both writers below address columns by name)
+        df.to_csv(path, sep='\t', header=True, index=False)
+        return
     if os.environ.get('STP_TSV', '') != 'python' and _write_tsv_native(df, path):
         return
     cols = []

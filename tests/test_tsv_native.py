@@ -69,6 +69,15 @@ def test_both_writers_equal_pandas(tmp_path, monkeypatch, writer):
         assert open(p, newline='').read() == _pandas_bytes(t), tag
 
 
+def test_duplicate_column_names_go_to_pandas(tmp_path, monkeypatch):
+    df = pd.DataFrame([[1, 2.5, 'a'], [3, 4.5, 'b']], columns=['x', 'x', 's'])
+    for writer in ('native', 'python'):
+        monkeypatch.setenv('STP_TSV', writer)
+        p = str(tmp_path / (writer + '.tsv'))
+        write_tsv(df, p)
+        assert open(p, newline='').read() == _pandas_bytes(df)
+
+
 def test_native_writer_declines_what_it_cannot_describe(tmp_path):
     p = str(tmp_path / 'x.tsv')
     assert not _write_tsv_native(pd.DataFrame({'n': ['a\tb', 'c'], 'v': [1.0, 2.0]}), p)            # needs quoting
